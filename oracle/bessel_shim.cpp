@@ -1,0 +1,8 @@
+// bessel_shim.cpp -- TEST INFRASTRUCTURE ONLY (see jinc_oracle.h).
+// The reference evaluates J1 for tap >= 5 with libstdc++'s std::cyl_bessel_j
+// (/root/reference/src/JincResize.cpp:233-234, :242-243).  Plain C has no binding for that routine,
+// so the C oracle reaches the very same library function through this one-line C++ shim.
+// Dependency: libstdc++ (GCC 11.4.0) <cmath> special functions; pinned by the LUT hashes in
+// tests/test_oracle_kat.py.
+#include <cmath>
+extern "C" double oracle_cyl_bessel_j1(double x) { return std::cyl_bessel_j(1, x); }

@@ -1,0 +1,85 @@
+/*
+ * jinc_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the opt=0 hot path of Asd-g/AviSynth-JincResize v2.1.4:
+ * LUT -> coefficient table -> per-plane sequential fp32 gather-MAC.  It is the checker the HIP
+ * path is compared against; it is never linked into, imported by, or called from the product
+ * library.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * Parity pin: SURVEY.md section 8(c) known-answer vectors that were produced by executing the
+ * reference itself (LUT FNV-1a-64 hashes, table hashes, crc32 of opt=0 outputs for configs C1..C4
+ * and the 64x48->160x120 KAT) -- checked in tests/test_oracle_kat.py.
+ *
+ * All "ref:" citations are /root/reference/src/JincResize.cpp unless stated otherwise.
+ */
+#ifndef JINC_ORACLE_H
+#define JINC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ref: JincResize.h:11-16 */
+typedef struct {
+    int start_x;
+    int start_y;
+    int coeff_meta;
+} oracle_meta;
+
+/* ref: JincResize.h:18-25 (factor_map is internal to table generation and is not kept) */
+typedef struct {
+    float *factor;        /* coefficient sets, coeff_stride floats per row, filter_size rows per set */
+    oracle_meta *meta;    /* dst_width*dst_height entries, raster order */
+    int filter_size;
+    int coeff_stride;
+    int dst_width;
+    int dst_height;
+    int64_t factor_count; /* number of floats used in factor (= number of sets * filter_size * coeff_stride) */
+    int64_t cached_phases;/* number of interior phase sets that were cached in factor_map */
+} oracle_table;
+
+/* ref: JincResize.cpp:315-333 (initial_capacity / initial_factor only steer a scratch-growth
+ * heuristic and cannot change results, so they are not part of the oracle) */
+typedef struct {
+    int quantize_x, quantize_y;
+    int samples;
+    int src_width, src_height;
+    int dst_width, dst_height;
+    double radius;
+    double crop_left, crop_top, crop_width, crop_height;
+} oracle_table_params;
+
+/* ref: JincResize.cpp:84-102 */
+double oracle_jinc_zero(int tap);
+/* ref: JincResize.cpp:201-245 */
+double oracle_jinc_sqr(double x2);
+/* ref: JincResize.cpp:265-275. lut must hold lut_size doubles. */
+void oracle_lut_init(double *lut, int lut_size, double radius, double blur);
+/* ref: JincResize.cpp:336-533. Returns 0 on success. */
+int oracle_table_generate(const double *lut, const oracle_table_params *p, oracle_table *out);
+void oracle_table_free(oracle_table *t);
+
+/* ref: JincResize.cpp:536-601 for one plane.  sample_bytes: 1 (uint8), 2 (uint16), 4 (float).
+ * Pitches in bytes.  peak is used for integer planes only (ref :581-582, :793).
+ * threads: 1 = serial rows (thr==1 instantiation); >1 = OpenMP rows (stands in for the PSTL
+ * row fan-out of ref :596-598; the per-pixel arithmetic is identical). */
+void oracle_resize_plane(const void *src, int src_pitch, void *dst, int dst_pitch,
+                         const oracle_table *t, int sample_bytes, float peak, int threads);
+
+/* the synthetic frame generator behind every KAT hash.
+ * 32-bit LCG s = s*1664525 + 1013904223, r = s>>8; one stream across planes.
+ * Fills `height` rows of `width` samples at `pitch` bytes; padding bytes are left untouched.
+ * bits: 8..16 for integer samples (mask (1<<bits)-1), 32 for float ((r&0xffffff)/16777215.0f).
+ * Returns the advanced LCG state. */
+uint32_t oracle_lcg_fill(void *plane, int pitch, int width, int height, int sample_bytes, int bits, uint32_t state);
+
+/* FNV-1a 64-bit over a byte range (used for the LUT / table KATs). */
+uint64_t oracle_fnv1a64(const void *data, size_t n, uint64_t h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
