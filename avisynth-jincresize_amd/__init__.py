@@ -1,0 +1,363 @@
+"""Python host mirror of the AviSynth+ JincResize plugin surface, over libjincresize_hip.so.
+
+The product is the C-ABI library (include/jincresize_hip.h: host C++ + gfx950 HIP kernels); this
+module only binds it with ctypes and mirrors the script-level interface of the reference plugin
+(/root/reference/src/JincResize.cpp:1042-1111): ``JincResize(clip, target_width, target_height,
+src_left, src_top, src_width, src_height, quant_x, quant_y, tap, blur, cplace, threads, opt,
+initial_capacity, initial_factor)`` and the ``Jinc36Resize/Jinc64Resize/Jinc144Resize/
+Jinc256Resize`` aliases.  Errors surface as ``JincError`` carrying the reference's message text.
+
+There is no CPU fallback here: if the library is missing the import fails, and frame calls fail
+loudly when no HIP device is present.
+
+The directory name contains a hyphen, so load it with ``importlib`` (see ``__graft_entry__.py``
+``load_package()``), e.g. as module ``avisynth_jincresize_amd``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjincresize_hip.so")
+ISA_PATH = os.path.join(_HERE, "lib", "kernels-gfx950.s")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
+
+
+def build(jobs: int = 4) -> str:
+    """Compile the HIP/C++ library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", _HERE, f"-j{jobs}"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libjincresize_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    return LIB_PATH
+
+
+class JincError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+# ---- ctypes mirror of include/jincresize_hip.h ---------------------------------------------------
+class VideoInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "bits_per_component", "component_size", "num_components",
+                                       "is_planar", "is_rgb", "sub_w", "sub_h")]
+
+
+class Args(C.Structure):
+    _fields_ = [
+        ("target_width", C.c_int), ("target_height", C.c_int),
+        ("src_left", C.c_double), ("src_top", C.c_double), ("src_width", C.c_double), ("src_height", C.c_double),
+        ("quant_x", C.c_int), ("quant_y", C.c_int), ("tap", C.c_int), ("blur", C.c_double),
+        ("cplace", C.c_char_p), ("threads", C.c_int), ("opt", C.c_int), ("initial_capacity", C.c_int),
+        ("initial_factor", C.c_double), ("defined", C.c_uint),
+        ("frame0_chroma_location", C.c_int),
+        ("cpu_has_sse41", C.c_int), ("cpu_has_avx2", C.c_int), ("cpu_has_avx512f", C.c_int),
+    ]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("src_width", "src_height", "dst_width", "dst_height", "filter_size", "num_sets",
+                                       "periodic", "period_x", "period_y", "step_x", "step_y",
+                                       "interior_x0", "interior_x1", "interior_y0", "interior_y1")] + \
+               [("plan_bytes", C.c_int64)]
+
+
+ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_height": 1 << 3, "quant_x": 1 << 4,
+            "quant_y": 1 << 5, "tap": 1 << 6, "blur": 1 << 7, "cplace": 1 << 8, "threads": 1 << 9, "opt": 1 << 10,
+            "initial_capacity": 1 << 11, "initial_factor": 1 << 12}
+
+EXPORTS = ["jinc_device_count", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
+           "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
+           "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
+           "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode",
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times"]
+
+_lib = None
+_P4 = C.c_void_p * 4
+_I4 = C.c_int * 4
+_S4 = C.c_size_t * 4
+
+
+def lib():
+    """Loads the C-ABI library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc) first")
+        L = C.CDLL(LIB_PATH)
+        L.jinc_device_count.restype = C.c_int
+        L.jinc_last_error.restype = C.c_char_p
+        L.jinc_filter_create.restype = C.c_int
+        L.jinc_filter_create.argtypes = [C.POINTER(VideoInfo), C.POINTER(Args), C.c_int, C.POINTER(C.c_void_p),
+                                         C.c_char_p, C.c_size_t]
+        L.jinc_filter_free.restype = None
+        L.jinc_filter_free.argtypes = [C.c_void_p]
+        L.jinc_filter_output_info.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
+        L.jinc_filter_chroma_location.argtypes = [C.c_void_p]
+        L.jinc_filter_get_frame.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4]
+        L.jinc_filter_process_device.argtypes = [C.c_void_p, _P4, _I4, _S4, _P4, _I4, _S4, C.c_int, C.c_void_p]
+        L.jinc_filter_sync.argtypes = [C.c_void_p]
+        L.jinc_alias_args.argtypes = [C.c_int, C.POINTER(Args), C.POINTER(Args)]
+        L.jinc_filter_num_tables.argtypes = [C.c_void_p]
+        L.jinc_filter_plan_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(PlanInfo)]
+        L.jinc_filter_plan_pixel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                             C.POINTER(C.c_int), C.c_void_p]
+        L.jinc_filter_plan_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jinc_filter_plan_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.jinc_filter_lut.argtypes = [C.c_void_p, C.c_void_p]
+        L.jinc_filter_set_kernel_mode.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().jinc_device_count())
+
+
+# ---- clip / format model (what an AviSynth+ host would provide) -----------------------------------
+@dataclass(frozen=True)
+class Format:
+    name: str
+    bits: int
+    planes: int
+    sub_w: int = 0
+    sub_h: int = 0
+    rgb: bool = False
+
+    @property
+    def sample_bytes(self) -> int:
+        return 1 if self.bits == 8 else (2 if self.bits <= 16 else 4)
+
+    @property
+    def dtype(self):
+        return {1: np.uint8, 2: np.uint16, 4: np.float32}[self.sample_bytes]
+
+    def plane_dims(self, w: int, h: int) -> List[Tuple[int, int]]:
+        dims = [(w, h)]
+        if self.planes >= 3:
+            dims += [(w >> self.sub_w, h >> self.sub_h)] * 2
+        if self.planes == 4:
+            dims.append((w, h))
+        return dims
+
+    def video_info(self, w: int, h: int) -> VideoInfo:
+        return VideoInfo(w, h, self.bits, self.sample_bytes, self.planes, 1, int(self.rgb), self.sub_w, self.sub_h)
+
+
+def _fmts() -> Dict[str, Format]:
+    out = {}
+    for bits, tag in ((8, "8"), (10, "10"), (12, "12"), (14, "14"), (16, "16"), (32, "S")):
+        out[f"Y{tag if bits != 32 else '32'}"] = Format(f"Y{tag if bits != 32 else '32'}", bits, 1)
+        for fam, sw, sh in (("420", 1, 1), ("422", 1, 0), ("444", 0, 0), ("411", 2, 0)):
+            out[f"YUV{fam}P{tag}"] = Format(f"YUV{fam}P{tag}", bits, 3, sw, sh)
+            out[f"YUVA{fam}P{tag}"] = Format(f"YUVA{fam}P{tag}", bits, 4, sw, sh)
+        out[f"RGBP{tag}"] = Format(f"RGBP{tag}", bits, 3, rgb=True)
+        out[f"RGBAP{tag}"] = Format(f"RGBAP{tag}", bits, 4, rgb=True)
+    out["YV12"], out["YV16"], out["YV24"], out["YV411"] = out["YUV420P8"], out["YUV422P8"], out["YUV444P8"], out["YUV411P8"]
+    return out
+
+
+FORMATS = _fmts()
+
+
+def alloc_plane(w: int, h: int, dtype, align: int = 64) -> np.ndarray:
+    """Host plane with an AviSynth+-style pitch (row size rounded up to 64 bytes)."""
+    isz = np.dtype(dtype).itemsize
+    pitch = (w * isz + align - 1) // align * align
+    return np.zeros((h, pitch // isz), dtype=dtype)
+
+
+@dataclass
+class Clip:
+    """Minimal stand-in for an AviSynth clip: format, size, and a frame source returning planes in the
+    reference's processing order (Y,U,V,A or G,B,R,A; ref JincResize.cpp:539-541)."""
+    fmt: Format
+    width: int
+    height: int
+    num_frames: int
+    source: Callable[[int], Sequence[np.ndarray]]
+    props: Dict[str, int] = field(default_factory=dict)  # frame properties of frame 0 (e.g. _ChromaLocation)
+    planar: bool = True
+
+    def get_frame(self, n: int) -> Sequence[np.ndarray]:
+        return self.source(n)
+
+
+class Filter:
+    """One filter instance (= one `JincResize` object of the reference)."""
+
+    def __init__(self, fmt: Format, width: int, height: int, target_width: int, target_height: int, *,
+                 device: int = 0, frame0_chroma_location: int = -1, planar: bool = True,
+                 cpu_flags: Tuple[bool, bool, bool] = (True, True, True), alias_taps: Optional[int] = None, **kw):
+        self.fmt = fmt
+        vi = fmt.video_info(width, height)
+        vi.is_planar = int(planar)
+        a = Args()
+        a.target_width, a.target_height = int(target_width), int(target_height)
+        a.frame0_chroma_location = int(frame0_chroma_location)
+        a.cpu_has_sse41, a.cpu_has_avx2, a.cpu_has_avx512f = (int(bool(x)) for x in cpu_flags)
+        self._keep = []
+        for k, v in kw.items():
+            if k not in ARG_BITS:
+                raise TypeError(f"JincResize: unknown argument {k!r}")
+            if v is None:
+                continue
+            a.defined |= ARG_BITS[k]
+            if k == "cplace":
+                b = str(v).encode()
+                self._keep.append(b)
+                a.cplace = b
+            else:
+                setattr(a, k, v)
+        if alias_taps is not None:
+            b = Args()
+            rc = lib().jinc_alias_args(int(alias_taps), C.byref(a), C.byref(b))
+            if rc != 0:
+                raise JincError(rc, lib().jinc_last_error().decode())
+            a = b
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().jinc_filter_create(C.byref(vi), C.byref(a), int(device), C.byref(self._h), err, len(err))
+        if rc != 0:
+            raise JincError(rc, err.value.decode())
+        out = VideoInfo()
+        lib().jinc_filter_output_info(self._h, C.byref(out))
+        self.src_w, self.src_h = width, height
+        self.dst_w, self.dst_h = out.width, out.height
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().jinc_filter_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise JincError(rc, lib().jinc_last_error().decode())
+
+    @property
+    def chroma_location(self) -> int:
+        return int(lib().jinc_filter_chroma_location(self._h))
+
+    def out_dims(self) -> List[Tuple[int, int]]:
+        return self.fmt.plane_dims(self.dst_w, self.dst_h)
+
+    def set_kernel_mode(self, mode: int) -> None:
+        self._check(lib().jinc_filter_set_kernel_mode(self._h, mode))
+
+    # -- GetFrame on host planes (H2D, kernels, D2H) --
+    def get_frame(self, src_planes: Sequence[np.ndarray]) -> List[np.ndarray]:
+        n = self.fmt.planes
+        outs = [alloc_plane(w, h, self.fmt.dtype) for (w, h) in self.out_dims()]
+        sp, spitch, dp, dpitch = _P4(), _I4(), _P4(), _I4()
+        for i in range(n):
+            s = src_planes[i]
+            if s.dtype != self.fmt.dtype:
+                raise TypeError("plane dtype does not match the clip format")
+            sp[i], spitch[i] = s.ctypes.data, s.strides[0]
+            dp[i], dpitch[i] = outs[i].ctypes.data, outs[i].strides[0]
+        self._check(lib().jinc_filter_get_frame(self._h, sp, spitch, dp, dpitch))
+        return outs
+
+    # -- device-resident batch (pointers are raw device addresses) --
+    def process_device(self, src_ptrs, src_pitches, src_strides, dst_ptrs, dst_pitches, dst_strides, nframes: int,
+                       stream: int = 0) -> None:
+        sp, spitch, ss, dp, dpitch, ds = _P4(), _I4(), _S4(), _P4(), _I4(), _S4()
+        for i in range(self.fmt.planes):
+            sp[i], spitch[i], ss[i] = src_ptrs[i], src_pitches[i], src_strides[i]
+            dp[i], dpitch[i], ds[i] = dst_ptrs[i], dst_pitches[i], dst_strides[i]
+        self._check(lib().jinc_filter_process_device(self._h, sp, spitch, ss, dp, dpitch, ds, int(nframes),
+                                                     C.c_void_p(stream)))
+
+    def set_profiling(self, enable: bool) -> None:
+        self._check(lib().jinc_filter_set_profiling(self._h, int(enable)))
+
+    def kernel_times(self):
+        """(periodic_ms, periodic_launches, gather_ms, gather_launches) since the last call."""
+        pm, gm, pn, gn = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+        self._check(lib().jinc_filter_kernel_times(self._h, C.byref(pm), C.byref(pn), C.byref(gm), C.byref(gn)))
+        return pm.value, pn.value, gm.value, gn.value
+
+    def sync(self) -> None:
+        self._check(lib().jinc_filter_sync(self._h))
+
+    # -- plan introspection --
+    @property
+    def num_tables(self) -> int:
+        return int(lib().jinc_filter_num_tables(self._h))
+
+    def plan_info(self, table: int = 0) -> PlanInfo:
+        info = PlanInfo()
+        self._check(lib().jinc_filter_plan_info(self._h, table, C.byref(info)))
+        return info
+
+    def plan_dump(self, table: int = 0):
+        info = self.plan_info(table)
+        sx = np.zeros(info.dst_width, np.int32)
+        sy = np.zeros(info.dst_height, np.int32)
+        ids = np.zeros((info.dst_height, info.dst_width), np.int32)
+        self._check(lib().jinc_filter_plan_dump(self._h, table, sx.ctypes.data, sy.ctypes.data, ids.ctypes.data))
+        return sx, sy, ids
+
+    def plan_sets(self, table: int = 0) -> np.ndarray:
+        info = self.plan_info(table)
+        fs = info.filter_size
+        out = np.zeros((info.num_sets, fs, fs), np.float32)
+        for s in range(info.num_sets):
+            self._check(lib().jinc_filter_plan_set(self._h, table, s, out[s].ctypes.data))
+        return out
+
+    def lut(self) -> np.ndarray:
+        a = np.zeros(1024, np.float64)
+        self._check(lib().jinc_filter_lut(self._h, a.ctypes.data))
+        return a
+
+
+# ---- script-level functions (ref JincResize.cpp:1044-1108) ---------------------------------------
+def _make(clip: Clip, target_width: int, target_height: int, device: int, alias_taps: Optional[int], **kw) -> Clip:
+    cl = clip.props.get("_ChromaLocation", -1)
+    flt = Filter(clip.fmt, clip.width, clip.height, target_width, target_height, device=device,
+                 frame0_chroma_location=cl if isinstance(cl, int) else -1, planar=clip.planar,
+                 alias_taps=alias_taps, **kw)
+    props = dict(clip.props)
+    if flt.chroma_location >= 0:
+        props["_ChromaLocation"] = flt.chroma_location  # ref :617-625
+
+    out = Clip(clip.fmt, flt.dst_w, flt.dst_h, clip.num_frames, lambda n: flt.get_frame(clip.get_frame(n)), props)
+    out.filter = flt
+    return out
+
+
+def JincResize(clip: Clip, target_width: int, target_height: int, src_left=None, src_top=None, src_width=None,
+               src_height=None, quant_x=None, quant_y=None, tap=None, blur=None, cplace=None, threads=None, opt=None,
+               initial_capacity=None, initial_factor=None, *, device: int = 0) -> Clip:
+    return _make(clip, target_width, target_height, device, None, src_left=src_left, src_top=src_top,
+                 src_width=src_width, src_height=src_height, quant_x=quant_x, quant_y=quant_y, tap=tap, blur=blur,
+                 cplace=cplace, threads=threads, opt=opt, initial_capacity=initial_capacity,
+                 initial_factor=initial_factor)
+
+
+def _alias(taps: int):
+    def fn(clip: Clip, target_width: int, target_height: int, src_left=None, src_top=None, src_width=None,
+           src_height=None, quant_x=None, quant_y=None, cplace=None, threads=None, *, device: int = 0) -> Clip:
+        return _make(clip, target_width, target_height, device, taps, src_left=src_left, src_top=src_top,
+                     src_width=src_width, src_height=src_height, quant_x=quant_x, quant_y=quant_y, cplace=cplace,
+                     threads=threads)
+    return fn
+
+
+Jinc36Resize = _alias(3)
+Jinc64Resize = _alias(4)
+Jinc144Resize = _alias(6)
+Jinc256Resize = _alias(8)

@@ -1,0 +1,682 @@
+// filter.cpp -- host side of libjincresize_hip.so: the C ABI declared in include/jincresize_hip.h.
+//
+// Mirrors the reference plugin's filter life cycle for the accelerated path
+// ("ref:" = /root/reference/src/JincResize.cpp):
+//   jinc_filter_create      <- Create_JincResize      (ref :654-984)  same defaults, same checks in
+//                                                      the same order, same error strings
+//   jinc_filter_get_frame   <- process_frame call in JincResize_GetFrame (ref :615)
+//   jinc_filter_free        <- free_JincResize         (ref :632-647)
+//   jinc_alias_args         <- resizer()/resizer_jincresize<taps> (ref :1007-1040)
+// There is no CPU fallback: without a HIP device every frame call fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/jincresize_hip.h"
+#include "jinc_lut.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& what) : std::runtime_error(what) {}
+};
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw HipError(std::string("JincResize: HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+struct ArgError : std::runtime_error {
+    explicit ArgError(const char* what) : std::runtime_error(what) {}
+};
+
+// One table's device-resident plan: a single allocation carved into the arrays of DevicePlan.
+struct DeviceTable {
+    void* blob = nullptr;
+    size_t bytes = 0;
+    jinc::DevicePlan plan;
+    bool use_periodic = false;
+    jinc::PeriodicArgs periodic;
+    jinc::RectList border_rects;  // gather work when the periodic kernel covers the interior
+    jinc::RectList whole;         // gather work when it does not
+};
+
+struct EventPair {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+struct DeviceFrameBuf {  // staging planes for the host-pointer entry point
+    void* src[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int src_pitch[4] = {0, 0, 0, 0};
+    int dst_pitch[4] = {0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct jinc_filter {
+    jinc_video_info vi_in{};
+    jinc_video_info vi_out{};
+    std::string cplace;
+    int chroma_location = -1;
+    float peak = 0.f;
+    int planecount = 0;
+    bool subsampled = false;
+    jinc::JincLut lut;
+    std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
+    int kernel_mode = 0;
+
+    int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
+    hipStream_t stream = nullptr;
+    std::vector<DeviceTable> tables;
+    DeviceFrameBuf bufs;
+    bool bufs_ready = false;
+    bool profiling = false;
+    std::vector<EventPair> ev_periodic, ev_gather;  // recorded, not yet collected
+
+    ~jinc_filter() {
+        if (device >= 0) {
+            (void)hipSetDevice(device);
+            for (auto& t : tables)
+                if (t.blob) (void)hipFree(t.blob);
+            for (int i = 0; i < 4; ++i) {
+                if (bufs.src[i]) (void)hipFree(bufs.src[i]);
+                if (bufs.dst[i]) (void)hipFree(bufs.dst[i]);
+            }
+            for (auto* v : {&ev_periodic, &ev_gather})
+                for (auto& e : *v) {
+                    (void)hipEventDestroy(e.start);
+                    (void)hipEventDestroy(e.stop);
+                }
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    }
+
+    int table_of_plane(int i) const { return (subsampled && (i == 1 || i == 2)) ? 1 : 0; }  // ref :552-558
+    void plane_dims(const jinc_video_info& vi, int i, int& w, int& h) const {
+        w = vi.width;
+        h = vi.height;
+        if (subsampled && (i == 1 || i == 2)) {
+            w >>= vi.sub_w;
+            h >>= vi.sub_h;
+        }
+    }
+};
+
+namespace {
+
+bool is_yuv_subsampled(const jinc_video_info& vi, int sw, int sh) {
+    return !vi.is_rgb && vi.num_components >= 3 && vi.sub_w == sw && vi.sub_h == sh;
+}
+
+std::string lower(std::string s) {
+    for (auto& c : s) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+    return s;
+}
+
+// ---- Create_JincResize argument handling (ref :700-789), then geometry (ref :791-866) ------------
+void configure(jinc_filter& f, const jinc_video_info& vi, const jinc_args& a) {
+    auto has = [&](unsigned bit) { return (a.defined & bit) != 0; };
+
+    if (!vi.is_planar) throw ArgError("JincResize: clip must be in planar format.");
+
+    const int tap = has(JINC_ARG_TAP) ? a.tap : 3;
+    if (tap < 1 || tap > 16) throw ArgError("JincResize: tap must be between 1..16.");
+
+    const int quant_x = has(JINC_ARG_QUANT_X) ? a.quant_x : 256;
+    if (quant_x < 1 || quant_x > 256) throw ArgError("JincResize: quant_x must be between 1..256.");
+    const int quant_y = has(JINC_ARG_QUANT_Y) ? a.quant_y : 256;
+    if (quant_y < 1 || quant_y > 256) throw ArgError("JincResize: quant_y must be between 1..256.");
+
+    std::string cplace = (has(JINC_ARG_CPLACE) && a.cplace) ? a.cplace : "";
+    if (!cplace.empty()) {
+        cplace = lower(cplace);
+        if (cplace != "mpeg2" && cplace != "mpeg1" && cplace != "topleft")
+            throw ArgError("JincResize: cplace must be MPEG2, MPEG1 or topleft.");
+    } else {
+        if (a.frame0_chroma_location >= 0) {  // the property exists and is an integer (ref :730)
+            switch (a.frame0_chroma_location) {
+                case 0: cplace = "mpeg2"; break;
+                case 1: cplace = "mpeg1"; break;
+                case 2: cplace = "topleft"; break;
+                default: throw ArgError("JincResize: invalid _ChromaLocation");
+            }
+        } else {
+            cplace = "mpeg2";
+        }
+    }
+    const bool is_420 = is_yuv_subsampled(vi, 1, 1);
+    if (cplace == "topleft" && !is_420)
+        throw ArgError("JincResize: topleft must be used only for 4:2:0 chroma subsampling.");
+
+    const int opt = has(JINC_ARG_OPT) ? a.opt : -1;
+    if (opt > 3) throw ArgError("JincResize: opt higher than 3 is not allowed.");
+    if (opt == 3 && !a.cpu_has_avx512f) throw ArgError("JincResize: opt=3 requires AVX-512F.");
+    if (opt == 2 && !a.cpu_has_avx2) throw ArgError("JincResize: opt=2 requires AVX2.");
+    if (opt == 1 && !a.cpu_has_sse41) throw ArgError("JincResize: opt=1 requires SSE4.1.");
+
+    const int threads = has(JINC_ARG_THREADS) ? a.threads : 0;
+    if (threads < 0 || threads > 1) throw ArgError("JincResize: threads must be either 0 or 1.");
+
+    double crop_left = has(JINC_ARG_SRC_LEFT) ? a.src_left : 0.0;
+    double crop_width = has(JINC_ARG_SRC_WIDTH) ? a.src_width : static_cast<double>(vi.width);
+    if (crop_width <= 0.0) crop_width = vi.width - crop_left + crop_width;
+    double crop_top = has(JINC_ARG_SRC_TOP) ? a.src_top : 0.0;
+    double crop_height = has(JINC_ARG_SRC_HEIGHT) ? a.src_height : static_cast<double>(vi.height);
+    if (crop_height <= 0.0) crop_height = vi.height - crop_top + crop_height;
+
+    double blur = has(JINC_ARG_BLUR) ? a.blur : 0.0;
+    if (!blur) blur = 1.0;
+
+    const int target_width = a.target_width;
+    const int target_height = a.target_height;
+
+    const double initial_factor = has(JINC_ARG_INITIAL_FACTOR) ? a.initial_factor : 1.50;
+    if (initial_factor < 1.0) throw ArgError("JincResize: initial_factor must be eqaul to or greater than 1.0.");
+
+    const int src_width = vi.width;
+    const int src_height = vi.height;
+    const int initial_capacity = has(JINC_ARG_INITIAL_CAPACITY)
+                                     ? a.initial_capacity
+                                     : std::max(target_width * target_height, src_width * src_height);
+    if (initial_capacity <= 0) throw ArgError("JincResize: initial_capacity must be greater than 0.");
+
+    // ---- ref :791-866 ----
+    f.vi_in = vi;
+    f.vi_out = vi;
+    f.vi_out.width = target_width;
+    f.vi_out.height = target_height;
+    f.cplace = cplace;
+    f.peak = vi.bits_per_component <= 16 ? static_cast<float>((1 << vi.bits_per_component) - 1) : 0.f;
+    f.planecount = vi.num_components;
+    const double radius = jinc::jinc_radius(tap);
+    jinc::build_lut(f.lut, radius, blur);
+
+    jinc::TableGeometry g;
+    g.quant_x = quant_x;
+    g.quant_y = quant_y;
+    g.src_w = src_width;
+    g.src_h = src_height;
+    g.dst_w = target_width;
+    g.dst_h = target_height;
+    g.radius = radius;
+    g.crop_left = crop_left;
+    g.crop_top = crop_top;
+    g.crop_w = crop_width;
+    g.crop_h = crop_height;
+
+    const bool is_444 = !vi.is_rgb && vi.sub_w == 0 && vi.sub_h == 0;
+    f.subsampled = f.planecount > 1 && !(is_444 || vi.is_rgb);
+    f.plans.push_back(jinc::build_plane_plan(f.lut, g));
+    if (f.subsampled) {
+        const double div_w = 1 << vi.sub_w;
+        const double div_h = 1 << vi.sub_h;
+        const double crop_left_uv =
+            (cplace == "mpeg2" || cplace == "topleft")
+                ? (0.5 * (1.0 - static_cast<double>(src_width) / target_width) + crop_left) / div_w
+                : crop_left / div_w;
+        const double crop_top_uv =
+            (cplace == "topleft") ? (0.5 * (1.0 - static_cast<double>(src_height) / target_height) + crop_top) / div_h
+                                  : crop_top / div_h;
+        jinc::TableGeometry gc = g;
+        gc.src_w = src_width >> vi.sub_w;
+        gc.src_h = src_height >> vi.sub_h;
+        gc.dst_w = target_width >> vi.sub_w;
+        gc.dst_h = target_height >> vi.sub_h;
+        gc.crop_left = crop_left_uv;
+        gc.crop_top = crop_top_uv;
+        gc.crop_w = crop_width / div_w;
+        gc.crop_h = crop_height / div_h;
+        f.plans.push_back(jinc::build_plane_plan(f.lut, gc));
+    }
+
+    // ref :617-625
+    if (is_420 || is_yuv_subsampled(vi, 1, 0) || is_yuv_subsampled(vi, 2, 0))
+        f.chroma_location = cplace == "mpeg2" ? 0 : (cplace == "mpeg1" ? 1 : 2);
+    else
+        f.chroma_location = -1;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) {
+    struct Piece {
+        const void* host;
+        size_t bytes;
+        size_t offset;
+    };
+    std::vector<Piece> pieces;
+    size_t off = 0;
+    auto add = [&](const void* host, size_t bytes) {
+        off = align_up(off, 256);
+        pieces.push_back({host, bytes, off});
+        off += bytes;
+        return pieces.size() - 1;
+    };
+    const size_t i_cs = add(p.col_start.data(), p.col_start.size() * 4);
+    const size_t i_rs = add(p.row_start.data(), p.row_start.size() * 4);
+    const size_t i_cc = add(p.col_class.data(), p.col_class.size() * 4);
+    const size_t i_rc = add(p.row_class.data(), p.row_class.size() * 4);
+    const size_t i_is = add(p.interior_set.data(), p.interior_set.size() * 4);
+    const size_t i_bc = add(p.bcol_set.data(), p.bcol_set.size() * 4);
+    const size_t i_br = add(p.brow_set.data(), p.brow_set.size() * 4);
+    const size_t i_co = add(p.coeffs.data(), p.coeffs.size() * 4);
+    t.bytes = align_up(off, 256);
+    hip_check(hipMalloc(&t.blob, t.bytes), "hipMalloc(plan)");
+    char* base = static_cast<char*>(t.blob);
+    for (const Piece& pc : pieces)
+        if (pc.bytes) hip_check(hipMemcpyAsync(base + pc.offset, pc.host, pc.bytes, hipMemcpyHostToDevice, stream), "plan upload");
+    hip_check(hipStreamSynchronize(stream), "plan upload sync");
+
+    auto ptr_i = [&](size_t i) { return reinterpret_cast<const int32_t*>(base + pieces[i].offset); };
+    t.plan.col_start = ptr_i(i_cs);
+    t.plan.row_start = ptr_i(i_rs);
+    t.plan.col_class = ptr_i(i_cc);
+    t.plan.row_class = ptr_i(i_rc);
+    t.plan.interior_set = ptr_i(i_is);
+    t.plan.bcol_set = ptr_i(i_bc);
+    t.plan.brow_set = ptr_i(i_br);
+    t.plan.coeffs = reinterpret_cast<const float*>(base + pieces[i_co].offset);
+    t.plan.src_w = p.g.src_w;
+    t.plan.src_h = p.g.src_h;
+    t.plan.dst_w = p.g.dst_w;
+    t.plan.dst_h = p.g.dst_h;
+    t.plan.fs = p.fs;
+    t.plan.n_col_classes = p.n_col_classes;
+}
+
+// Decides how the output plane is split between the periodic kernel and the gather kernel.
+void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
+    const int W = p.g.dst_w, H = p.g.dst_h;
+    t.whole = jinc::RectList{};
+    t.whole.n = 1;
+    t.whole.w[0] = W;
+    t.whole.h[0] = H;
+    t.use_periodic = false;
+    if (!p.periodic || !jinc::periodic_supported(p.fs, p.px, p.py, p.sx, p.sy)) return;
+
+    jinc::PeriodicArgs pa;
+    pa.coeffs = t.plan.coeffs;
+    pa.px = p.px;
+    pa.py = p.py;
+    pa.ix0 = p.ix0;
+    pa.iy0 = p.iy0;
+    pa.ni = (p.ix1 - p.ix0) / p.px;
+    pa.nj = (p.iy1 - p.iy0) / p.py;
+    if (pa.ni < 1 || pa.nj < 1) return;
+    int min_sx = INT32_MAX, max_sx = INT32_MIN, min_sy = INT32_MAX, max_sy = INT32_MIN;
+    for (int q = 0; q < p.px; ++q) {
+        pa.start_x[q] = p.col_start[p.ix0 + q];
+        min_sx = std::min(min_sx, pa.start_x[q]);
+        max_sx = std::max(max_sx, pa.start_x[q]);
+    }
+    for (int q = 0; q < p.py; ++q) {
+        pa.start_y[q] = p.row_start[p.iy0 + q];
+        min_sy = std::min(min_sy, pa.start_y[q]);
+        max_sy = std::max(max_sy, pa.start_y[q]);
+    }
+    // The kernel's LDS tile has room for a phase spread of one source sample per axis.
+    if (max_sx - min_sx > 1 || max_sy - min_sy > 1) return;
+    pa.min_sx = min_sx;
+    pa.min_sy = min_sy;
+    for (int q = 0; q < p.py; ++q)
+        for (int r = 0; r < p.px; ++r)
+            pa.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
+                                                  p.col_class[p.ix0 + r]];
+    pa.src_w = p.g.src_w;
+    pa.src_h = p.g.src_h;
+    t.periodic = pa;
+    t.use_periodic = true;
+
+    const int x_end = p.ix0 + p.px * pa.ni;
+    const int y_end = p.iy0 + p.py * pa.nj;
+    jinc::RectList r;
+    auto add = [&](int x0, int y0, int w, int h) {
+        if (w <= 0 || h <= 0) return;
+        r.x0[r.n] = x0;
+        r.y0[r.n] = y0;
+        r.w[r.n] = w;
+        r.h[r.n] = h;
+        ++r.n;
+    };
+    add(0, 0, W, p.iy0);                     // top rows
+    add(0, y_end, W, H - y_end);             // bottom rows
+    add(0, p.iy0, p.ix0, y_end - p.iy0);     // left columns
+    add(x_end, p.iy0, W - x_end, y_end - p.iy0);  // right columns
+    t.border_rects = r;
+}
+
+void init_device(jinc_filter& f, int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw HipError("JincResize: no HIP device available.");
+    if (device >= count) throw HipError("JincResize: HIP device index out of range.");
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    f.device = device;
+    hip_check(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking), "hipStreamCreate");
+    f.tables.resize(f.plans.size());
+    for (size_t i = 0; i < f.plans.size(); ++i) {
+        upload_table(f.plans[i], f.tables[i], f.stream);
+        plan_launches(f.plans[i], f.tables[i]);
+    }
+}
+
+void ensure_frame_bufs(jinc_filter& f) {
+    if (f.bufs_ready) return;
+    const int sb = f.vi_in.component_size;
+    for (int i = 0; i < f.planecount; ++i) {
+        int sw, sh, dw, dh;
+        f.plane_dims(f.vi_in, i, sw, sh);
+        f.plane_dims(f.vi_out, i, dw, dh);
+        f.bufs.src_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(sw) * sb, 256));
+        f.bufs.dst_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(dw) * sb, 256));
+        hip_check(hipMalloc(&f.bufs.src[i], static_cast<size_t>(f.bufs.src_pitch[i]) * sh), "hipMalloc(src plane)");
+        hip_check(hipMalloc(&f.bufs.dst[i], static_cast<size_t>(f.bufs.dst_pitch[i]) * dh), "hipMalloc(dst plane)");
+    }
+    f.bufs_ready = true;
+}
+
+void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
+             void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
+    const int sb = f.vi_in.component_size;
+    for (int i = 0; i < f.planecount; ++i) {
+        DeviceTable& t = f.tables[f.table_of_plane(i)];
+        if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
+        if (src_pitch[i] % sb || dst_pitch[i] % sb) throw ArgError("JincResize: plane pitch is not a multiple of the sample size.");
+        if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(t.plan.src_w) * sb ||
+            static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(t.plan.dst_w) * sb)
+            throw ArgError("JincResize: plane pitch is smaller than the row size.");
+        jinc::PlaneIO io;
+        io.src = src[i];
+        io.dst = dst[i];
+        io.src_pitch = src_pitch[i];
+        io.dst_pitch = dst_pitch[i];
+        io.src_frame_stride = src_fs ? src_fs[i] : 0;
+        io.dst_frame_stride = dst_fs ? dst_fs[i] : 0;
+        io.nframes = nframes;
+        io.sample_bytes = sb;
+        io.peak = f.peak;
+        const bool periodic = t.use_periodic && f.kernel_mode != 1;
+        auto timed = [&](std::vector<EventPair>& sink, const char* what, auto&& launch) {
+            EventPair ev;
+            if (f.profiling) {
+                hip_check(hipEventCreate(&ev.start), "hipEventCreate");
+                hip_check(hipEventCreate(&ev.stop), "hipEventCreate");
+                hip_check(hipEventRecord(ev.start, stream), "hipEventRecord");
+            }
+            hip_check(static_cast<hipError_t>(launch()), what);
+            if (f.profiling) {
+                hip_check(hipEventRecord(ev.stop, stream), "hipEventRecord");
+                sink.push_back(ev);
+            }
+        };
+        if (periodic) {
+            timed(f.ev_periodic, "periodic kernel launch", [&] { return jinc::launch_periodic(t.periodic, t.plan.fs, io, stream); });
+            if (t.border_rects.n > 0)
+                timed(f.ev_gather, "border kernel launch", [&] { return jinc::launch_gather(t.plan, io, t.border_rects, stream); });
+        } else {
+            timed(f.ev_gather, "gather kernel launch", [&] { return jinc::launch_gather(t.plan, io, t.whole, stream); });
+        }
+    }
+}
+
+template <typename Fn>
+int guarded(Fn&& fn) {
+    try {
+        fn();
+        g_last_error.clear();
+        return JINC_OK;
+    } catch (const ArgError& e) {
+        return fail(JINC_ERR_INVALID_ARG, e.what());
+    } catch (const HipError& e) {
+        return fail(JINC_ERR_HIP, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(JINC_ERR_NOMEM, "JincResize: out of memory.");
+    } catch (const std::exception& e) {
+        return fail(JINC_ERR_UNSUPPORTED, e.what());
+    }
+}
+
+const jinc::PlanePlan* table_or_null(const jinc_filter* f, int table) {
+    if (!f || table < 0 || table >= static_cast<int>(f->plans.size())) return nullptr;
+    return &f->plans[table];
+}
+
+}  // namespace
+
+extern "C" {
+
+int jinc_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+const char* jinc_last_error(void) { return g_last_error.c_str(); }
+
+int jinc_filter_create(const jinc_video_info* vi, const jinc_args* args, int device, jinc_filter** out, char* err,
+                       size_t err_len) {
+    if (out) *out = nullptr;
+    if (err && err_len) err[0] = '\0';
+    if (!vi || !args || !out) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    std::unique_ptr<jinc_filter> f(new (std::nothrow) jinc_filter());
+    if (!f) return fail(JINC_ERR_NOMEM, "JincResize: out of memory.");
+    int rc = guarded([&] {
+        configure(*f, *vi, *args);
+        if (device >= 0) init_device(*f, device);
+    });
+    if (rc == JINC_ERR_HIP && device >= 0 && jinc_device_count() == 0) rc = JINC_ERR_NO_DEVICE;
+    if (rc != JINC_OK) {
+        if (err && err_len) {
+            std::strncpy(err, g_last_error.c_str(), err_len - 1);
+            err[err_len - 1] = '\0';
+        }
+        return rc;
+    }
+    *out = f.release();
+    return JINC_OK;
+}
+
+void jinc_filter_free(jinc_filter* f) { delete f; }
+
+int jinc_filter_output_info(const jinc_filter* f, jinc_video_info* out_vi) {
+    if (!f || !out_vi) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    *out_vi = f->vi_out;
+    return JINC_OK;
+}
+
+int jinc_filter_chroma_location(const jinc_filter* f) { return f ? f->chroma_location : -1; }
+
+int jinc_filter_get_frame(jinc_filter* f, const void* const src[4], const int src_pitch[4], void* const dst[4],
+                          const int dst_pitch[4]) {
+    if (!f || !src || !dst || !src_pitch || !dst_pitch) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        ensure_frame_bufs(*f);
+        const int sb = f->vi_in.component_size;
+        for (int i = 0; i < f->planecount; ++i) {
+            if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
+            int sw, sh;
+            f->plane_dims(f->vi_in, i, sw, sh);
+            hip_check(hipMemcpy2DAsync(f->bufs.src[i], f->bufs.src_pitch[i], src[i], src_pitch[i],
+                                       static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, f->stream),
+                      "H2D copy");
+        }
+        enqueue(*f, f->bufs.src, f->bufs.src_pitch, nullptr, f->bufs.dst, f->bufs.dst_pitch, nullptr, 1, f->stream);
+        for (int i = 0; i < f->planecount; ++i) {
+            int dw, dh;
+            f->plane_dims(f->vi_out, i, dw, dh);
+            hip_check(hipMemcpy2DAsync(dst[i], dst_pitch[i], f->bufs.dst[i], f->bufs.dst_pitch[i],
+                                       static_cast<size_t>(dw) * sb, dh, hipMemcpyDeviceToHost, f->stream),
+                      "D2H copy");
+        }
+        hip_check(hipStreamSynchronize(f->stream), "stream sync");
+    });
+}
+
+int jinc_filter_process_device(jinc_filter* f, const void* const src[4], const int src_pitch[4],
+                               const size_t src_frame_stride[4], void* const dst[4], const int dst_pitch[4],
+                               const size_t dst_frame_stride[4], int nframes, void* hip_stream) {
+    if (!f || !src || !dst || !src_pitch || !dst_pitch) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    if (nframes < 1 || nframes > 65535) return fail(JINC_ERR_INVALID_ARG, "JincResize: nframes must be in 1..65535.");
+    if (nframes > 1 && (!src_frame_stride || !dst_frame_stride))
+        return fail(JINC_ERR_INVALID_ARG, "JincResize: frame strides are required for nframes > 1.");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : f->stream;
+        enqueue(*f, src, src_pitch, src_frame_stride, dst, dst_pitch, dst_frame_stride, nframes, s);
+    });
+}
+
+int jinc_filter_sync(jinc_filter* f) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        hip_check(hipStreamSynchronize(f->stream), "stream sync");
+    });
+}
+
+int jinc_alias_args(int taps, const jinc_args* in, jinc_args* out) {
+    if (!in || !out) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (taps != 3 && taps != 4 && taps != 6 && taps != 8)
+        return fail(JINC_ERR_INVALID_ARG, "JincResize: alias tap count must be 3, 4, 6 or 8.");
+    jinc_args a{};
+    a.target_width = in->target_width;
+    a.target_height = in->target_height;
+    const unsigned forwarded = JINC_ARG_SRC_LEFT | JINC_ARG_SRC_TOP | JINC_ARG_SRC_WIDTH | JINC_ARG_SRC_HEIGHT |
+                               JINC_ARG_QUANT_X | JINC_ARG_QUANT_Y | JINC_ARG_CPLACE | JINC_ARG_THREADS;
+    a.defined = (in->defined & forwarded) | JINC_ARG_TAP;
+    a.src_left = in->src_left;
+    a.src_top = in->src_top;
+    a.src_width = in->src_width;
+    a.src_height = in->src_height;
+    a.quant_x = in->quant_x;
+    a.quant_y = in->quant_y;
+    a.cplace = in->cplace;
+    a.threads = in->threads;
+    a.tap = taps;
+    a.frame0_chroma_location = in->frame0_chroma_location;
+    a.cpu_has_sse41 = in->cpu_has_sse41;
+    a.cpu_has_avx2 = in->cpu_has_avx2;
+    a.cpu_has_avx512f = in->cpu_has_avx512f;
+    *out = a;
+    return JINC_OK;
+}
+
+int jinc_filter_num_tables(const jinc_filter* f) { return f ? static_cast<int>(f->plans.size()) : 0; }
+
+int jinc_filter_plan_info(const jinc_filter* f, int table, jinc_plan_info* out) {
+    const jinc::PlanePlan* p = table_or_null(f, table);
+    if (!p || !out) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad table index.");
+    jinc_plan_info i{};
+    i.src_width = p->g.src_w;
+    i.src_height = p->g.src_h;
+    i.dst_width = p->g.dst_w;
+    i.dst_height = p->g.dst_h;
+    i.filter_size = p->fs;
+    i.num_sets = p->num_sets;
+    i.periodic = p->periodic ? 1 : 0;
+    i.period_x = p->px;
+    i.period_y = p->py;
+    i.step_x = p->sx;
+    i.step_y = p->sy;
+    i.interior_x0 = p->ix0;
+    i.interior_x1 = p->ix1;
+    i.interior_y0 = p->iy0;
+    i.interior_y1 = p->iy1;
+    i.plan_bytes = static_cast<int64_t>(4) * (p->col_start.size() + p->row_start.size() + p->col_class.size() +
+                                              p->row_class.size() + p->interior_set.size() + p->bcol_set.size() +
+                                              p->brow_set.size() + p->coeffs.size());
+    *out = i;
+    return JINC_OK;
+}
+
+int jinc_filter_plan_pixel(const jinc_filter* f, int table, int x, int y, int* start_x, int* start_y, float* coeffs) {
+    const jinc::PlanePlan* p = table_or_null(f, table);
+    if (!p || x < 0 || y < 0 || x >= p->g.dst_w || y >= p->g.dst_h)
+        return fail(JINC_ERR_INVALID_ARG, "JincResize: bad table index or pixel.");
+    if (start_x) *start_x = p->col_start[x];
+    if (start_y) *start_y = p->row_start[y];
+    if (coeffs) std::memcpy(coeffs, p->set_ptr(p->set_of(x, y)), sizeof(float) * p->fs * p->fs);
+    return JINC_OK;
+}
+
+int jinc_filter_plan_dump(const jinc_filter* f, int table, int* start_x, int* start_y, int* set_id) {
+    const jinc::PlanePlan* p = table_or_null(f, table);
+    if (!p) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad table index.");
+    if (start_x) std::memcpy(start_x, p->col_start.data(), sizeof(int) * p->g.dst_w);
+    if (start_y) std::memcpy(start_y, p->row_start.data(), sizeof(int) * p->g.dst_h);
+    if (set_id)
+        for (int y = 0; y < p->g.dst_h; ++y)
+            for (int x = 0; x < p->g.dst_w; ++x) set_id[static_cast<size_t>(y) * p->g.dst_w + x] = p->set_of(x, y);
+    return JINC_OK;
+}
+
+int jinc_filter_plan_set(const jinc_filter* f, int table, int set, float* coeffs) {
+    const jinc::PlanePlan* p = table_or_null(f, table);
+    if (!p || !coeffs || set < 0 || set >= p->num_sets) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad table or set index.");
+    std::memcpy(coeffs, p->set_ptr(set), sizeof(float) * p->fs * p->fs);
+    return JINC_OK;
+}
+
+int jinc_filter_lut(const jinc_filter* f, double* lut1024) {
+    if (!f || !lut1024) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    std::memcpy(lut1024, f->lut.v.data(), sizeof(double) * jinc::kLutSamples);
+    return JINC_OK;
+}
+
+int jinc_filter_set_profiling(jinc_filter* f, int enable) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    f->profiling = enable != 0;
+    return JINC_OK;
+}
+
+int jinc_filter_kernel_times(jinc_filter* f, double* periodic_ms, int* periodic_launches, double* gather_ms,
+                             int* gather_launches) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        auto collect = [](std::vector<EventPair>& v, double* ms_out, int* n_out) {
+            double total = 0.0;
+            for (auto& e : v) {
+                hip_check(hipEventSynchronize(e.stop), "hipEventSynchronize");
+                float ms = 0.f;
+                hip_check(hipEventElapsedTime(&ms, e.start, e.stop), "hipEventElapsedTime");
+                total += ms;
+                (void)hipEventDestroy(e.start);
+                (void)hipEventDestroy(e.stop);
+            }
+            if (ms_out) *ms_out = total;
+            if (n_out) *n_out = static_cast<int>(v.size());
+            v.clear();
+        };
+        collect(f->ev_periodic, periodic_ms, periodic_launches);
+        collect(f->ev_gather, gather_ms, gather_launches);
+    });
+}
+
+int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
+    if (!f || mode < 0 || mode > 2) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    f->kernel_mode = mode;
+    return JINC_OK;
+}
+
+}  // extern "C"

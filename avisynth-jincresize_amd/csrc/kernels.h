@@ -1,0 +1,62 @@
+// kernels.h -- launch interface between the host filter (filter.cpp) and the gfx950 kernels
+// (kernels.hip).  Plain structs of device pointers and sizes; no HIP types except the stream.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace jinc {
+
+// Device-resident compact plan of one table (see plan.h for the meaning of each array).
+struct DevicePlan {
+    const int32_t* col_start = nullptr;
+    const int32_t* row_start = nullptr;
+    const int32_t* col_class = nullptr;
+    const int32_t* row_class = nullptr;
+    const int32_t* interior_set = nullptr;
+    const int32_t* bcol_set = nullptr;
+    const int32_t* brow_set = nullptr;
+    const float* coeffs = nullptr;
+    int src_w = 0, src_h = 0, dst_w = 0, dst_h = 0;
+    int fs = 0;
+    int n_col_classes = 0;
+};
+
+// One plane of a batch of frames, device pointers, pitches/strides in bytes.
+struct PlaneIO {
+    const void* src = nullptr;
+    void* dst = nullptr;
+    int src_pitch = 0, dst_pitch = 0;
+    size_t src_frame_stride = 0, dst_frame_stride = 0;
+    int nframes = 1;
+    int sample_bytes = 1;  // 1: uint8, 2: uint16, 4: float
+    float peak = 255.f;    // clamp ceiling of integer planes (ref JincResize.cpp:582, :793)
+};
+
+// Up to four output rectangles handled by one gather launch (whole plane, or the border frame
+// around the periodic interior).
+struct RectList {
+    int n = 0;
+    int x0[4] = {0, 0, 0, 0}, y0[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+};
+
+// Phase-periodic interior (see plan.h): output pixel (ix0 + px*i + p, iy0 + py*j + q) reads the
+// source window at (start_x[p] + i, start_y[q] + j) with coefficient set set[q*px + p].
+struct PeriodicArgs {
+    const float* coeffs = nullptr;
+    int px = 1, py = 1;
+    int ix0 = 0, iy0 = 0;
+    int ni = 0, nj = 0;          // number of whole periods covered in x / y
+    int start_x[8] = {0}, start_y[8] = {0};
+    int min_sx = 0, min_sy = 0;  // min over phases of start_x / start_y
+    int set[64] = {0};
+    int src_w = 0, src_h = 0;
+};
+
+// Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
+int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);
+
+// True when a specialised periodic kernel exists for this filter size / period / sample type.
+bool periodic_supported(int fs, int px, int py, int sx, int sy);
+int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream);
+
+}  // namespace jinc

@@ -1,0 +1,279 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the EWA-Jinc gather-MAC.
+//
+// Replaces resize_plane_{c,sse41,avx2,avx512}<T,thr,subsampled> and their row fan-out
+// (/root/reference/src/JincResize.cpp:536-601, resize_plane_*.cpp).  The result is DEFINED by the
+// reference's opt=0 path: per output sample a strictly sequential fp32 chain
+//     r = 0; for ly: for lx: r = fl(r + fl(float(src) * coeff))          (ref :570-579)
+// followed by clamp + round-half-even for integer planes (ref :581-582).  Therefore:
+//   * one lane owns one output sample's whole chain; cross-lane operations move data only;
+//   * multiply and add stay un-fused: this file is compiled with -ffp-contract=off AND carries the
+//     pragma below; the build greps the ISA for v_fma/v_fmac/v_mad/v_pk_fma (tests/test_build.py);
+//   * fp32 denormals are kept (gfx9 default; no -fgpu-flush-denormals-to-zero).
+//
+// Two kernels:
+//   ewa_gather_kernel   -- any plan: one lane per output pixel, per-lane window origin and
+//                          coefficient-set pointer (plan arrays are L2-resident).
+//   ewa_periodic_kernel -- phase-periodic interior (integer upscales): a wave owns ONE phase, so its
+//                          fs*fs coefficients are wave-uniform and live in SGPRs (s_load through a
+//                          constant-address-space pointer; v_mul_f32 takes the SGPR operand directly);
+//                          lanes are consecutive source-aligned columns; the source tile is converted
+//                          to fp32 once and staged in LDS; each lane keeps an fs x fs register window
+//                          that slides down the tile (one new LDS row per output row, rotation done by
+//                          compile-time unrolling, no register moves).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace jinc {
+namespace {
+
+#define JINC_CONSTANT __attribute__((address_space(4)))
+
+template <typename T>
+__device__ __forceinline__ float to_float(T v) {
+    return static_cast<float>(v);
+}
+
+// ref :581-584 -- avs clamp order (upper bound first), lrintf = round-half-even.
+template <typename T>
+__device__ __forceinline__ void store_sample(T* p, float r, float peak) {
+    if constexpr (std::is_same_v<T, float>) {
+        *p = r;
+    } else {
+        r = r > peak ? peak : r;
+        r = r < 0.f ? 0.f : r;
+        *p = static_cast<T>(static_cast<uint32_t>(__builtin_rintf(r)));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic gather kernel
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    DevicePlan plan;
+    PlaneIO io;
+    RectList rects;
+    int block_begin[5];
+    int blocks_x[4];
+};
+
+template <typename T, int FS>
+__global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
+    const int b = blockIdx.x;
+    int r = 0;
+    while (r + 1 < a.rects.n && b >= a.block_begin[r + 1]) ++r;
+    const int local = b - a.block_begin[r];
+    const int bx = local % a.blocks_x[r];
+    const int by = local / a.blocks_x[r];
+    const int x = a.rects.x0[r] + bx * 64 + (threadIdx.x & 63);
+    const int y = a.rects.y0[r] + by * 4 + (threadIdx.x >> 6);
+    if (x >= a.rects.x0[r] + a.rects.w[r] || y >= a.rects.y0[r] + a.rects.h[r]) return;
+
+    const DevicePlan& p = a.plan;
+    const int fs = FS ? FS : p.fs;
+    const int sx = p.col_start[x];
+    const int sy = p.row_start[y];
+    const int rc = p.row_class[y];
+    const int cc = p.col_class[x];
+    int set;
+    if (rc < 0)
+        set = p.brow_set[static_cast<size_t>(~rc) * p.dst_w + x];
+    else if (cc < 0)
+        set = p.bcol_set[static_cast<size_t>(~cc) * p.dst_h + y];
+    else
+        set = p.interior_set[rc * p.n_col_classes + cc];
+
+    const size_t frame = blockIdx.y;
+    const char* srow = static_cast<const char*>(a.io.src) + frame * a.io.src_frame_stride +
+                       static_cast<size_t>(sy) * a.io.src_pitch + static_cast<size_t>(sx) * sizeof(T);
+    const float* c = p.coeffs + static_cast<size_t>(set) * fs * fs;
+
+    float acc = 0.f;
+    for (int ly = 0; ly < fs; ++ly) {
+        const T* s = reinterpret_cast<const T*>(srow);
+#pragma unroll
+        for (int lx = 0; lx < fs; ++lx) acc = acc + to_float(s[lx]) * c[lx];
+        srow += a.io.src_pitch;
+        c += fs;
+    }
+    T* d = reinterpret_cast<T*>(static_cast<char*>(a.io.dst) + frame * a.io.dst_frame_stride +
+                                static_cast<size_t>(y) * a.io.dst_pitch) + x;
+    store_sample<T>(d, acc, a.io.peak);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Periodic interior kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileCols = 64;  // source-aligned columns per tile = lanes of a wave
+
+template <int FS>
+struct PeriodicCfg {
+    static constexpr int kRowGroups = FS <= 7 ? 4 : 3;
+    static constexpr int kTileRows = FS * kRowGroups;     // period-rows per tile (multiple of FS)
+    static constexpr int kLdsCols = kTileCols + FS;       // 64 + (FS-1) halo + 1 phase spread
+    static constexpr int kLdsPitch = kLdsCols + 1;        // odd pitch not needed for row reads; keeps staging writes spread
+    static constexpr int kLdsRows = kTileRows + FS;       // TJ + (FS-1) halo + 1 phase spread
+};
+
+template <typename T, int FS>
+__global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = PeriodicCfg<FS>;
+    __shared__ float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i0 = blockIdx.x * kTileCols;
+    const int j0 = blockIdx.y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+
+    // ---- stage the source tile as fp32 (each source sample converted once) ----
+    {
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        for (int r = wave; r < Cfg::kLdsRows; r += 4) {
+            int gy = gy0 + r;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int c = lane; c < Cfg::kLdsCols; c += 64) {
+                int gx = gx0 + c;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                tile[r * Cfg::kLdsPitch + c] = to_float(srow[gx]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nphase = a.px * a.py;
+    for (int ph = wave; ph < nphase; ph += 4) {
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+
+        // wave-uniform coefficients -> SGPRs
+        const JINC_CONSTANT float* cs =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * FS));
+        float cf[FS * FS];
+#pragma unroll
+        for (int k = 0; k < FS * FS; ++k) cf[k] = cs[k];
+
+        const float* base = tile + (a.start_y[q] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[p] - a.min_sx) + lane;
+
+        const int x = a.ix0 + a.px * (i0 + lane) + p;
+        const bool lane_ok = (i0 + lane) < a.ni;
+        T* dcol = reinterpret_cast<T*>(static_cast<char*>(io.dst) + frame * io.dst_frame_stride) + x;
+
+        float win[FS][FS];
+#pragma unroll
+        for (int r = 0; r < FS - 1; ++r)
+#pragma unroll
+            for (int lx = 0; lx < FS; ++lx) win[r][lx] = base[r * Cfg::kLdsPitch + lx];
+
+        for (int g = 0; g < Cfg::kRowGroups; ++g) {
+            const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#pragma unroll
+            for (int u = 0; u < FS; ++u) {
+                // newest window row: tile row g*FS + u + FS-1 -> slot (u + FS-1) % FS
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx)
+                    win[(u + FS - 1) % FS][lx] = gbase[(u + FS - 1) * Cfg::kLdsPitch + lx];
+
+                float acc = 0.f;
+#pragma unroll
+                for (int ly = 0; ly < FS; ++ly)
+#pragma unroll
+                    for (int lx = 0; lx < FS; ++lx) acc = acc + win[(u + ly) % FS][lx] * cf[ly * FS + lx];
+
+                const int j = j0 + g * FS + u;
+                if (lane_ok && j < a.nj) {
+                    const int y = a.iy0 + a.py * j + q;
+                    T* d = reinterpret_cast<T*>(reinterpret_cast<char*>(dcol) + static_cast<size_t>(y) * io.dst_pitch);
+                    store_sample<T>(d, acc, io.peak);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int FS>
+int launch_gather_t(const GatherArgs& ga, int total_blocks, hipStream_t stream) {
+    dim3 grid(total_blocks, ga.io.nframes, 1), block(256, 1, 1);
+    hipLaunchKernelGGL((ewa_gather_kernel<T, FS>), grid, block, 0, stream, ga);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <typename T>
+int launch_gather_fs(const GatherArgs& ga, int total_blocks, hipStream_t stream) {
+    switch (ga.plan.fs) {
+        case 7: return launch_gather_t<T, 7>(ga, total_blocks, stream);
+        case 9: return launch_gather_t<T, 9>(ga, total_blocks, stream);
+        case 17: return launch_gather_t<T, 17>(ga, total_blocks, stream);
+        default: return launch_gather_t<T, 0>(ga, total_blocks, stream);
+    }
+}
+
+template <typename T, int FS>
+int launch_periodic_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicCfg<FS>;
+    dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_kernel<T, FS>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <typename T>
+int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream) {
+    switch (fs) {
+        case 7: return launch_periodic_t<T, 7>(pa, io, stream);
+        case 9: return launch_periodic_t<T, 9>(pa, io, stream);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
+}  // namespace
+
+int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream) {
+    GatherArgs ga;
+    ga.plan = plan;
+    ga.io = io;
+    ga.rects = rects;
+    int total = 0;
+    for (int r = 0; r < 4; ++r) {
+        ga.block_begin[r] = total;
+        ga.blocks_x[r] = 1;
+        if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
+            ga.blocks_x[r] = (rects.w[r] + 63) / 64;
+            total += ga.blocks_x[r] * ((rects.h[r] + 3) / 4);
+        }
+    }
+    ga.block_begin[4] = total;
+    if (total == 0 || io.nframes <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (io.sample_bytes) {
+        case 1: return launch_gather_fs<uint8_t>(ga, total, s);
+        case 2: return launch_gather_fs<uint16_t>(ga, total, s);
+        default: return launch_gather_fs<float>(ga, total, s);
+    }
+}
+
+bool periodic_supported(int fs, int px, int py, int sx, int sy) {
+    if (sx != 1 || sy != 1) return false;
+    if (px < 1 || py < 1 || px > 8 || py > 8) return false;
+    return fs == 7 || fs == 9;
+}
+
+int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream) {
+    if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (io.sample_bytes) {
+        case 1: return launch_periodic_fs<uint8_t>(args, fs, io, s);
+        case 2: return launch_periodic_fs<uint16_t>(args, fs, io, s);
+        default: return launch_periodic_fs<float>(args, fs, io, s);
+    }
+}
+
+}  // namespace jinc

@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the EWA-Jinc hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): 1920x1080 -> 3840x2160, Y8 (u8 samples), tap=3.
+A *step* is one pass of the hot path over one batch of `--frames` independent synthetic frames
+that are already resident in HBM (one jinc_filter_process_device call = one periodic-interior
+kernel launch + one border gather launch for the whole batch).  Frames are the sharding unit:
+with N GPUs every rank (one process per GPU) holds its own batch and there is no data-path
+collective -- the only communication is the barrier and the MAX over ranks of the elapsed time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--config C2|C3|C4]
+
+Rank 0 prints ONE JSON line (see the task contract): value = Mpix/s over all ranks, plus
+  "roofline"     -- dominant (periodic-interior) kernel: algorithmic HBM bytes / its mean launch
+                    duration measured with hipEvents on the launch stream, vs the 8 TB/s peak;
+                    also the un-fused fp32 VALU fraction, the roof that actually binds;
+  "cpu_baseline" -- the CPU oracle (port of the reference opt=0 path) timed on this host's cores
+                    on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_UNFUSED_PEAK = 78.6e12  # 256 CU x 128 lanes/clk x 2.4 GHz, one IEEE op per lane-clk (no FMA allowed)
+
+CONFIGS = {
+    # name: (format, src_w, src_h, dst_w, dst_h, script args, default frames per step)
+    "C2": ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 64),
+    "C3": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=8, cplace="mpeg2"), 16),
+    "C4": ("RGBPS", 3840, 2160, 7680, 4320, dict(tap=4, blur=0.98), 4),
+}
+
+
+def shard_frames(total_frames: int, rank: int, world: int):
+    """Contiguous shard of a global batch of independent frames for `rank` (frames never interact)."""
+    base, rem = divmod(total_frames, world)
+    start = rank * base + min(rank, rem)
+    return start, base + (1 if rank < rem else 0)
+
+
+def aggregate(elapsed_s: float, units: float, dist=None):
+    """MAX over ranks of the elapsed time, SUM over ranks of the processed units."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return elapsed_s, units
+    import torch
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
+    u = torch.tensor([units], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(u.item())
+
+
+def algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh):
+    """every source sample read once + every output sample written once."""
+    b = 0
+    for (w, h), (ow, oh) in zip(fmt.plane_dims(sw, sh), fmt.plane_dims(dw, dh)):
+        b += (w * h + ow * oh) * fmt.sample_bytes
+    return b
+
+
+def cpu_baseline(cfg_name, budget_s=12.0):
+    """Times the CPU oracle (port of resize_plane_c) on this host: all cores (row-parallel, the
+    reference's thr==0 design) and one core, on a bounded number of frames of the same workload."""
+    O = entry.load_oracle()
+    fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[cfg_name]
+    fmt = O.FORMATS[fmt_name]
+    flt = O.OracleFilter(fmt, sw, sh, dw, dh, **kw)
+    src = O.lcg_frame(fmt, sw, sh)
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, threads, share in (("all", cores, 0.6), ("one", 1, 0.4)):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            flt.get_frame(src, threads=threads)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s * share or n >= 64:
+                break
+        out[label] = (dw * dh * n / el / 1e6, n, el)
+    v, n, el = out["all"]
+    return {"value": round(v, 2), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"{n} frames of {cfg_name} in {el:.1f}s, oracle rows over {cores} OpenMP threads",
+            "single_core_value": round(out["one"][0], 2),
+            "single_core_sample": f"{out['one'][1]} frames in {out['one'][2]:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default per config)")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists in the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+
+    pkg = entry.load_package()
+    fmt_name, sw, sh, dw, dh, kw, default_frames = CONFIGS[args.config]
+    fmt = pkg.FORMATS[fmt_name]
+    B = args.frames or default_frames
+    flt = pkg.Filter(fmt, sw, sh, dw, dh, device=local_rank, **kw)
+    flt.set_kernel_mode(args.kernel_mode)
+    info = flt.plan_info(0)
+
+    # ---- synthetic frames, resident in HBM: rank r owns global frames [r*B, (r+1)*B) ----
+    tdtype = {1: torch.uint8, 2: torch.uint16, 4: torch.float32}[fmt.sample_bytes]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(12345 + rank)
+    sdims, ddims = fmt.plane_dims(sw, sh), fmt.plane_dims(dw, dh)
+
+    def pitch_elems(w):
+        return ((w * fmt.sample_bytes + 255) // 256 * 256) // fmt.sample_bytes
+
+    src_t, dst_t = [], []
+    for (w, h) in sdims:
+        shape = (B, h, pitch_elems(w))
+        if fmt.sample_bytes == 4:
+            t = torch.rand(shape, device="cuda", generator=gen, dtype=torch.float32)
+        else:
+            hi = 1 << fmt.bits
+            t = torch.randint(0, hi, shape, device="cuda", generator=gen, dtype=torch.int32).to(
+                torch.uint8 if fmt.sample_bytes == 1 else torch.int16)
+            if fmt.sample_bytes == 2:
+                t = t.view(torch.uint16)
+        src_t.append(t)
+    for (w, h) in ddims:
+        dst_t.append(torch.zeros((B, h, pitch_elems(w)), device="cuda", dtype=tdtype))
+    sb = fmt.sample_bytes
+    sp = [t.data_ptr() for t in src_t]
+    spitch = [t.stride(1) * sb for t in src_t]
+    sstride = [t.stride(0) * sb for t in src_t]
+    dp = [t.data_ptr() for t in dst_t]
+    dpitch = [t.stride(1) * sb for t in dst_t]
+    dstride = [t.stride(0) * sb for t in dst_t]
+    stream = torch.cuda.current_stream()
+
+    def step():
+        flt.process_device(sp, spitch, sstride, dp, dpitch, dstride, B, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    flt.set_profiling(True)
+    flt.kernel_times()  # reset
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
+    flt.set_profiling(False)
+
+    frames_done = float(B * args.steps)
+    elapsed_max, frames_all = aggregate(elapsed, frames_done, dist if world > 1 else None)
+    mpix = frames_all * dw * dh / elapsed_max / 1e6
+
+    if rank == 0:
+        bytes_frame = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
+        n_planes = fmt.planes
+        fs = info.filter_size
+        samples_frame = sum(w * h for (w, h) in ddims)
+        if per_n > 0:
+            dom_name, dom_ms, dom_n = "ewa_periodic_kernel", per_ms, per_n
+        else:
+            dom_name, dom_ms, dom_n = "ewa_gather_kernel", gat_ms, gat_n
+        # one launch per plane per step; algorithmic bytes of a launch = the batch's bytes for that plane,
+        # so summed over the planes of a step it is bytes_frame * B
+        launches_per_step = max(1, dom_n // max(1, args.steps))
+        kernel_ms_per_step = dom_ms / args.steps
+        achieved_gbs = bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9
+        valu_ops = 2.0 * fs * fs * samples_frame * B / (kernel_ms_per_step * 1e-3)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.config, {}).get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        line = {
+            "metric": "Mpix/s per GPU (1080p->4K tap=3 Y8); % HBM-read roofline" if args.config == "C2"
+            else f"Mpix/s ({args.config})",
+            "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {1: "u8", 2: "u16", 4: "f32"}[sb] + "->f32 accumulate",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {sw}x{sh}->{dw}x{dh} {fmt_name} tap={kw['tap']}"
+                                   + (f" blur={kw['blur']}" if 'blur' in kw else ""),
+                       "frames_per_step_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "kernel": dom_name, "filter_size": fs, "plan_sets": info.num_sets,
+                       "plan_bytes": int(info.plan_bytes)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": dom_name, "kernel_ms_per_launch": round(dom_ms / max(1, dom_n), 4),
+                         "launches": dom_n, "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": bytes_frame * B // max(1, launches_per_step),
+                         "binding_roof": "un-fused fp32 VALU (v_mul_f32+v_add_f32 per tap; FMA/MFMA would break bit-exactness)",
+                         "valu_achieved_Tops": round(valu_ops / 1e12, 2), "valu_peak_Tops": VALU_UNFUSED_PEAK / 1e12,
+                         "valu_frac": round(valu_ops / VALU_UNFUSED_PEAK, 4),
+                         "border_kernel_ms_per_step": round(gat_ms / args.steps, 4) if per_n > 0 else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    flt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,210 @@
+/*
+ * jincresize_hip.h -- C ABI of libjincresize_hip.so, the MI355X (gfx950) replacement for the
+ * per-frame hot path of Asd-g/AviSynth-JincResize v2.1.4.
+ *
+ * "ref:" citations are /root/reference/src/JincResize.cpp unless another file is named.
+ *
+ * What this boundary replaces in the reference plugin:
+ *   - Create_JincResize's argument handling + table construction          (ref :654-984)
+ *   - (d->*d->process_frame)(src, dst, vi) inside JincResize_GetFrame      (ref :615), i.e. the
+ *     resize_plane_{c,sse41,avx2,avx512}<T,thr,subsampled> kernels        (ref :536-601 and
+ *     resize_plane_sse41.cpp / _avx2.cpp / _avx512.cpp) and their row dispatch (ref :589-599)
+ *   - free_JincResize                                                     (ref :632-647)
+ * The AviSynth registration glue (avisynth_c_plugin_init, the Jinc36/64/144/256 aliases,
+ * _ChromaLocation frame property) stays on the plugin side and calls these entry points; the
+ * binding is shown in INTEGRATION.md.
+ *
+ * Results are those of the reference's opt=0 C++ path (resize_plane_c): bit-exact for 8..16-bit
+ * integer planes and for float planes (strict sequential un-fused fp32 accumulation).
+ *
+ * Plain pointers and sizes only; no C++ or framework types cross this boundary.  Every function
+ * returning int returns 0 on success and a negative jinc_status on failure; the message is
+ * available from jinc_last_error() (thread-local) and, for jinc_filter_create, also copied to
+ * the caller's buffer because AviSynth reports Create-time errors as strings (ref :682-687).
+ */
+#ifndef JINCRESIZE_HIP_H
+#define JINCRESIZE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define JINC_API __attribute__((visibility("default")))
+#else
+#define JINC_API
+#endif
+
+typedef enum jinc_status {
+    JINC_OK = 0,
+    JINC_ERR_INVALID_ARG = -1, /* argument rejected with one of the reference's "JincResize: ..." messages */
+    JINC_ERR_NO_DEVICE = -2,   /* no usable HIP device / HIP runtime error */
+    JINC_ERR_HIP = -3,
+    JINC_ERR_NOMEM = -4,
+    JINC_ERR_UNSUPPORTED = -5  /* geometry the reference itself handles with undefined behaviour */
+} jinc_status;
+
+/* The AVS_VideoInfo facts Create_JincResize / resize_plane_c read from the input clip:
+ * avs_is_planar (ref :700), width/height (ref :783-784), avs_bits_per_component (ref :793),
+ * avs_num_components (ref :798), avs_is_444 / avs_is_rgb (ref :826), avs_is_420 (ref :744),
+ * avs_get_plane_{width,height}_subsampling(vi, AVS_PLANAR_U) (ref :833-834),
+ * avs_component_size (ref :903). */
+typedef struct jinc_video_info {
+    int width;
+    int height;
+    int bits_per_component; /* 8, 10, 12, 14, 16 or 32 (float) */
+    int component_size;     /* bytes per sample: 1, 2 or 4 */
+    int num_components;     /* 1 (Y), 3 or 4 (with alpha) */
+    int is_planar;          /* non-zero for planar formats */
+    int is_rgb;             /* planar RGB(A): plane order G,B,R,A (ref :540) */
+    int sub_w;              /* log2 horizontal chroma subsampling (0 for Y/444/RGB) */
+    int sub_h;              /* log2 vertical chroma subsampling */
+} jinc_video_info;
+
+/* Bits of jinc_args.defined: which optional script arguments were given (avs_defined). */
+enum {
+    JINC_ARG_SRC_LEFT = 1 << 0,
+    JINC_ARG_SRC_TOP = 1 << 1,
+    JINC_ARG_SRC_WIDTH = 1 << 2,
+    JINC_ARG_SRC_HEIGHT = 1 << 3,
+    JINC_ARG_QUANT_X = 1 << 4,
+    JINC_ARG_QUANT_Y = 1 << 5,
+    JINC_ARG_TAP = 1 << 6,
+    JINC_ARG_BLUR = 1 << 7,
+    JINC_ARG_CPLACE = 1 << 8,
+    JINC_ARG_THREADS = 1 << 9,
+    JINC_ARG_OPT = 1 << 10,
+    JINC_ARG_INITIAL_CAPACITY = 1 << 11,
+    JINC_ARG_INITIAL_FACTOR = 1 << 12
+};
+
+/* The script arguments of JincResize(), in registration order (ref :1044-1060), as the plugin
+ * reads them in Create_JincResize (ref :703-789).  Arguments whose bit is clear in `defined`
+ * take the reference's defaults. */
+typedef struct jinc_args {
+    int target_width;       /* "i" (required) */
+    int target_height;      /* "i" (required) */
+    double src_left;        /* [src_left]f   default 0 */
+    double src_top;         /* [src_top]f    default 0 */
+    double src_width;       /* [src_width]f  default clip width;  <= 0: relative (ref :763-765) */
+    double src_height;      /* [src_height]f default clip height; <= 0: relative (ref :768-770) */
+    int quant_x;            /* [quant_x]i    default 256, 1..256 */
+    int quant_y;            /* [quant_y]i    default 256, 1..256 */
+    int tap;                /* [tap]i        default 3, 1..16 */
+    double blur;            /* [blur]f       default (and 0) -> 1.0 (ref :772-774) */
+    const char *cplace;     /* [cplace]s     "MPEG2" | "MPEG1" | "topleft", case-insensitive */
+    int threads;            /* [threads]i    0 or 1; advisory on the GPU path */
+    int opt;                /* [opt]i        -1..3; validated as in the reference, advisory on the GPU path */
+    int initial_capacity;   /* [initial_capacity]i > 0; validated, otherwise unused (scratch sizing only) */
+    double initial_factor;  /* [initial_factor]f >= 1.0; validated, otherwise unused */
+    unsigned defined;       /* JINC_ARG_* bits */
+    /* Host facts the reference queries from the script environment: */
+    int frame0_chroma_location; /* _ChromaLocation of frame 0 if that property is an int, else -1
+                                   (only consulted when cplace is not given; ref :727-742) */
+    int cpu_has_sse41;      /* avs_get_cpu_flags() & AVS_CPUF_SSE4_1 (ref :755) */
+    int cpu_has_avx2;       /* ... & AVS_CPUF_AVX2    (ref :753) */
+    int cpu_has_avx512f;    /* ... & AVS_CPUF_AVX512F (ref :751) */
+} jinc_args;
+
+/* Opaque filter instance = the reference's `JincResize` object (JincResize.h:39-57) plus its
+ * device-resident plan.  One instance is not re-entrant (AviSynth MT_MULTI_INSTANCE, ref :649-652):
+ * create one per host thread; instances share nothing mutable. */
+typedef struct jinc_filter jinc_filter;
+
+/* Number of usable HIP devices (0 when there is none); replaces nothing, used to shard frames. */
+JINC_API int jinc_device_count(void);
+
+/* Message of the last failure on the calling thread ("" if none). */
+JINC_API const char *jinc_last_error(void);
+
+/* Create_JincResize (ref :654-984): validates the arguments with the reference's rules and error
+ * strings, derives crop/chroma geometry (ref :762-866), builds the LUT and the coefficient plan(s)
+ * and uploads them to HIP device `device`.  On failure *out is NULL and the message (e.g.
+ * "JincResize: tap must be between 1..16.") is copied to err (if err_len > 0). */
+JINC_API int jinc_filter_create(const jinc_video_info *vi, const jinc_args *args, int device,
+                                jinc_filter **out, char *err, size_t err_len);
+
+/* free_JincResize (ref :632-647). NULL is allowed. */
+JINC_API void jinc_filter_free(jinc_filter *f);
+
+/* The output clip's AVS_VideoInfo: the input's with width/height replaced (ref :791-792). */
+JINC_API int jinc_filter_output_info(const jinc_filter *f, jinc_video_info *out_vi);
+
+/* Value JincResize_GetFrame writes to the _ChromaLocation frame property (ref :617-625):
+ * 0 mpeg2, 1 mpeg1, 2 topleft; -1 when the property is not written (not 4:2:0/4:2:2/4:1:1). */
+JINC_API int jinc_filter_chroma_location(const jinc_filter *f);
+
+/* The body of JincResize_GetFrame between avs_new_video_frame_p and avs_prop_set_int, i.e.
+ * (d->*d->process_frame)(src, dst, vi) (ref :615), on HOST plane buffers as AviSynth hands them
+ * over (avs_get_read_ptr_p / avs_get_write_ptr_p, pitches from avs_get_pitch_p in bytes).
+ * Planes are indexed in the reference's processing order (ref :539-541): {Y,U,V,A} or {G,B,R,A}.
+ * Synchronous: copies to the device, runs the kernels, copies back, returns when dst is complete. */
+JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], const int src_pitch[4],
+                                   void *const dst[4], const int dst_pitch[4]);
+
+/* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t, or
+ * NULL for the filter's own stream), for a batch of `nframes` independent frames (frames are the
+ * sharding unit; no frame reads another).  Plane i of frame n starts at
+ * src[i] + n*src_frame_stride[i] bytes (likewise dst).  Pitches/strides in bytes; sample alignment
+ * required.  src and dst must not overlap.  Returns after enqueueing. */
+JINC_API int jinc_filter_process_device(jinc_filter *f, const void *const src[4], const int src_pitch[4],
+                                        const size_t src_frame_stride[4], void *const dst[4],
+                                        const int dst_pitch[4], const size_t dst_frame_stride[4],
+                                        int nframes, void *hip_stream);
+
+/* Block until everything enqueued on the filter's own stream has finished. */
+JINC_API int jinc_filter_sync(jinc_filter *f);
+
+/* ---- Jinc36Resize / Jinc64Resize / Jinc144Resize / Jinc256Resize (ref :986-1040, :1061-1108) ----
+ * Builds the argument set the alias forwards through avs_invoke("JincResize", ...): the three
+ * positional arguments plus, when defined, src_left/top/width/height, quant_x/y, cplace, threads
+ * (ref :1007-1029), plus tap = taps (3, 4, 6 or 8; ref :1037).  Everything else stays undefined. */
+JINC_API int jinc_alias_args(int taps, const jinc_args *alias_in, jinc_args *out);
+
+/* ---- Plan introspection (tests, tools, benchmarks) -------------------------------------------- */
+typedef struct jinc_plan_info {
+    int src_width, src_height, dst_width, dst_height;
+    int filter_size;      /* ref :356 */
+    int num_sets;         /* distinct coefficient sets kept (the reference keeps one per border pixel) */
+    int periodic;         /* 1 when the interior was recognised as phase-periodic (fast kernel) */
+    int period_x, period_y;   /* output-pixel period of the interior phase pattern */
+    int step_x, step_y;       /* source-pixel advance per period */
+    int interior_x0, interior_x1, interior_y0, interior_y1; /* half-open interior rectangle */
+    int64_t plan_bytes;   /* bytes of the device-resident plan for this table */
+} jinc_plan_info;
+
+/* table: 0 = luma / all planes, 1 = chroma table of subsampled formats (ref :552-558). */
+JINC_API int jinc_filter_num_tables(const jinc_filter *f);
+JINC_API int jinc_filter_plan_info(const jinc_filter *f, int table, jinc_plan_info *out);
+/* Expands the compact plan back to the reference's per-pixel view for output pixel (x, y):
+ * start_x/start_y (EWAPixelCoeffMeta, JincResize.h:11-16) and the filter_size^2 coefficients
+ * (row-major, no stride padding) that pixel uses.  coeffs may be NULL. */
+JINC_API int jinc_filter_plan_pixel(const jinc_filter *f, int table, int x, int y, int *start_x, int *start_y,
+                                    float *coeffs);
+/* Bulk form: fills start_x[dst_w], start_y[dst_h] and set_id[dst_h*dst_w]; any pointer may be NULL. */
+JINC_API int jinc_filter_plan_dump(const jinc_filter *f, int table, int *start_x, int *start_y, int *set_id);
+/* Copies the coefficient set `set` (filter_size^2 floats). */
+JINC_API int jinc_filter_plan_set(const jinc_filter *f, int table, int set, float *coeffs);
+/* The 1024-entry LUT (ref :265-275) as doubles. */
+JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
+
+/* Kernel selection override for tests/benchmarks: 0 = automatic, 1 = force the generic gather
+ * kernel for every pixel, 2 = periodic fast kernel where the plan allows (same as automatic). */
+JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
+
+/* ---- Kernel timing (benchmarks) ---------------------------------------------------------------
+ * When enabled, every kernel launch made by jinc_filter_get_frame / jinc_filter_process_device is
+ * bracketed by a pair of hipEvents recorded on the launch stream.  jinc_filter_kernel_times waits
+ * for the recorded events, returns the accumulated device time (milliseconds) and launch count
+ * of the periodic-interior kernel and of the gather kernel since the last call, and resets them. */
+JINC_API int jinc_filter_set_profiling(jinc_filter *f, int enable);
+JINC_API int jinc_filter_kernel_times(jinc_filter *f, double *periodic_ms, int *periodic_launches,
+                                      double *gather_ms, int *gather_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JINCRESIZE_HIP_H */

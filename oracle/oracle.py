@@ -196,18 +196,22 @@ class Format:
         return out
 
 
-FORMATS = {
-    "Y8": Format("Y8", 8, 1), "Y10": Format("Y10", 10, 1), "Y16": Format("Y16", 16, 1), "Y32": Format("Y32", 32, 1),
-    "YV12": Format("YV12", 8, 3, 1, 1), "YV16": Format("YV16", 8, 3, 1, 0), "YV24": Format("YV24", 8, 3),
-    "YV411": Format("YV411", 8, 3, 2, 0),
-    "YUV420P10": Format("YUV420P10", 10, 3, 1, 1), "YUV420P16": Format("YUV420P16", 16, 3, 1, 1),
-    "YUV422P16": Format("YUV422P16", 16, 3, 1, 0), "YUV444P16": Format("YUV444P16", 16, 3),
-    "YUV444PS": Format("YUV444PS", 32, 3), "YUV420PS": Format("YUV420PS", 32, 3, 1, 1),
-    "YUVA420P8": Format("YUVA420P8", 8, 4, 1, 1), "YUVA444P16": Format("YUVA444P16", 16, 4),
-    "RGBP8": Format("RGBP8", 8, 3, rgb=True), "RGBP16": Format("RGBP16", 16, 3, rgb=True),
-    "RGBPS": Format("RGBPS", 32, 3, rgb=True), "RGBAP8": Format("RGBAP8", 8, 4, rgb=True),
-    "RGBAPS": Format("RGBAPS", 32, 4, rgb=True),
-}
+def _formats():
+    out = {}
+    for bits, tag in ((8, "8"), (10, "10"), (12, "12"), (14, "14"), (16, "16"), (32, "S")):
+        yname = "Y32" if bits == 32 else f"Y{tag}"
+        out[yname] = Format(yname, bits, 1)
+        for fam, sw, sh in (("420", 1, 1), ("422", 1, 0), ("444", 0, 0), ("411", 2, 0)):
+            out[f"YUV{fam}P{tag}"] = Format(f"YUV{fam}P{tag}", bits, 3, sw, sh)
+            out[f"YUVA{fam}P{tag}"] = Format(f"YUVA{fam}P{tag}", bits, 4, sw, sh)
+        out[f"RGBP{tag}"] = Format(f"RGBP{tag}", bits, 3, rgb=True)
+        out[f"RGBAP{tag}"] = Format(f"RGBAP{tag}", bits, 4, rgb=True)
+    out["YV12"], out["YV16"], out["YV24"], out["YV411"] = (out["YUV420P8"], out["YUV422P8"], out["YUV444P8"],
+                                                            out["YUV411P8"])
+    return out
+
+
+FORMATS = _formats()
 
 
 def alloc_plane(w: int, h: int, dtype, align: int = 64) -> np.ndarray:

@@ -1,0 +1,111 @@
+"""Create_JincResize argument surface through the C ABI: defaults, validation order and the
+reference's exact error strings (ref /root/reference/src/JincResize.cpp:700-789), plus the alias
+forwarding of Jinc36/64/144/256Resize (ref :1007-1040).  CPU only (device = -1)."""
+import numpy as np
+import pytest
+
+
+def mk(pkg, fmt="Y8", w=64, h=48, tw=128, th=96, **kw):
+    return pkg.Filter(pkg.FORMATS[fmt], w, h, tw, th, device=-1, **kw)
+
+
+@pytest.mark.parametrize("kw,msg", [
+    (dict(tap=0), "JincResize: tap must be between 1..16."),
+    (dict(tap=17), "JincResize: tap must be between 1..16."),
+    (dict(quant_x=0), "JincResize: quant_x must be between 1..256."),
+    (dict(quant_x=257), "JincResize: quant_x must be between 1..256."),
+    (dict(quant_y=0), "JincResize: quant_y must be between 1..256."),
+    (dict(cplace="jpeg"), "JincResize: cplace must be MPEG2, MPEG1 or topleft."),
+    (dict(cplace="topleft"), "JincResize: topleft must be used only for 4:2:0 chroma subsampling."),
+    (dict(opt=4), "JincResize: opt higher than 3 is not allowed."),
+    (dict(threads=2), "JincResize: threads must be either 0 or 1."),
+    (dict(threads=-1), "JincResize: threads must be either 0 or 1."),
+    (dict(initial_factor=0.5), "JincResize: initial_factor must be eqaul to or greater than 1.0."),
+    (dict(initial_capacity=0), "JincResize: initial_capacity must be greater than 0."),
+])
+def test_error_strings(pkg, kw, msg):
+    with pytest.raises(pkg.JincError) as e:
+        mk(pkg, **kw)
+    assert str(e.value) == msg and e.value.code == -1
+
+
+def test_validation_order(pkg):
+    """tap is checked before quant_x, quant_x before cplace (ref :703-724)."""
+    with pytest.raises(pkg.JincError) as e:
+        mk(pkg, tap=99, quant_x=999, cplace="bogus")
+    assert "tap" in str(e.value)
+    with pytest.raises(pkg.JincError) as e:
+        mk(pkg, quant_x=999, cplace="bogus")
+    assert "quant_x" in str(e.value)
+
+
+def test_non_planar_rejected(pkg):
+    with pytest.raises(pkg.JincError) as e:
+        pkg.Filter(pkg.FORMATS["Y8"], 64, 48, 128, 96, device=-1, planar=False)
+    assert str(e.value) == "JincResize: clip must be in planar format."
+
+
+def test_opt_requires_cpu_flags(pkg):
+    for opt, msg in ((3, "JincResize: opt=3 requires AVX-512F."), (2, "JincResize: opt=2 requires AVX2."),
+                     (1, "JincResize: opt=1 requires SSE4.1.")):
+        with pytest.raises(pkg.JincError) as e:
+            pkg.Filter(pkg.FORMATS["Y8"], 64, 48, 128, 96, device=-1, cpu_flags=(False, False, False), opt=opt)
+        assert str(e.value) == msg
+        mk(pkg, opt=opt).close()  # accepted (advisory) when the flag is present
+
+
+def test_cplace_case_insensitive_and_topleft_420(pkg):
+    f = mk(pkg, fmt="YUV420P8", cplace="TopLeft")
+    assert f.chroma_location == 2
+    assert mk(pkg, fmt="YUV420P8", cplace="MPEG1").chroma_location == 1
+    assert mk(pkg, fmt="YUV422P8").chroma_location == 0      # default mpeg2, property written for 4:2:2
+    assert mk(pkg, fmt="YUV411P8").chroma_location == 0
+    assert mk(pkg, fmt="YUV444P8").chroma_location == -1     # not written for 4:4:4 / Y / RGB (ref :617)
+    assert mk(pkg, fmt="Y8").chroma_location == -1
+    assert mk(pkg, fmt="RGBP8").chroma_location == -1
+
+
+def test_cplace_from_frame_property(pkg):
+    F = pkg.FORMATS["YUV420P8"]
+    assert pkg.Filter(F, 64, 48, 128, 96, device=-1, frame0_chroma_location=1).chroma_location == 1
+    assert pkg.Filter(F, 64, 48, 128, 96, device=-1, frame0_chroma_location=2).chroma_location == 2
+    assert pkg.Filter(F, 64, 48, 128, 96, device=-1, frame0_chroma_location=-1).chroma_location == 0
+    with pytest.raises(pkg.JincError) as e:
+        pkg.Filter(F, 64, 48, 128, 96, device=-1, frame0_chroma_location=5)
+    assert str(e.value) == "JincResize: invalid _ChromaLocation"
+    # an explicit cplace wins over the property (ref :717-742)
+    assert pkg.Filter(F, 64, 48, 128, 96, device=-1, frame0_chroma_location=1, cplace="mpeg2").chroma_location == 0
+
+
+def test_defaults_match_reference(pkg, O):
+    """No optional argument == tap 3, quant 256/256, blur 1.0, full-frame crop."""
+    a = mk(pkg)
+    b = mk(pkg, tap=3, quant_x=256, quant_y=256, blur=1.0, src_left=0.0, src_top=0.0, src_width=64.0, src_height=48.0)
+    assert np.array_equal(a.plan_sets(), b.plan_sets())
+    assert np.array_equal(a.lut(), O.make_lut(3, 1.0))
+    # blur = 0 means 1.0 (ref :772-774)
+    assert np.array_equal(mk(pkg, blur=0.0).plan_sets(), a.plan_sets())
+    # src_width <= 0 is relative to the clip (ref :763-765)
+    c = mk(pkg, src_left=2.0, src_width=-3.0)
+    d = mk(pkg, src_left=2.0, src_width=64 - 2.0 - 3.0)
+    assert np.array_equal(c.plan_sets(), d.plan_sets())
+
+
+def test_output_info(pkg):
+    f = mk(pkg, fmt="YUV420P16", w=64, h=48, tw=200, th=100)
+    assert (f.dst_w, f.dst_h) == (200, 100)
+    assert f.out_dims() == [(200, 100), (100, 50), (100, 50)]
+    assert f.num_tables == 2
+    assert mk(pkg, fmt="YUV444P16").num_tables == 1 and mk(pkg, fmt="RGBAP8").num_tables == 1
+
+
+@pytest.mark.parametrize("name,tap", [("Jinc36Resize", 3), ("Jinc64Resize", 4), ("Jinc144Resize", 6), ("Jinc256Resize", 8)])
+def test_alias_functions(pkg, name, tap):
+    """JincXXResize == JincResize(..., tap=N) and forwards only its own argument list."""
+    src = pkg.Clip(pkg.FORMATS["Y8"], 96, 64, 1, lambda n: [pkg.alloc_plane(96, 64, np.uint8)])
+    direct = pkg.Filter(pkg.FORMATS["Y8"], 96, 64, 192, 128, device=-1, tap=tap, src_left=1.5, quant_x=64)
+    alias = pkg.Filter(pkg.FORMATS["Y8"], 96, 64, 192, 128, device=-1, alias_taps=tap, src_left=1.5, quant_x=64,
+                       blur=0.5, opt=7)   # blur/opt are not alias arguments: they must not be forwarded
+    assert alias.plan_info().filter_size == direct.plan_info().filter_size
+    assert np.array_equal(alias.plan_sets(), direct.plan_sets())
+    assert callable(getattr(pkg, name))
