@@ -39,15 +39,19 @@ __device__ __forceinline__ float to_float(T v) {
     return static_cast<float>(v);
 }
 
-// ref :581-584 -- avs clamp order (upper bound first), lrintf = round-half-even.
+// ref :581-582 -- clamp(result, 0, peak) then lrintf (round-half-even).  For every non-NaN input
+// v_med3_f32(r, 0, peak) equals the reference's "upper bound first, then lower" clamp; a NaN (only
+// reachable through non-finite coefficients) ends as 0 on both sides.
+__device__ __forceinline__ uint32_t round_sample(float r, float peak) {
+    return static_cast<uint32_t>(__builtin_rintf(__builtin_amdgcn_fmed3f(r, 0.f, peak)));
+}
+
 template <typename T>
 __device__ __forceinline__ void store_sample(T* p, float r, float peak) {
     if constexpr (std::is_same_v<T, float>) {
         *p = r;
     } else {
-        r = r > peak ? peak : r;
-        r = r < 0.f ? 0.f : r;
-        *p = static_cast<T>(static_cast<uint32_t>(__builtin_rintf(r)));
+        *p = static_cast<T>(round_sample(r, peak));
     }
 }
 
@@ -60,6 +64,7 @@ struct GatherArgs {
     RectList rects;
     int block_begin[5];
     int blocks_x[4];
+    int lanes_x_log2[4];  // a 256-thread block covers (1 << lx) x (256 >> lx) output pixels of its rectangle
 };
 
 template <typename T, int FS>
@@ -70,8 +75,9 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     const int local = b - a.block_begin[r];
     const int bx = local % a.blocks_x[r];
     const int by = local / a.blocks_x[r];
-    const int x = a.rects.x0[r] + bx * 64 + (threadIdx.x & 63);
-    const int y = a.rects.y0[r] + by * 4 + (threadIdx.x >> 6);
+    const int lxl = a.lanes_x_log2[r];
+    const int x = a.rects.x0[r] + (bx << lxl) + (threadIdx.x & ((1 << lxl) - 1));
+    const int y = a.rects.y0[r] + by * (256 >> lxl) + (threadIdx.x >> lxl);
     if (x >= a.rects.x0[r] + a.rects.w[r] || y >= a.rects.y0[r] + a.rects.h[r]) return;
 
     const DevicePlan& p = a.plan;
@@ -164,9 +170,9 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 
         const float* base = tile + (a.start_y[q] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[p] - a.min_sx) + lane;
 
-        const int x = a.ix0 + a.px * (i0 + lane) + p;
-        const bool lane_ok = (i0 + lane) < a.ni;
-        T* dcol = reinterpret_cast<T*>(static_cast<char*>(io.dst) + frame * io.dst_frame_stride) + x;
+        const unsigned x = a.ix0 + a.px * (i0 + lane) + p;  // per-lane output column
+        if ((i0 + lane) >= a.ni) continue;                   // whole phase loop under one exec mask
+        char* dframe = static_cast<char*>(io.dst) + frame * io.dst_frame_stride;  // wave-uniform
 
         float win[FS][FS];
 #pragma unroll
@@ -189,11 +195,11 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 #pragma unroll
                     for (int lx = 0; lx < FS; ++lx) acc = acc + win[(u + ly) % FS][lx] * cf[ly * FS + lx];
 
-                const int j = j0 + g * FS + u;
-                if (lane_ok && j < a.nj) {
+                const int j = j0 + g * FS + u;  // wave-uniform
+                if (j < a.nj) {
                     const int y = a.iy0 + a.py * j + q;
-                    T* d = reinterpret_cast<T*>(reinterpret_cast<char*>(dcol) + static_cast<size_t>(y) * io.dst_pitch);
-                    store_sample<T>(d, acc, io.peak);
+                    T* drow = reinterpret_cast<T*>(dframe + static_cast<size_t>(y) * io.dst_pitch);  // SGPR base
+                    store_sample<T>(drow + x, acc, io.peak);
                 }
             }
         }
@@ -245,9 +251,14 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
     for (int r = 0; r < 4; ++r) {
         ga.block_begin[r] = total;
         ga.blocks_x[r] = 1;
+        ga.lanes_x_log2[r] = 6;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
-            ga.blocks_x[r] = (rects.w[r] + 63) / 64;
-            total += ga.blocks_x[r] * ((rects.h[r] + 3) / 4);
+            int lxl = 6;  // narrow rectangles (border columns) get tall blocks so lanes are not wasted
+            while (lxl > 2 && (1 << (lxl - 1)) >= rects.w[r]) --lxl;
+            ga.lanes_x_log2[r] = lxl;
+            const int bw = 1 << lxl, bh = 256 >> lxl;
+            ga.blocks_x[r] = (rects.w[r] + bw - 1) / bw;
+            total += ga.blocks_x[r] * ((rects.h[r] + bh - 1) / bh);
         }
     }
     ga.block_begin[4] = total;

@@ -100,13 +100,13 @@ def test_float_special_values(gpu_pkg, O):
     src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=1)
     p = src[0]
     p[:sh, :sw] = (rng.standard_normal((sh, sw)) * 4).astype(np.float32)          # negative and > 1 values
-    p[10:14, 10:40] = np.float32(1e-41)                                            # denormal inputs
-    p[20:24, 5:30] = np.float32(-3e-39)
+    p[8:26, 4:44] = np.float32(1e-41)                                              # denormal inputs (block > window)
+    p[12:20, 10:30] = np.float32(-3e-39)
     p[30, 50] = np.inf
     p[40, 20] = -np.inf
     p[50, 60] = np.nan
-    p[5:9, 60:90] = 0.0
-    p[5:9, 60:90] *= -1.0                                                          # negative zeros
+    p[36:50, 60:90] = 0.0
+    p[36:50, 60:90] *= -1.0                                                         # negative zeros
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
     want = of.get_frame(src)[0][:th, :tw]
     for mode in (0, 1):
@@ -123,22 +123,30 @@ def test_float_special_values(gpu_pkg, O):
 
 
 def test_integer_extremes(gpu_pkg, O):
-    """All-zero, all-peak and checkerboard planes: exercises the clamp at 0 and at peak (ref :582)."""
+    """All-zero, all-peak, checkerboard and hard-edged bars: the bars ring below 0 and above peak, which
+    exercises both clamp bounds (ref :582)."""
     for fmt, peak in (("Y8", 255), ("Y10", 1023), ("Y16", 65535)):
         sw, sh, tw, th = 128, 96, 256, 192
         of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
         f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
         yy, xx = np.mgrid[0:sh, 0:sw]
         for name, img in (("zero", np.zeros((sh, sw))), ("peak", np.full((sh, sw), peak)),
-                          ("checker", ((xx + yy) % 2) * peak), ("stripes", (xx % 2) * peak)):
+                          ("checker", ((xx + yy) % 2) * peak), ("stripes", (xx % 2) * peak),
+                          ("bars", ((xx // 8 + yy // 8) % 2) * peak)):
             p = gpu_pkg.alloc_plane(sw, sh, O.FORMATS[fmt].dtype)
             p[:sh, :sw] = img
             want = of.get_frame([p])
             got = f.get_frame([p])
             assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {name}")
-            if name == "checker":
+            if name == "bars":
                 v = want[0][:th, :tw]
-                assert v.min() == 0 and v.max() == peak, "overshoot must hit both clamp bounds"
+                assert v.min() == 0 and v.max() == peak
+                # without the clamp the sums leave [0, peak]: check via the float path on the same pattern
+                fo = O.OracleFilter(O.FORMATS["Y32"], sw, sh, tw, th)
+                pf = gpu_pkg.alloc_plane(sw, sh, np.float32)
+                pf[:sh, :sw] = img
+                vf = fo.get_frame([pf])[0][:th, :tw]
+                assert vf.min() < -0.5 and vf.max() > peak + 0.5, "bars must overshoot both clamp bounds"
         f.close()
 
 
