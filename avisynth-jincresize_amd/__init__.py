@@ -76,7 +76,7 @@ EXPORTS = ["jinc_device_count", "jinc_last_error", "jinc_filter_create", "jinc_f
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times"]
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -112,6 +112,7 @@ def lib():
         L.jinc_filter_plan_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.jinc_filter_lut.argtypes = [C.c_void_p, C.c_void_p]
         L.jinc_filter_set_kernel_mode.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_set_border_overlap.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                                C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -279,6 +280,9 @@ class Filter:
             dp[i], dpitch[i], ds[i] = dst_ptrs[i], dst_pitches[i], dst_strides[i]
         self._check(lib().jinc_filter_process_device(self._h, sp, spitch, ss, dp, dpitch, ds, int(nframes),
                                                      C.c_void_p(stream)))
+
+    def set_border_overlap(self, enable: bool) -> None:
+        self._check(lib().jinc_filter_set_border_overlap(self._h, int(enable)))
 
     def set_profiling(self, enable: bool) -> None:
         self._check(lib().jinc_filter_set_profiling(self._h, int(enable)))

@@ -79,6 +79,7 @@ struct jinc_filter {
     jinc::JincLut lut;
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
+    bool overlap_border = true;
 
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
     hipStream_t stream = nullptr;
@@ -87,6 +88,10 @@ struct jinc_filter {
     bool bufs_ready = false;
     bool profiling = false;
     std::vector<EventPair> ev_periodic, ev_gather;  // recorded, not yet collected
+    // The border gather kernel (load/store-issue bound) runs on a side stream next to the periodic
+    // interior kernel (VALU bound): fork/join with two reusable events.
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     ~jinc_filter() {
         if (device >= 0) {
@@ -102,6 +107,9 @@ struct jinc_filter {
                     (void)hipEventDestroy(e.start);
                     (void)hipEventDestroy(e.stop);
                 }
+            if (ev_fork) (void)hipEventDestroy(ev_fork);
+            if (ev_join) (void)hipEventDestroy(ev_join);
+            if (aux_stream) (void)hipStreamDestroy(aux_stream);
             if (stream) (void)hipStreamDestroy(stream);
         }
     }
@@ -368,6 +376,9 @@ void init_device(jinc_filter& f, int device) {
     hip_check(hipSetDevice(device), "hipSetDevice");
     f.device = device;
     hip_check(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipStreamCreateWithFlags(&f.aux_stream, hipStreamNonBlocking), "hipStreamCreate");
+    hip_check(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming), "hipEventCreate");
     f.tables.resize(f.plans.size());
     for (size_t i = 0; i < f.plans.size(); ++i) {
         upload_table(f.plans[i], f.tables[i], f.stream);
@@ -393,6 +404,15 @@ void ensure_frame_bufs(jinc_filter& f) {
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
              void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
     const int sb = f.vi_in.component_size;
+    bool any_periodic = false;
+    for (int i = 0; i < f.planecount; ++i)
+        any_periodic |= f.tables[f.table_of_plane(i)].use_periodic && f.kernel_mode != 1;
+    const bool fork = any_periodic && f.overlap_border;
+    if (fork) {  // border work may start once everything already queued on `stream` is done
+        hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");
+        hip_check(hipStreamWaitEvent(f.aux_stream, f.ev_fork, 0), "hipStreamWaitEvent(fork)");
+    }
+    hipStream_t border_stream = fork ? f.aux_stream : stream;
     for (int i = 0; i < f.planecount; ++i) {
         DeviceTable& t = f.tables[f.table_of_plane(i)];
         if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
@@ -411,26 +431,34 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         io.sample_bytes = sb;
         io.peak = f.peak;
         const bool periodic = t.use_periodic && f.kernel_mode != 1;
-        auto timed = [&](std::vector<EventPair>& sink, const char* what, auto&& launch) {
+        auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
             EventPair ev;
             if (f.profiling) {
                 hip_check(hipEventCreate(&ev.start), "hipEventCreate");
                 hip_check(hipEventCreate(&ev.stop), "hipEventCreate");
-                hip_check(hipEventRecord(ev.start, stream), "hipEventRecord");
+                hip_check(hipEventRecord(ev.start, s), "hipEventRecord");
             }
-            hip_check(static_cast<hipError_t>(launch()), what);
+            hip_check(static_cast<hipError_t>(launch(s)), what);
             if (f.profiling) {
-                hip_check(hipEventRecord(ev.stop, stream), "hipEventRecord");
+                hip_check(hipEventRecord(ev.stop, s), "hipEventRecord");
                 sink.push_back(ev);
             }
         };
         if (periodic) {
-            timed(f.ev_periodic, "periodic kernel launch", [&] { return jinc::launch_periodic(t.periodic, t.plan.fs, io, stream); });
             if (t.border_rects.n > 0)
-                timed(f.ev_gather, "border kernel launch", [&] { return jinc::launch_gather(t.plan, io, t.border_rects, stream); });
+                timed(f.ev_gather, border_stream, "border kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
+            timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
+                return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode == 3 ? 1 : 0);
+            });
         } else {
-            timed(f.ev_gather, "gather kernel launch", [&] { return jinc::launch_gather(t.plan, io, t.whole, stream); });
+            timed(f.ev_gather, stream, "gather kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.whole, s); });
         }
+    }
+    if (fork) {  // `stream` continues only after the border kernels have finished too
+        hip_check(hipEventRecord(f.ev_join, f.aux_stream), "hipEventRecord(join)");
+        hip_check(hipStreamWaitEvent(stream, f.ev_join, 0), "hipStreamWaitEvent(join)");
     }
 }
 
@@ -674,8 +702,14 @@ int jinc_filter_kernel_times(jinc_filter* f, double* periodic_ms, int* periodic_
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 2) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 3) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
+    return JINC_OK;
+}
+
+int jinc_filter_set_border_overlap(jinc_filter* f, int enable) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    f->overlap_border = enable != 0;
     return JINC_OK;
 }
 

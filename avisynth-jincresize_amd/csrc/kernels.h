@@ -57,6 +57,7 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 
 // True when a specialised periodic kernel exists for this filter size / period / sample type.
 bool periodic_supported(int fs, int px, int py, int sx, int sy);
-int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream);
+// variant: 0 = default choice per filter size, 1 = always the row-streamed kernel (A/B measurements)
+int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
 
 }  // namespace jinc

@@ -206,6 +206,141 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, row-streamed form (any filter size, used for fs > 9)
+// ------------------------------------------------------------------------------------------------
+// Same phase-uniform idea as ewa_periodic_kernel (one phase per wave => coefficients in SGPRs), but
+// sized for footprints whose fs x fs window does not fit the register file (fs = 17: 289 values):
+//   * a lane owns K = 4 consecutive source-aligned columns and R = 4 consecutive period-rows
+//     (16 independent accumulation chains), so one LDS row segment of fs+K-1 samples feeds K*fs taps;
+//   * the loop runs ly-major: the fs coefficients of kernel row ly sit in SGPRs and are reused by
+//     all 16 pixels; each pixel still sees its taps in (ly, lx) raster order, so every chain is the
+//     reference's sequential chain;
+//   * the LDS tile is stored as K column-planes (column c -> plane c % K, index c / K) so that the
+//     64 lanes of a wave, which are K columns apart, read consecutive LDS words (no bank conflicts).
+template <int FS>
+struct RowsCfg {
+    static constexpr int K = 4;        // columns per lane
+    static constexpr int R = 4;        // rows per chunk (accumulators per lane = R * K)
+    static constexpr int kChunks = 4;  // chunks per tile
+    static constexpr int kTileRows = R * kChunks;
+    static constexpr int kTileCols = 64 * K;
+    static constexpr int kCols = kTileCols + FS;  // + (FS-1) halo + 1 phase spread
+    static constexpr int kPlaneMin = 64 + (FS + K - 1) / K + 1;
+    static constexpr int kPlane = ((kPlaneMin - 8 + 31) / 32) * 32 + 8;  // == 8 (mod 32): the K planes start on distinct banks
+    static constexpr int kRows = kTileRows + FS;  // + (FS-1) halo + 1 phase spread
+    // LDS layout [plane][row][index]: every ds_read of a lane stays within 255 dwords of one of K
+    // per-plane base registers (ds_read2_b32 immediate range), so the inner loop has no address VALU.
+    static constexpr int kPlaneStride = kRows * kPlane;  // kRows is odd -> plane bases fall on distinct banks
+    static constexpr int kWaves = 8;
+    static constexpr int kThreads = 64 * kWaves;
+};
+
+template <typename T, int FS, int OFF>
+__device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs, char* dframe,
+                                          int dst_pitch, float peak, int y0, int ystep, int rows_valid, unsigned x0,
+                                          unsigned xstep, int cols_valid) {
+    using Cfg = RowsCfg<FS>;
+    constexpr int K = Cfg::K, R = Cfg::R;
+    float acc[R][K];
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[jj][k] = 0.f;
+
+    // One LDS word offset per plane, kept in its own VGPR (the empty asm stops the compiler from
+    // re-deriving plane bases as "base + large constant" with a VALU add in front of every read).
+    unsigned plane_off[K];
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        plane_off[m] = base_off + m * Cfg::kPlaneStride;
+        asm volatile("" : "+v"(plane_off[m]));
+    }
+
+    for (int ly = 0; ly < FS; ++ly) {
+        float c[FS];
+#pragma unroll
+        for (int lx = 0; lx < FS; ++lx) c[lx] = cs[ly * FS + lx];
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            float seg[FS + K - 1];
+#pragma unroll
+            for (int u = 0; u < FS + K - 1; ++u)
+                seg[u] = tile[plane_off[(u + OFF) % K] + (jj * Cfg::kPlane + (u + OFF) / K)];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx) acc[jj][k] = acc[jj][k] + seg[k + lx] * c[lx];
+        }
+#pragma unroll
+        for (int m = 0; m < K; ++m) plane_off[m] += Cfg::kPlane;  // next kernel row
+    }
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj) {
+        if (jj < rows_valid) {  // wave-uniform
+            T* drow = reinterpret_cast<T*>(dframe + static_cast<size_t>(y0 + jj * ystep) * dst_pitch);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (k < cols_valid) store_sample<T>(drow + (x0 + k * xstep), acc[jj][k], peak);
+        }
+    }
+}
+
+template <typename T, int FS>
+__global__ __launch_bounds__(RowsCfg<FS>::kThreads) void ewa_periodic_rows_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = RowsCfg<FS>;
+    constexpr int K = Cfg::K, R = Cfg::R;
+    __shared__ float tile[K * Cfg::kPlaneStride];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i0 = blockIdx.x * Cfg::kTileCols;
+    const int j0 = blockIdx.y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+
+    {
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        for (int r = wave; r < Cfg::kRows; r += Cfg::kWaves) {
+            int gy = gy0 + r;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int c = lane; c < Cfg::kCols; c += 64) {
+                int gx = gx0 + c;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = to_float(srow[gx]);
+            }
+        }
+    }
+    __syncthreads();
+
+    char* dframe = static_cast<char*>(io.dst) + frame * io.dst_frame_stride;
+    const int nphase = a.px * a.py;
+    const int nitems = nphase * Cfg::kChunks;
+    const int cols_valid = a.ni - (i0 + K * lane);  // per lane: how many of its K columns exist
+    if (cols_valid <= 0) return;
+    for (int item = wave; item < nitems; item += Cfg::kWaves) {
+        const int ch = item / nphase;
+        const int ph = item - ch * nphase;
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+        const int j = j0 + ch * R;  // first period-row of the chunk
+        const int rows_valid = a.nj - j;
+        if (rows_valid <= 0) continue;
+        const JINC_CONSTANT float* cs =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * FS));
+        const unsigned base = ((a.start_y[q] - a.min_sy) + ch * R) * Cfg::kPlane + lane;
+        const int y0 = a.iy0 + a.py * j + q;
+        const unsigned x0 = a.ix0 + a.px * (i0 + K * lane) + p;
+        if (a.start_x[p] - a.min_sx)
+            rows_item<T, FS, 1>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+        else
+            rows_item<T, FS, 0>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+    }
+}
+
 template <typename T, int FS>
 int launch_gather_t(const GatherArgs& ga, int total_blocks, hipStream_t stream) {
     dim3 grid(total_blocks, ga.io.nframes, 1), block(256, 1, 1);
@@ -231,11 +366,29 @@ int launch_periodic_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t str
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int FS>
+int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = RowsCfg<FS>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_rows_kernel<T, FS>), grid, dim3(Cfg::kThreads, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T>
-int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream) {
+int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
+    if (variant == 1) {
+        if (fs == 7) return launch_rows_t<T, 7>(pa, io, stream);
+        if (fs == 9) return launch_rows_t<T, 9>(pa, io, stream);
+    }
     switch (fs) {
+        case 3: return launch_rows_t<T, 3>(pa, io, stream);
+        case 5: return launch_rows_t<T, 5>(pa, io, stream);
         case 7: return launch_periodic_t<T, 7>(pa, io, stream);
         case 9: return launch_periodic_t<T, 9>(pa, io, stream);
+        case 11: return launch_rows_t<T, 11>(pa, io, stream);
+        case 13: return launch_rows_t<T, 13>(pa, io, stream);
+        case 15: return launch_rows_t<T, 15>(pa, io, stream);
+        case 17: return launch_rows_t<T, 17>(pa, io, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
 }
@@ -274,16 +427,16 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 bool periodic_supported(int fs, int px, int py, int sx, int sy) {
     if (sx != 1 || sy != 1) return false;
     if (px < 1 || py < 1 || px > 8 || py > 8) return false;
-    return fs == 7 || fs == 9;
+    return fs >= 3 && fs <= 17 && (fs & 1);  // taps 1..8 at >= 1x scale
 }
 
-int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream) {
+int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant) {
     if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (io.sample_bytes) {
-        case 1: return launch_periodic_fs<uint8_t>(args, fs, io, s);
-        case 2: return launch_periodic_fs<uint16_t>(args, fs, io, s);
-        default: return launch_periodic_fs<float>(args, fs, io, s);
+        case 1: return launch_periodic_fs<uint8_t>(args, fs, io, s, variant);
+        case 2: return launch_periodic_fs<uint16_t>(args, fs, io, s, variant);
+        default: return launch_periodic_fs<float>(args, fs, io, s, variant);
     }
 }
 

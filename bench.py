@@ -78,22 +78,78 @@ def cpu_baseline(cfg_name, budget_s=12.0):
     fmt = O.FORMATS[fmt_name]
     flt = O.OracleFilter(fmt, sw, sh, dw, dh, **kw)
     src = O.lcg_frame(fmt, sw, sh)
-    cores = os.cpu_count() or 1
-    out = {}
-    for label, threads, share in (("all", cores, 0.6), ("one", 1, 0.4)):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+
+    def run(threads, budget, max_frames=64):
         n, t0 = 0, time.perf_counter()
         while True:
             flt.get_frame(src, threads=threads)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s * share or n >= 64:
-                break
-        out[label] = (dw * dh * n / el / 1e6, n, el)
-    v, n, el = out["all"]
-    return {"value": round(v, 2), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": f"{n} frames of {cfg_name} in {el:.1f}s, oracle rows over {cores} OpenMP threads",
-            "single_core_value": round(out["one"][0], 2),
-            "single_core_sample": f"{out['one'][1]} frames in {out['one'][2]:.1f}s"}
+            if el > budget or n >= max_frames:
+                return dw * dh * n / el / 1e6, n, el
+
+    # the row fan-out does not scale to every core count (memory-bound table walk, container CPU
+    # quotas): probe a few thread counts briefly and keep the fastest for the timed sample
+    run(1, 0.0, 1)  # touch tables once
+    cands = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, avail) if t <= avail})
+    probe = {t: run(t, 0.4, 4)[0] for t in cands}
+    best = max(probe, key=probe.get)
+    v, n, el = run(best, budget_s * 0.6)
+    v1, n1, el1 = run(1, budget_s * 0.3)
+    return {"value": round(v, 2), "unit": "Mpix/s", "cores": best, "kind": "port",
+            "sample": f"{n} frames of {cfg_name} in {el:.1f}s; oracle (opt=0 port) rows over {best} OpenMP "
+                      f"threads (fastest of {cands} on a host with {avail} usable cores)",
+            "single_core_value": round(v1, 2),
+            "single_core_sample": f"{n1} frames in {el1:.1f}s",
+            "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in probe.items()}}
+
+
+def make_workload(pkg, torch, config, frames, device, seed):
+    """Creates the filter and a batch of `frames` synthetic frames resident in HBM (random samples, not
+    zeros: DVFS differs); returns (filter, step(), stream, format, output plane dims).  One step() =
+    one jinc_filter_process_device call over the whole batch on torch's current stream."""
+    fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
+    fmt = pkg.FORMATS[fmt_name]
+    flt = pkg.Filter(fmt, sw, sh, dw, dh, device=device, **kw)
+    tdtype = {1: torch.uint8, 2: torch.uint16, 4: torch.float32}[fmt.sample_bytes]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    sdims, ddims = fmt.plane_dims(sw, sh), fmt.plane_dims(dw, dh)
+    sb = fmt.sample_bytes
+
+    def pitch_elems(w):
+        return ((w * sb + 255) // 256 * 256) // sb
+
+    src_t, dst_t = [], []
+    for (w, h) in sdims:
+        shape = (frames, h, pitch_elems(w))
+        if sb == 4:
+            t = torch.rand(shape, device="cuda", generator=gen, dtype=torch.float32)
+        else:
+            t = torch.randint(0, 1 << fmt.bits, shape, device="cuda", generator=gen, dtype=torch.int32).to(
+                torch.uint8 if sb == 1 else torch.int16)
+            if sb == 2:
+                t = t.view(torch.uint16)
+        src_t.append(t)
+    for (w, h) in ddims:
+        dst_t.append(torch.zeros((frames, h, pitch_elems(w)), device="cuda", dtype=tdtype))
+    sp = [t.data_ptr() for t in src_t]
+    spitch = [t.stride(1) * sb for t in src_t]
+    sstride = [t.stride(0) * sb for t in src_t]
+    dp = [t.data_ptr() for t in dst_t]
+    dpitch = [t.stride(1) * sb for t in dst_t]
+    dstride = [t.stride(0) * sb for t in dst_t]
+    stream = torch.cuda.current_stream()
+
+    def step():
+        flt.process_device(sp, spitch, sstride, dp, dpitch, dstride, frames, stream=stream.cuda_stream)
+
+    step.keepalive = (src_t, dst_t)
+    return flt, step, stream, fmt, ddims
 
 
 def main():
@@ -125,46 +181,11 @@ def main():
 
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, default_frames = CONFIGS[args.config]
-    fmt = pkg.FORMATS[fmt_name]
     B = args.frames or default_frames
-    flt = pkg.Filter(fmt, sw, sh, dw, dh, device=local_rank, **kw)
+    flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, local_rank, 12345 + rank * B)
     flt.set_kernel_mode(args.kernel_mode)
     info = flt.plan_info(0)
-
-    # ---- synthetic frames, resident in HBM: rank r owns global frames [r*B, (r+1)*B) ----
-    tdtype = {1: torch.uint8, 2: torch.uint16, 4: torch.float32}[fmt.sample_bytes]
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(12345 + rank)
-    sdims, ddims = fmt.plane_dims(sw, sh), fmt.plane_dims(dw, dh)
-
-    def pitch_elems(w):
-        return ((w * fmt.sample_bytes + 255) // 256 * 256) // fmt.sample_bytes
-
-    src_t, dst_t = [], []
-    for (w, h) in sdims:
-        shape = (B, h, pitch_elems(w))
-        if fmt.sample_bytes == 4:
-            t = torch.rand(shape, device="cuda", generator=gen, dtype=torch.float32)
-        else:
-            hi = 1 << fmt.bits
-            t = torch.randint(0, hi, shape, device="cuda", generator=gen, dtype=torch.int32).to(
-                torch.uint8 if fmt.sample_bytes == 1 else torch.int16)
-            if fmt.sample_bytes == 2:
-                t = t.view(torch.uint16)
-        src_t.append(t)
-    for (w, h) in ddims:
-        dst_t.append(torch.zeros((B, h, pitch_elems(w)), device="cuda", dtype=tdtype))
     sb = fmt.sample_bytes
-    sp = [t.data_ptr() for t in src_t]
-    spitch = [t.stride(1) * sb for t in src_t]
-    sstride = [t.stride(0) * sb for t in src_t]
-    dp = [t.data_ptr() for t in dst_t]
-    dpitch = [t.stride(1) * sb for t in dst_t]
-    dstride = [t.stride(0) * sb for t in dst_t]
-    stream = torch.cuda.current_stream()
-
-    def step():
-        flt.process_device(sp, spitch, sstride, dp, dpitch, dstride, B, stream=stream.cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -190,9 +211,9 @@ def main():
 
     if rank == 0:
         bytes_frame = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
-        n_planes = fmt.planes
         fs = info.filter_size
         samples_frame = sum(w * h for (w, h) in ddims)
+        n_planes = fmt.planes
         if per_n > 0:
             dom_name, dom_ms, dom_n = "ewa_periodic_kernel", per_ms, per_n
         else:

@@ -28,9 +28,17 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // MODE 1: 4 independent packed chains  A = A + A*C        (v_pk_mul_f32 + v_pk_add_f32)
 // MODE 2: 8 independent fma chains     a = fma(a,c,a)     (v_fma/v_fmac; reference point only)
 // MODE 3: 1 scalar chain, products independent of the chain: a = a + w_k*c_k (the real kernel's shape)
+// per-wave clock stamps: s_memtime = shader clock ticks, s_memrealtime = 100 MHz constant clock
+__device__ unsigned long long g_stamps[4];
+
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(float* out, float c, int iters) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long t0 = 0, r0 = 0;
+    if (tid == 0) {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
     float seed = 1.0f + 1e-3f * (threadIdx.x & 63);
     if constexpr (MODE == 0) {
         float a[8];
@@ -78,6 +86,12 @@ __global__ __launch_bounds__(256) void probe(float* out, float c, int iters) {
         }
         out[tid] = a;
     }
+    if (tid == 0) {
+        g_stamps[0] = t0;
+        g_stamps[1] = r0;
+        g_stamps[2] = __builtin_amdgcn_s_memtime();
+        g_stamps[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 int main() {
@@ -114,7 +128,12 @@ int main() {
             }
             // per lane per iteration: 8 multiplies + 8 adds = 16 IEEE ops (fma mode: 8 fma = 16 flop)
             const double ops = 16.0 * iters * 256.0 * blocks;
-            std::printf("%-26s waves/SIMD %d : %8.3f ms  %7.2f Tops/s\n", names[mode], wps, best, ops / best * 1e-9);
+            unsigned long long st[4];
+            CHECK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof(st)));
+            const double mhz = double(st[2] - st[0]) / double(st[3] - st[1]) * 100.0;
+            const double cyc_per_instr = double(st[2] - st[0]) / (double(iters) * (mode == 0 || mode == 3 ? 16 : 8) * wps);
+            std::printf("%-26s waves/SIMD %d : %8.3f ms  %7.2f Tops/s  shader clock %6.0f MHz  %.2f clk per wave-instr per SIMD\n",
+                        names[mode], wps, best, ops / best * 1e-9, mhz, cyc_per_instr);
         }
     }
     return 0;

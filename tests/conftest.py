@@ -5,6 +5,14 @@ import sys
 import numpy as np
 import pytest
 
+# PyTorch-ROCm bundles its own HIP runtime; when a process uses both torch and libjincresize_hip.so the
+# runtime that is loaded first serves both, and only torch's own copy is known to work for torch.  The
+# device-batch test passes torch tensors to the C ABI, so torch goes first (plumbing, not the product).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -35,6 +35,11 @@ SMALL_CASES = [
     ("Y8", 90, 70, 180, 140, dict(tap=5)),
     ("Y8", 160, 120, 320, 240, dict(tap=8)),                        # fs 17
     ("Y8", 120, 90, 240, 180, dict(tap=16)),                        # fs 33 (runtime-size loop)
+    ("Y8", 150, 100, 300, 200, dict(tap=2)),                        # fs 5  row-streamed periodic kernel
+    ("Y16", 150, 100, 300, 200, dict(tap=6)),                       # fs 13
+    ("Y32", 150, 100, 300, 200, dict(tap=7)),                       # fs 15
+    ("Y8", 300, 40, 1200, 160, dict(tap=1)),                        # 4x, fs 3, several 256-column tiles
+    ("Y16", 531, 70, 1062, 140, dict(tap=8)),                       # fs 17, ragged tile edges in x and y
     ("Y10", 128, 96, 256, 192, {}),                                 # peak 1023 clamp
     ("Y12", 128, 96, 256, 192, dict(tap=4)),
     ("Y14", 128, 96, 200, 150, {}),
