@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of kernel variants in ONE process on ONE device (cdna_hip_programming.md
 rule 24): for every variant, `rounds` rounds of `steps` steps each, round-robin over variants.
-Prints median / min of the whole-step device time (hipEvents around the step on the launch stream)
+Prints median / min of the whole-step wall time (device-synchronised, `steps` steps per sample)
 and of the periodic-kernel time reported by the library's own events.
 
 usage: python profiles/ab_kernels.py [--config C2] [--frames 64] [--rounds 7] [--steps 5] variant [variant ...]
@@ -13,6 +13,7 @@ import json
 import os
 import statistics
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,7 +37,6 @@ def main():
     flt, step, stream, fmt, ddims = bench.make_workload(pkg, torch, a.config, B, 0, 12345)
     _, sw, sh, dw, dh, kw, _ = bench.CONFIGS[a.config]
     res = {v: {"step_ms": [], "periodic_ms": [], "gather_ms": []} for v in a.variants}
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rnd in range(a.rounds + 1):
         for v in a.variants:
             mode = int(v.rstrip("os"))
@@ -45,16 +45,16 @@ def main():
             flt.set_profiling(True)
             flt.kernel_times()
             torch.cuda.synchronize()
-            e0.record(stream)
+            t0 = time.perf_counter()
             for _ in range(a.steps):
                 step()
-            e1.record(stream)
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()  # device-wide: the library may run on its own streams
+            wall_ms = (time.perf_counter() - t0) * 1e3
             pm, pn, gm, gn = flt.kernel_times()
             flt.set_profiling(False)
             if rnd == 0:
                 continue  # warm-up round
-            res[v]["step_ms"].append(e0.elapsed_time(e1) / a.steps)
+            res[v]["step_ms"].append(wall_ms / a.steps)
             res[v]["periodic_ms"].append(pm / a.steps)
             res[v]["gather_ms"].append(gm / a.steps)
     pix = dw * dh * B
