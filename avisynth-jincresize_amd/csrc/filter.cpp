@@ -282,7 +282,14 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
     const size_t i_is = add(p.interior_set.data(), p.interior_set.size() * 4);
     const size_t i_bc = add(p.bcol_set.data(), p.bcol_set.size() * 4);
     const size_t i_br = add(p.brow_set.data(), p.brow_set.size() * 4);
-    const size_t i_co = add(p.coeffs.data(), p.coeffs.size() * 4);
+    // device layout of a set: fs rows of padded_fs floats (row stride a multiple of 16 bytes, zero padded)
+    const int fsp = (p.fs + 3) & ~3;
+    std::vector<float> padded(static_cast<size_t>(p.num_sets) * p.fs * fsp, 0.f);
+    for (int s = 0; s < p.num_sets; ++s)
+        for (int ly = 0; ly < p.fs; ++ly)
+            std::memcpy(&padded[(static_cast<size_t>(s) * p.fs + ly) * fsp], p.set_ptr(s) + static_cast<size_t>(ly) * p.fs,
+                        sizeof(float) * p.fs);
+    const size_t i_co = add(padded.data(), padded.size() * 4);
     t.bytes = align_up(off, 256);
     hip_check(hipMalloc(&t.blob, t.bytes), "hipMalloc(plan)");
     char* base = static_cast<char*>(t.blob);
@@ -449,7 +456,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
             timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
-                return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode == 3 ? 1 : 0);
+                return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode >= 3 ? f.kernel_mode - 2 : 0);
             });
         } else {
             timed(f.ev_gather, stream, "gather kernel launch",
@@ -702,7 +709,7 @@ int jinc_filter_kernel_times(jinc_filter* f, double* periodic_ms, int* periodic_
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 3) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 5) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

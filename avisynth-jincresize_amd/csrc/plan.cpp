@@ -173,6 +173,11 @@ PlanePlan build_plane_plan(const JincLut& lut, const TableGeometry& g) {
 
     plan.col_start = cols.start;
     plan.row_start = rows.start;
+    // The kernels size their source tiles from the first and last window origin of a block.
+    for (int i = 1; i < g.dst_w; ++i)
+        if (cols.start[i] < cols.start[i - 1]) throw std::runtime_error("JincResize: window origins are not monotonic in x.");
+    for (int i = 1; i < g.dst_h; ++i)
+        if (rows.start[i] < rows.start[i - 1]) throw std::runtime_error("JincResize: window origins are not monotonic in y.");
 
     // ---- coefficient sets, one per distinct (column profile, row profile) pair -------------------
     const double radius2 = g.radius * g.radius;  // ref :377
