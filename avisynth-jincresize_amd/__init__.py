@@ -281,8 +281,9 @@ class Filter:
         self._check(lib().jinc_filter_process_device(self._h, sp, spitch, ss, dp, dpitch, ds, int(nframes),
                                                      C.c_void_p(stream)))
 
-    def set_border_overlap(self, enable: bool) -> None:
-        self._check(lib().jinc_filter_set_border_overlap(self._h, int(enable)))
+    def set_border_overlap(self, enable) -> None:
+        """True / False, or None for the automatic choice."""
+        self._check(lib().jinc_filter_set_border_overlap(self._h, -1 if enable is None else int(bool(enable))))
 
     def set_profiling(self, enable: bool) -> None:
         self._check(lib().jinc_filter_set_profiling(self._h, int(enable)))

@@ -79,7 +79,7 @@ struct jinc_filter {
     jinc::JincLut lut;
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
-    bool overlap_border = true;
+    int overlap_border = -1;  // -1: automatic (side stream when the border frame is heavy: fs > 9), 0: off, 1: on
 
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
     hipStream_t stream = nullptr;
@@ -261,6 +261,23 @@ void configure(jinc_filter& f, const jinc_video_info& vi, const jinc_args& a) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Smallest stride P <= 8 such that at least 90 % of the interior coordinates keep their class when
+// stepping by P (1 if there is none).  Exact for periodic plans; for drifting ratios (1.5x, 3x) it is
+// the nominal period, and the gather kernel's waterfall absorbs the deviations.
+int dominant_period(const std::vector<int32_t>& cls) {
+    const int n = static_cast<int>(cls.size());
+    for (int P = 1; P <= 8; ++P) {
+        long long same = 0, total = 0;
+        for (int i = 0; i + P < n; ++i) {
+            if (cls[i] < 0 || cls[i + P] < 0) continue;
+            ++total;
+            same += cls[i] == cls[i + P];
+        }
+        if (total > 0 && same * 10 >= total * 9) return P;
+    }
+    return 1;
+}
+
 void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) {
     struct Piece {
         const void* host;
@@ -312,6 +329,8 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
     t.plan.dst_h = p.g.dst_h;
     t.plan.fs = p.fs;
     t.plan.n_col_classes = p.n_col_classes;
+    t.plan.gather_period_x = dominant_period(p.col_class);
+    t.plan.gather_period_y = dominant_period(p.row_class);
 }
 
 // Decides how the output plane is split between the periodic kernel and the gather kernel.
@@ -414,7 +433,9 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i)
         any_periodic |= f.tables[f.table_of_plane(i)].use_periodic && f.kernel_mode != 1;
-    const bool fork = any_periodic && f.overlap_border;
+    // A/B on MI355X: overlapping wins 12 % on C3 (fs 17) and 2-3 % on C4 (fs 9), loses 4 % on C2 (fs 7).
+    const bool want_overlap = f.overlap_border < 0 ? f.plans[0].fs >= 9 : f.overlap_border != 0;
+    const bool fork = any_periodic && want_overlap;
     if (fork) {  // border work may start once everything already queued on `stream` is done
         hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");
         hip_check(hipStreamWaitEvent(f.aux_stream, f.ev_fork, 0), "hipStreamWaitEvent(fork)");
@@ -716,7 +737,7 @@ int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
 
 int jinc_filter_set_border_overlap(jinc_filter* f, int enable) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
-    f->overlap_border = enable != 0;
+    f->overlap_border = enable < 0 ? -1 : (enable != 0);
     return JINC_OK;
 }
 

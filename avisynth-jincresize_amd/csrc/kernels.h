@@ -19,6 +19,8 @@ struct DevicePlan {
     int src_w = 0, src_h = 0, dst_w = 0, dst_h = 0;
     int fs = 0;
     int n_col_classes = 0;
+    // Dominant phase period of the output columns / rows (1..8): the lane stride of the gather kernel.
+    int gather_period_x = 1, gather_period_y = 1;
 };
 
 // One plane of a batch of frames, device pointers, pitches/strides in bytes.

@@ -63,15 +63,25 @@ struct GatherArgs {
     PlaneIO io;
     RectList rects;
     int block_begin[5];
-    int blocks_x[4];
-    int lanes_x_log2[4];  // a 256-thread block covers (1 << lx) x (256 >> lx) output pixels of its rectangle
+    int blocks_a[4];  // blocks along the lane axis of each rectangle
+    int lane_axis[4]; // 0: lanes run along x (wide rectangles), 1: along y (border columns)
+    int stride[4];    // lane stride P: lane l of an item handles coordinate origin + P*l + residue
 };
 
 constexpr int kGatherLdsFloats = 6144;  // 24 KB source tile per block
+constexpr int kGatherLines = 4;         // lines (rows for lane_axis 0, columns for lane_axis 1) per block
 
 // Coefficient rows are padded to a multiple of 4 floats on the device (16-byte aligned rows).
 __host__ __device__ constexpr int padded_row(int fs) { return (fs + 3) & ~3; }
 
+// Any plan.  A block covers 64*P coordinates along the lane axis x 4 lines; its source footprint is
+// staged once in LDS as fp32.  Work items = (line, residue): the 64 lanes of an item are P apart, P
+// being the plan's dominant phase period, so that (nearly) all lanes of an item share one coefficient
+// set.  The item then runs a waterfall over the distinct sets actually present: the set of the first
+// pending lane is made wave-uniform (readlane), its coefficients are fetched with scalar loads into
+// SGPRs and every lane that uses this set runs its sequential chain.  For exactly periodic plans
+// that is one pass; ratios whose phases drift (1.5x, 3x: the reference accumulates positions in
+// float) add a pass per deviation.  There is no per-lane coefficient traffic.
 template <typename T, int FS>
 __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     __shared__ float tile[kGatherLdsFloats];
@@ -80,22 +90,25 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     int r = 0;
     while (r + 1 < a.rects.n && b >= a.block_begin[r + 1]) ++r;
     const int local = b - a.block_begin[r];
-    const int bx = local % a.blocks_x[r];
-    const int by = local / a.blocks_x[r];
-    const int lxl = a.lanes_x_log2[r];
-    const int rx1 = a.rects.x0[r] + a.rects.w[r], ry1 = a.rects.y0[r] + a.rects.h[r];
-    const int bx0 = a.rects.x0[r] + (bx << lxl);          // block origin and (clipped) last pixel: wave-uniform
-    const int by0 = a.rects.y0[r] + by * (256 >> lxl);
-    const int bx1 = min(bx0 + (1 << lxl), rx1) - 1;
-    const int by1 = min(by0 + (256 >> lxl), ry1) - 1;
-    const int x = bx0 + (threadIdx.x & ((1 << lxl) - 1));
-    const int y = by0 + (threadIdx.x >> lxl);
-    const bool active = x <= bx1 && y <= by1;
+    const int axis = a.lane_axis[r];
+    const int P = a.stride[r];
+    const int ba = local % a.blocks_a[r];  // block index along the lane axis
+    const int bl = local / a.blocks_a[r];  // block index along the line axis
+    const int rx0 = a.rects.x0[r], ry0 = a.rects.y0[r];
+    const int rx1 = rx0 + a.rects.w[r], ry1 = ry0 + a.rects.h[r];
+    // block extent in output pixels (inclusive last pixel), all wave-uniform
+    const int bx0 = axis == 0 ? rx0 + ba * 64 * P : rx0 + bl * kGatherLines;
+    const int by0 = axis == 0 ? ry0 + bl * kGatherLines : ry0 + ba * 64 * P;
+    const int bx1 = min(bx0 + (axis == 0 ? 64 * P : kGatherLines), rx1) - 1;
+    const int by1 = min(by0 + (axis == 0 ? kGatherLines : 64 * P), ry1) - 1;
 
     const int fs = FS ? FS : p.fs;
     const int fsp = FS ? padded_row(FS) : padded_row(p.fs);
     const size_t frame = blockIdx.y;
     const char* sframe = static_cast<const char*>(a.io.src) + frame * a.io.src_frame_stride;
+    char* dframe = static_cast<char*>(a.io.dst) + frame * a.io.dst_frame_stride;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
     // Source footprint of the block (window origins are non-decreasing in x and in y).
     const int tx0 = p.col_start[bx0], ty0 = p.row_start[by0];
@@ -104,7 +117,6 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     const int pitch = tw | 1;
     const bool staged = pitch * th <= kGatherLdsFloats;  // wave-uniform; huge down-scales read global memory
     if (staged) {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int rr = wave; rr < th; rr += 4) {
             const T* srow = reinterpret_cast<const T*>(sframe + static_cast<size_t>(ty0 + rr) * a.io.src_pitch) + tx0;
             for (int c = lane; c < tw; c += 64) tile[rr * pitch + c] = to_float(srow[c]);
@@ -112,90 +124,96 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     }
     __syncthreads();
 
-    // Inactive lanes (block overhang) look up the block's first pixel so every address stays in range.
-    const int qx = active ? x : bx0, qy = active ? y : by0;
-    const int sx = p.col_start[qx];
-    const int sy = p.row_start[qy];
-    const int rc = p.row_class[qy];
-    const int cc = p.col_class[qx];
-    int set;
-    if (rc < 0)
-        set = p.brow_set[static_cast<size_t>(~rc) * p.dst_w + qx];
-    else if (cc < 0)
-        set = p.bcol_set[static_cast<size_t>(~cc) * p.dst_h + qy];
-    else
-        set = p.interior_set[rc * p.n_col_classes + cc];
+    const int nitems = kGatherLines * P;
+    for (int item = wave; item < nitems; item += 4) {
+        const int line = item / P;
+        const int res = item - line * P;
+        const int x = axis == 0 ? bx0 + P * lane + res : bx0 + line;
+        const int y = axis == 0 ? by0 + line : by0 + P * lane + res;
+        const bool active = x <= bx1 && y <= by1;
+        if (!__builtin_amdgcn_readfirstlane(__ballot(active) != 0)) continue;
 
-    float acc = 0.f;
-    if constexpr (FS != 0) {
-        if (staged) {
-            // Waterfall over the distinct coefficient sets of the wave (2 for integer ratios, a handful for
-            // drifting ratios): the set of the first pending lane becomes wave-uniform, its coefficients go
-            // to SGPRs (scalar loads), and the lanes that use it run their chain; no per-lane coefficient
-            // traffic at all.  Small windows are read from LDS once and kept in registers across passes.
-            const float* s = tile + (sy - ty0) * pitch + (sx - tx0);
-            constexpr bool kWindowInRegs = FS <= 9;
-            float w[kWindowInRegs ? FS * FS : 1];
-            if constexpr (kWindowInRegs) {
+        // Inactive lanes (block overhang) look up the block's first pixel so every address stays in range.
+        const int qx = active ? x : bx0, qy = active ? y : by0;
+        const int sx = p.col_start[qx];
+        const int sy = p.row_start[qy];
+        const int rc = p.row_class[qy];
+        const int cc = p.col_class[qx];
+        int set;
+        if (rc < 0)
+            set = p.brow_set[static_cast<size_t>(~rc) * p.dst_w + qx];
+        else if (cc < 0)
+            set = p.bcol_set[static_cast<size_t>(~cc) * p.dst_h + qy];
+        else
+            set = p.interior_set[rc * p.n_col_classes + cc];
+
+        float acc = 0.f;
+        if constexpr (FS != 0) {
+            if (staged) {
+                const float* s = tile + (sy - ty0) * pitch + (sx - tx0);
+                constexpr bool kWindowInRegs = FS <= 9;  // small windows: read LDS once, reuse across passes
+                float w[kWindowInRegs ? FS * FS : 1];
+                if constexpr (kWindowInRegs) {
 #pragma unroll
-                for (int ly = 0; ly < FS; ++ly)
+                    for (int ly = 0; ly < FS; ++ly)
 #pragma unroll
-                    for (int lx = 0; lx < FS; ++lx) w[ly * FS + lx] = s[ly * pitch + lx];
-            }
-            unsigned long long todo = __ballot(active);
-            while (todo) {
-                const int leader = __ffsll(static_cast<long long>(todo)) - 1;
-                const int u = __builtin_amdgcn_readlane(set, leader);
-                const bool mine = active && set == u;
-                const JINC_CONSTANT float* cs =
-                    (const JINC_CONSTANT float*)(p.coeffs + static_cast<size_t>(u) * (FS * padded_row(FS)));
-                if (mine) {
-                    if constexpr (kWindowInRegs) {
+                        for (int lx = 0; lx < FS; ++lx) w[ly * FS + lx] = s[ly * pitch + lx];
+                }
+                unsigned long long todo = __ballot(active);
+                while (todo) {
+                    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+                    const int u = __builtin_amdgcn_readlane(set, leader);
+                    const bool mine = active && set == u;
+                    const JINC_CONSTANT float* cs =
+                        (const JINC_CONSTANT float*)(p.coeffs + static_cast<size_t>(u) * (FS * padded_row(FS)));
+                    if (mine) {
+                        if constexpr (kWindowInRegs) {
 #pragma unroll
-                        for (int ly = 0; ly < FS; ++ly)
+                            for (int ly = 0; ly < FS; ++ly)
 #pragma unroll
-                            for (int lx = 0; lx < FS; ++lx) acc = acc + w[ly * FS + lx] * cs[ly * padded_row(FS) + lx];
-                    } else {
-                        const float* sr = s;
-                        for (int ly = 0; ly < FS; ++ly) {
-                            float c[FS];
+                                for (int lx = 0; lx < FS; ++lx)
+                                    acc = acc + w[ly * FS + lx] * cs[ly * padded_row(FS) + lx];
+                        } else {
+                            const float* sr = s;
+                            for (int ly = 0; ly < FS; ++ly) {
+                                float c[FS];
 #pragma unroll
-                            for (int lx = 0; lx < FS; ++lx) c[lx] = cs[ly * padded_row(FS) + lx];
+                                for (int lx = 0; lx < FS; ++lx) c[lx] = cs[ly * padded_row(FS) + lx];
 #pragma unroll
-                            for (int lx = 0; lx < FS; ++lx) acc = acc + sr[lx] * c[lx];
-                            sr += pitch;
+                                for (int lx = 0; lx < FS; ++lx) acc = acc + sr[lx] * c[lx];
+                                sr += pitch;
+                            }
                         }
                     }
+                    todo &= ~__ballot(mine);
                 }
-                todo &= ~__ballot(mine);
             }
         }
-    }
-    if (FS == 0 || !staged) {
-        // Generic fallback: run-time filter size (even sizes of down-scales, fs > 17) or a source footprint
-        // larger than the LDS tile: per-lane loads through L1/L2.
-        const float* c = p.coeffs + static_cast<size_t>(set) * fs * fsp;
-        if (staged) {
-            const float* s = tile + (sy - ty0) * pitch + (sx - tx0);
-            for (int ly = 0; ly < fs; ++ly) {
-                for (int lx = 0; lx < fs; ++lx) acc = acc + s[lx] * c[lx];
-                s += pitch;
-                c += fsp;
-            }
-        } else {
-            const char* srow = sframe + static_cast<size_t>(sy) * a.io.src_pitch + static_cast<size_t>(sx) * sizeof(T);
-            for (int ly = 0; ly < fs; ++ly) {
-                const T* s = reinterpret_cast<const T*>(srow);
-                for (int lx = 0; lx < fs; ++lx) acc = acc + to_float(s[lx]) * c[lx];
-                srow += a.io.src_pitch;
-                c += fsp;
+        if (FS == 0 || !staged) {
+            // Fallback: run-time filter size (even sizes of down-scales, fs > 17) or a source footprint
+            // larger than the LDS tile: per-lane loads through L1/L2.
+            const float* c = p.coeffs + static_cast<size_t>(set) * fs * fsp;
+            if (staged) {
+                const float* s = tile + (sy - ty0) * pitch + (sx - tx0);
+                for (int ly = 0; ly < fs; ++ly) {
+                    for (int lx = 0; lx < fs; ++lx) acc = acc + s[lx] * c[lx];
+                    s += pitch;
+                    c += fsp;
+                }
+            } else {
+                const char* srow = sframe + static_cast<size_t>(sy) * a.io.src_pitch + static_cast<size_t>(sx) * sizeof(T);
+                for (int ly = 0; ly < fs; ++ly) {
+                    const T* s = reinterpret_cast<const T*>(srow);
+                    for (int lx = 0; lx < fs; ++lx) acc = acc + to_float(s[lx]) * c[lx];
+                    srow += a.io.src_pitch;
+                    c += fsp;
+                }
             }
         }
-    }
-    if (active) {
-        T* d = reinterpret_cast<T*>(static_cast<char*>(a.io.dst) + frame * a.io.dst_frame_stride +
-                                    static_cast<size_t>(y) * a.io.dst_pitch) + x;
-        store_sample<T>(d, acc, a.io.peak);
+        if (active) {
+            T* d = reinterpret_cast<T*>(dframe + static_cast<size_t>(y) * a.io.dst_pitch) + x;
+            store_sample<T>(d, acc, a.io.peak);
+        }
     }
 }
 
@@ -498,16 +516,19 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
     int total = 0;
     for (int r = 0; r < 4; ++r) {
         ga.block_begin[r] = total;
-        ga.blocks_x[r] = 1;
-        ga.lanes_x_log2[r] = 6;
+        ga.blocks_a[r] = 1;
+        ga.lane_axis[r] = 0;
+        ga.stride[r] = 1;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
-            // Narrow rectangles (border columns): one column x 256 rows per block, so a wave walks down one
-            // column and meets only as many coefficient sets as there are row phases.
-            const int lxl = rects.w[r] < 32 ? 0 : 6;
-            ga.lanes_x_log2[r] = lxl;
-            const int bw = 1 << lxl, bh = 256 >> lxl;
-            ga.blocks_x[r] = (rects.w[r] + bw - 1) / bw;
-            total += ga.blocks_x[r] * ((rects.h[r] + bh - 1) / bh);
+            // Narrow rectangles (border columns) put the lanes along y so that a wave is not mostly idle.
+            const int axis = rects.w[r] < 32 && rects.h[r] > rects.w[r] ? 1 : 0;
+            const int P = axis == 0 ? plan.gather_period_x : plan.gather_period_y;
+            const int along = axis == 0 ? rects.w[r] : rects.h[r];
+            const int across = axis == 0 ? rects.h[r] : rects.w[r];
+            ga.lane_axis[r] = axis;
+            ga.stride[r] = P;
+            ga.blocks_a[r] = (along + 64 * P - 1) / (64 * P);
+            total += ga.blocks_a[r] * ((across + kGatherLines - 1) / kGatherLines);
         }
     }
     ga.block_begin[4] = total;

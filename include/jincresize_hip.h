@@ -195,8 +195,9 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * kernel for every pixel, 2 = periodic fast kernel where the plan allows (same as automatic),
  * 3 = like 2 but always the row-streamed variant of the periodic kernel (A/B measurements). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
-/* 1 (default): the border gather kernel runs on a side stream concurrently with the periodic interior
- * kernel (fork/join by events around every call); 0: both on the caller's stream, back to back. */
+/* 1: the border gather kernel runs on a side stream concurrently with the periodic interior kernel
+ * (fork/join by events around every call); 0: both on the caller's stream, back to back;
+ * -1 (default): automatic -- side stream when the filter footprint is 9 or larger. */
 JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
 
 /* ---- Kernel timing (benchmarks) ---------------------------------------------------------------

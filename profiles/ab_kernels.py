@@ -6,7 +6,7 @@ and of the periodic-kernel time reported by the library's own events.
 
 usage: python profiles/ab_kernels.py [--config C2] [--frames 64] [--rounds 7] [--steps 5] variant [variant ...]
 variant = <kernel_mode>[o|s]   kernel_mode 0 auto, 1 gather only, 3 row-streamed periodic;
-                               o = border kernel overlapped on a side stream (default), s = serial
+                               o = border kernel overlapped on a side stream, s = serial, neither = automatic
 """
 import argparse
 import json
@@ -41,7 +41,7 @@ def main():
         for v in a.variants:
             mode = int(v.rstrip("os"))
             flt.set_kernel_mode(mode)
-            flt.set_border_overlap(not v.endswith("s"))
+            flt.set_border_overlap(False if v.endswith("s") else (True if v.endswith("o") else None))
             flt.set_profiling(True)
             flt.kernel_times()
             torch.cuda.synchronize()
