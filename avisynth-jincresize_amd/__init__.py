@@ -76,7 +76,7 @@ EXPORTS = ["jinc_device_count", "jinc_last_error", "jinc_filter_create", "jinc_f
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap"]
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -113,6 +113,7 @@ def lib():
         L.jinc_filter_lut.argtypes = [C.c_void_p, C.c_void_p]
         L.jinc_filter_set_kernel_mode.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_set_border_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_debug_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
         L.jinc_filter_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                                C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -122,6 +123,16 @@ def lib():
 
 def device_count() -> int:
     return int(lib().jinc_device_count())
+
+
+def debug_convert(sums: np.ndarray, dtype, peak: float, device: int = 0) -> np.ndarray:
+    """The kernels' sum -> sample conversion applied to `sums` on the device (test hook)."""
+    sums = np.ascontiguousarray(sums, dtype=np.float32)
+    out = np.zeros(sums.shape, dtype=dtype)
+    rc = lib().jinc_debug_convert(sums.ctypes.data, out.ctypes.data, sums.size, out.dtype.itemsize, float(peak), device)
+    if rc != 0:
+        raise JincError(rc, lib().jinc_last_error().decode())
+    return out
 
 
 # ---- clip / format model (what an AviSynth+ host would provide) -----------------------------------

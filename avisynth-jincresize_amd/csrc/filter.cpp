@@ -373,6 +373,7 @@ void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
                                                   p.col_class[p.ix0 + r]];
     pa.src_w = p.g.src_w;
     pa.src_h = p.g.src_h;
+    pa.dst_h = p.g.dst_h;
     t.periodic = pa;
     t.use_periodic = true;
 
@@ -726,6 +727,23 @@ int jinc_filter_kernel_times(jinc_filter* f, double* periodic_ms, int* periodic_
         };
         collect(f->ev_periodic, periodic_ms, periodic_launches);
         collect(f->ev_gather, gather_ms, gather_launches);
+    });
+}
+
+int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, float peak, int device) {
+    if (!sums || !out || n < 0 || (sample_bytes != 1 && sample_bytes != 2 && sample_bytes != 4))
+        return fail(JINC_ERR_INVALID_ARG, "JincResize: bad argument.");
+    return guarded([&] {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        float* d_in = nullptr;
+        void* d_out = nullptr;
+        hip_check(hipMalloc(&d_in, sizeof(float) * (n + 1)), "hipMalloc");
+        hip_check(hipMalloc(&d_out, static_cast<size_t>(sample_bytes) * (n + 1)), "hipMalloc");
+        hip_check(hipMemcpy(d_in, sums, sizeof(float) * n, hipMemcpyHostToDevice), "hipMemcpy");
+        hip_check(static_cast<hipError_t>(jinc::launch_debug_convert(d_in, d_out, n, sample_bytes, peak, nullptr)), "convert launch");
+        hip_check(hipMemcpy(out, d_out, static_cast<size_t>(sample_bytes) * n, hipMemcpyDeviceToHost), "hipMemcpy");
+        (void)hipFree(d_in);
+        (void)hipFree(d_out);
     });
 }
 

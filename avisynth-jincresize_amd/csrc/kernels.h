@@ -52,6 +52,7 @@ struct PeriodicArgs {
     int min_sx = 0, min_sy = 0;  // min over phases of start_x / start_y
     int set[64] = {0};
     int src_w = 0, src_h = 0;
+    int dst_h = 0;  // rows of the destination plane (bounds of the store descriptor)
 };
 
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
@@ -61,5 +62,8 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 bool periodic_supported(int fs, int px, int py, int sx, int sy);
 // variant: 0 = default choice per filter size, 1 = always the row-streamed kernel (A/B measurements)
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
+
+// Test hook: applies the kernels' float -> sample conversion (clamp, round-half-even, store) to n sums.
+int launch_debug_convert(const float* in, void* out, int n, int sample_bytes, float peak, void* stream);
 
 }  // namespace jinc

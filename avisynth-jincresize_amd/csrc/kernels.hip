@@ -46,13 +46,40 @@ __device__ __forceinline__ uint32_t round_sample(float r, float peak) {
     return static_cast<uint32_t>(__builtin_rintf(__builtin_amdgcn_fmed3f(r, 0.f, peak)));
 }
 
+// 8-bit planes (peak is always 255): v_cvt_pk_u8_f32 rounds to nearest even (MODE.fp_round default) and
+// saturates to [0, 255] in one instruction -- the same value as clamp + lrintf for every input, NaN -> 0.
+// tests/test_gpu_parity.py::test_integer_conversion_ties checks ties, bounds and specials on the device.
+__device__ __forceinline__ uint32_t round_sample_u8(float r) { return __builtin_amdgcn_cvt_pk_u8_f32(r, 0u, 0u); }
+
+template <typename T>
+__device__ __forceinline__ T convert_sample(float r, float peak) {
+    if constexpr (std::is_same_v<T, float>)
+        return r;
+    else if constexpr (std::is_same_v<T, uint8_t>)
+        return static_cast<uint8_t>(round_sample_u8(r));
+    else
+        return static_cast<T>(round_sample(r, peak));
+}
+
 template <typename T>
 __device__ __forceinline__ void store_sample(T* p, float r, float peak) {
-    if constexpr (std::is_same_v<T, float>) {
-        *p = r;
-    } else {
-        *p = static_cast<T>(round_sample(r, peak));
-    }
+    *p = convert_sample<T>(r, peak);
+}
+
+// Store through a buffer resource: per-lane byte offset in a VGPR that never changes, the row offset in
+// an SGPR -- no address arithmetic on the VALU (the binding unit of these kernels) per stored sample.
+using BufferRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufferRsrc make_rsrc(void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+}
+template <typename T>
+__device__ __forceinline__ void store_sample_buf(BufferRsrc rsrc, uint32_t voffset, uint32_t soffset, float r, float peak) {
+    if constexpr (std::is_same_v<T, float>)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, r), rsrc, voffset, soffset, 0);
+    else if constexpr (std::is_same_v<T, uint8_t>)
+        __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(round_sample_u8(r)), rsrc, voffset, soffset, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b16(static_cast<uint16_t>(round_sample(r, peak)), rsrc, voffset, soffset, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,7 +305,9 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 
         const unsigned x = a.ix0 + a.px * (i0 + lane) + p;  // per-lane output column
         if ((i0 + lane) >= a.ni) continue;                   // whole phase loop under one exec mask
-        char* dframe = static_cast<char*>(io.dst) + frame * io.dst_frame_stride;  // wave-uniform
+        const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                           static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+        const uint32_t xoff = x * static_cast<uint32_t>(sizeof(T));
 
         float win[FS][FS];
 #pragma unroll
@@ -304,8 +333,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
                 const int j = j0 + g * FS + u;  // wave-uniform
                 if (j < a.nj) {
                     const int y = a.iy0 + a.py * j + q;
-                    T* drow = reinterpret_cast<T*>(dframe + static_cast<size_t>(y) * io.dst_pitch);  // SGPR base
-                    store_sample<T>(drow + x, acc, io.peak);
+                    store_sample_buf<T>(drsrc, xoff, static_cast<uint32_t>(y) * io.dst_pitch, acc, io.peak);
                 }
             }
         }
@@ -343,7 +371,7 @@ struct RowsCfg {
 };
 
 template <typename T, int FS, int OFF>
-__device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs, char* dframe,
+__device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs, BufferRsrc drsrc,
                                           int dst_pitch, float peak, int y0, int ystep, int rows_valid, unsigned x0,
                                           unsigned xstep, int cols_valid) {
     using Cfg = RowsCfg<FS>;
@@ -384,10 +412,11 @@ __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsign
 #pragma unroll
     for (int jj = 0; jj < R; ++jj) {
         if (jj < rows_valid) {  // wave-uniform
-            T* drow = reinterpret_cast<T*>(dframe + static_cast<size_t>(y0 + jj * ystep) * dst_pitch);
+            const uint32_t soff = static_cast<uint32_t>(y0 + jj * ystep) * dst_pitch;
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                if (k < cols_valid) store_sample<T>(drow + (x0 + k * xstep), acc[jj][k], peak);
+                if (k < cols_valid)
+                    store_sample_buf<T>(drsrc, (x0 + k * xstep) * static_cast<uint32_t>(sizeof(T)), soff, acc[jj][k], peak);
         }
     }
 }
@@ -422,7 +451,8 @@ __global__ __launch_bounds__(RowsCfg<FS>::kThreads) void ewa_periodic_rows_kerne
     }
     __syncthreads();
 
-    char* dframe = static_cast<char*>(io.dst) + frame * io.dst_frame_stride;
+    const BufferRsrc dframe = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                        static_cast<uint32_t>(io.dst_pitch) * a.dst_h);
     const int nphase = a.px * a.py;
     const int nitems = nphase * Cfg::kChunks;
     const int cols_valid = a.ni - (i0 + K * lane);  // per lane: how many of its K columns exist
@@ -507,6 +537,32 @@ int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStr
 }
 
 }  // namespace
+
+namespace {
+// Runs exactly the conversion + store code of the resampling kernels on caller-supplied sums.
+template <typename T>
+__global__ void convert_kernel(const float* in, T* out, int n, float peak) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const BufferRsrc rsrc = make_rsrc(out, static_cast<uint32_t>(n) * sizeof(T));
+    if (i & 1)
+        store_sample_buf<T>(rsrc, static_cast<uint32_t>(i) * sizeof(T), 0u, in[i], peak);  // periodic kernels' path
+    else
+        store_sample<T>(out + i, in[i], peak);                                             // gather kernel's path
+}
+}  // namespace
+
+int launch_debug_convert(const float* in, void* out, int n, int sample_bytes, float peak, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((n + 255) / 256), block(256);
+    switch (sample_bytes) {
+        case 1: hipLaunchKernelGGL(convert_kernel<uint8_t>, grid, block, 0, s, in, static_cast<uint8_t*>(out), n, peak); break;
+        case 2: hipLaunchKernelGGL(convert_kernel<uint16_t>, grid, block, 0, s, in, static_cast<uint16_t*>(out), n, peak); break;
+        default: hipLaunchKernelGGL(convert_kernel<float>, grid, block, 0, s, in, static_cast<float*>(out), n, peak); break;
+    }
+    return static_cast<int>(hipGetLastError());
+}
 
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream) {
     GatherArgs ga;

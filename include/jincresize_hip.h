@@ -200,6 +200,11 @@ JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
  * -1 (default): automatic -- side stream when the filter footprint is 9 or larger. */
 JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
 
+/* Test hook: runs the kernels' own sum -> sample conversion (clamp to [0, peak], round-half-even, store;
+ * ref :581-584) on `n` caller-supplied fp32 sums on device `device` and returns the samples
+ * (sample_bytes 1, 2 or 4).  Lets tests probe ties, bounds, NaN and infinities directly. */
+JINC_API int jinc_debug_convert(const float *sums, void *out, int n, int sample_bytes, float peak, int device);
+
 /* ---- Kernel timing (benchmarks) ---------------------------------------------------------------
  * When enabled, every kernel launch made by jinc_filter_get_frame / jinc_filter_process_device is
  * bracketed by a pair of hipEvents recorded on the launch stream.  jinc_filter_kernel_times waits

@@ -240,3 +240,26 @@ def test_many_instances_share_a_device(gpu_pkg, O):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_integer_conversion_ties(gpu_pkg):
+    """The device conversion (v_cvt_pk_u8_f32 for 8-bit, med3 + rndne + cvt for 9..16-bit) against
+    clamp(r, 0, peak) + lrintf (ref :581-582): every tie k + 0.5, both clamp bounds, values just around
+    ties, huge values, infinities, NaN (-> 0 on both sides) and negative zero."""
+    for dtype, peak in ((np.uint8, 255.0), (np.uint16, 1023.0), (np.uint16, 4095.0), (np.uint16, 65535.0)):
+        ties = np.arange(-3, int(peak) + 3, dtype=np.float64) + 0.5
+        if len(ties) > 6000:
+            ties = np.concatenate([ties[:3000], ties[-3000:]])
+        vals = np.concatenate([
+            ties, np.nextafter(ties.astype(np.float32), np.float32(np.inf)),
+            np.nextafter(ties.astype(np.float32), np.float32(-np.inf)),
+            np.array([0.0, -0.0, 0.49999997, 0.50000006, peak, peak - 0.5, peak + 0.4999, peak + 0.5, peak + 1e6, 3e9, 1e30,
+                      -1e-30, -0.4, -0.5, -0.51, -1e9, np.inf, -np.inf, 1e-45, -1e-45]),
+            np.random.default_rng(0).uniform(-5, peak + 5, 5000),
+        ]).astype(np.float32)
+        want = np.rint(np.clip(vals, np.float32(0), np.float32(peak))).astype(dtype)
+        got = gpu_pkg.debug_convert(vals, dtype, peak)
+        assert np.array_equal(got, want), (dtype, peak, vals[got != want][:8], got[got != want][:8], want[got != want][:8])
+        assert gpu_pkg.debug_convert(np.array([np.nan, np.nan], np.float32), dtype, peak).tolist() == [0, 0]
+    f = np.array([1.5, -2.25, np.inf, 1e-41, -0.0], np.float32)
+    assert np.array_equal(gpu_pkg.debug_convert(f, np.float32, 0.0).view(np.uint32), f.view(np.uint32))
