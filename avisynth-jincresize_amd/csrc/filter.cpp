@@ -449,6 +449,8 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(t.plan.src_w) * sb ||
             static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(t.plan.dst_w) * sb)
             throw ArgError("JincResize: plane pitch is smaller than the row size.");
+        if (static_cast<uint64_t>(dst_pitch[i]) * t.plan.dst_h >= (1ull << 32))
+            throw ArgError("JincResize: destination plane larger than 4 GiB is not supported (32-bit store offsets).");
         jinc::PlaneIO io;
         io.src = src[i];
         io.dst = dst[i];
