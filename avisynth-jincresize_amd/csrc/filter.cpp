@@ -598,7 +598,7 @@ int jinc_filter_process_device(jinc_filter* f, const void* const src[4], const i
         return fail(JINC_ERR_INVALID_ARG, "JincResize: frame strides are required for nframes > 1.");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : f->stream;
+        hipStream_t s = static_cast<hipStream_t>(hip_stream);  // NULL = the HIP null stream, ordered with the caller's default-stream work
         enqueue(*f, src, src_pitch, src_frame_stride, dst, dst_pitch, dst_frame_stride, nframes, s);
     });
 }
@@ -750,7 +750,7 @@ int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, fl
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 5) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 6) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

@@ -341,6 +341,138 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, packed-math form (experimental A/B variant)
+// ------------------------------------------------------------------------------------------------
+// Same algorithm as ewa_periodic_kernel, but a lane owns TWO source-aligned columns 64 apart and keeps
+// both register windows as 2-vectors, so every tap is one v_pk_mul_f32 + one v_pk_add_f32 (two
+// independent IEEE products / sums per instruction; nothing is fused or reassociated: each half is
+// exactly the scalar chain).  The coefficient stays in an SGPR and is broadcast to both halves by op_sel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc-independent product of a 2-vector with ONE coefficient taken from the low (HI = false) or high half of
+// an aligned SGPR pair, broadcast to both halves by op_sel -- written as asm because the compiler otherwise
+// materialises every (c, c) splat as its own SGPR pair (98 SGPRs for fs = 7 -> spills).  Register-only VALU.
+// One kernel row (7 taps) of the packed chain as a single asm statement: acc += w[lx] * c[lx], lx = 0..6, each tap
+// v_pk_mul_f32 (coefficient = low or high half of an aligned SGPR pair, broadcast to both halves by op_sel)
+// followed by v_pk_add_f32 -- un-fused, in order.  One statement per row keeps the compiler's per-statement
+// boundary pad (one s_nop) at 1 per 14 instructions; register-only VALU, interlocked by hardware.
+__device__ __forceinline__ void pk_row7(f32x2& acc, const f32x2 (&w)[7], f32x2 p01, f32x2 p23, f32x2 p45, f32x2 p6x) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %9 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %10 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %6, %11 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %7, %11 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %8, %12 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "s"(p01), "s"(p23), "s"(p45), "s"(p6x));
+}
+
+template <int FS, int RG>
+struct PeriodicPkCfg {
+    static constexpr int kRowGroups = RG;
+    static constexpr int kTileRows = FS * RG;
+    static constexpr int kTileCols = 128;
+    static constexpr int kSrcCols = kTileCols + FS;  // source columns staged per tile row
+    // LDS row = pairs: pair k = (source column k, source column 64 + k), k = 0 .. 64+FS-1, so that a lane's two
+    // windows (columns lane+lx and 64+lane+lx) arrive as one aligned ds_read_b64 -> one VGPR pair.
+    static constexpr int kPairsPerRow = 64 + FS;
+    static constexpr int kLdsPitch = 2 * kPairsPerRow + 2;  // floats; even (8-byte aligned rows)
+    static constexpr int kLdsRows = kTileRows + FS;
+};
+
+template <typename T, int FS, int RG>
+__global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = PeriodicPkCfg<FS, RG>;
+    __shared__ __attribute__((aligned(16))) float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i0 = blockIdx.x * Cfg::kTileCols;
+    const int j0 = blockIdx.y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    {
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        for (int r = wave; r < Cfg::kLdsRows; r += 4) {
+            int gy = gy0 + r;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+            float* trow = tile + r * Cfg::kLdsPitch;
+#pragma unroll
+            for (int c = lane; c < Cfg::kSrcCols; c += 64) {
+                int gx = gx0 + c;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                const float v = to_float(srow[gx]);
+                if (c < Cfg::kPairsPerRow) trow[2 * c] = v;        // first element of pair c
+                if (c >= 64) trow[2 * (c - 64) + 1] = v;           // second element of pair c - 64
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nphase = a.px * a.py;
+    for (int ph = wave; ph < nphase; ph += 4) {
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+        const JINC_CONSTANT float* cs =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
+        // coefficient rows as aligned 64-bit SGPR pairs (rows are padded to a multiple of 4 floats)
+        constexpr int kPairs = padded_row(FS) / 2;
+        const JINC_CONSTANT f32x2* cs2 = (const JINC_CONSTANT f32x2*)cs;
+        f32x2 cp[FS * kPairs];
+#pragma unroll
+        for (int k = 0; k < FS * kPairs; ++k) cp[k] = cs2[k];
+
+        const f32x2* base = reinterpret_cast<const f32x2*>(tile + (a.start_y[q] - a.min_sy) * Cfg::kLdsPitch) +
+                            (a.start_x[p] - a.min_sx) + lane;
+        constexpr int kPitch2 = Cfg::kLdsPitch / 2;  // row pitch in pairs
+        const int ia = i0 + lane;
+        if (ia >= a.ni) continue;
+        const bool b_ok = ia + 64 < a.ni;
+        const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                           static_cast<uint32_t>(io.dst_pitch) * a.dst_h);
+        const uint32_t xoff_a = (a.ix0 + a.px * ia + p) * static_cast<uint32_t>(sizeof(T));
+        const uint32_t xoff_b = xoff_a + 64u * a.px * static_cast<uint32_t>(sizeof(T));
+
+        f32x2 win[FS][FS];
+#pragma unroll
+        for (int r = 0; r < FS - 1; ++r)
+#pragma unroll
+            for (int lx = 0; lx < FS; ++lx) win[r][lx] = base[r * kPitch2 + lx];
+
+        for (int g = 0; g < Cfg::kRowGroups; ++g) {
+            const f32x2* gbase = base + (g * FS) * kPitch2;
+#pragma unroll
+            for (int u = 0; u < FS; ++u) {
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx) win[(u + FS - 1) % FS][lx] = gbase[(u + FS - 1) * kPitch2 + lx];
+                f32x2 acc = {0.f, 0.f};
+                static_assert(FS == 7, "packed variant is written for fs = 7");
+#pragma unroll
+                for (int ly = 0; ly < FS; ++ly)
+                    pk_row7(acc, win[(u + ly) % FS], cp[ly * kPairs], cp[ly * kPairs + 1], cp[ly * kPairs + 2], cp[ly * kPairs + 3]);
+                const int j = j0 + g * FS + u;
+                if (j < a.nj) {
+                    const uint32_t soff = static_cast<uint32_t>(a.iy0 + a.py * j + q) * io.dst_pitch;
+                    store_sample_buf<T>(drsrc, xoff_a, soff, acc.x, io.peak);
+                    if (b_ok) store_sample_buf<T>(drsrc, xoff_b, soff, acc.y, io.peak);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Periodic interior kernel, row-streamed form (any filter size, used for fs > 9)
 // ------------------------------------------------------------------------------------------------
 // Same phase-uniform idea as ewa_periodic_kernel (one phase per wave => coefficients in SGPRs), but
@@ -507,6 +639,14 @@ int launch_periodic_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t str
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int FS, int RG>
+int launch_periodic_pk_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicPkCfg<FS, RG>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_pk_kernel<T, FS, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T, int FS>
 int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = RowsCfg<FS>;
@@ -517,6 +657,8 @@ int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream)
 
 template <typename T>
 int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
+    if (variant == 3 && fs == 7) return launch_periodic_pk_t<T, 7, 4>(pa, io, stream);
+    if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
     if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);
     if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 3>(pa, io, stream);
     if (variant == 1) {

@@ -145,8 +145,8 @@ JINC_API int jinc_filter_chroma_location(const jinc_filter *f);
 JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], const int src_pitch[4],
                                    void *const dst[4], const int dst_pitch[4]);
 
-/* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t, or
- * NULL for the filter's own stream), for a batch of `nframes` independent frames (frames are the
+/* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t; NULL is
+ * the HIP null stream, i.e. ordered with the caller's default-stream work), for a batch of `nframes` independent frames (frames are the
  * sharding unit; no frame reads another).  Plane i of frame n starts at
  * src[i] + n*src_frame_stride[i] bytes (likewise dst).  Pitches/strides in bytes; sample alignment
  * required.  src and dst must not overlap.  Returns after enqueueing. */
@@ -155,7 +155,8 @@ JINC_API int jinc_filter_process_device(jinc_filter *f, const void *const src[4]
                                         const int dst_pitch[4], const size_t dst_frame_stride[4],
                                         int nframes, void *hip_stream);
 
-/* Block until everything enqueued on the filter's own stream has finished. */
+/* Block until everything enqueued on the filter's own stream (jinc_filter_get_frame) has finished.
+ * Work given to jinc_filter_process_device is synchronised by the caller through its stream. */
 JINC_API int jinc_filter_sync(jinc_filter *f);
 
 /* ---- Jinc36Resize / Jinc64Resize / Jinc144Resize / Jinc256Resize (ref :986-1040, :1061-1108) ----

@@ -263,3 +263,20 @@ def test_integer_conversion_ties(gpu_pkg):
         assert gpu_pkg.debug_convert(np.array([np.nan, np.nan], np.float32), dtype, peak).tolist() == [0, 0]
     f = np.array([1.5, -2.25, np.inf, 1e-41, -0.0], np.float32)
     assert np.array_equal(gpu_pkg.debug_convert(f, np.float32, 0.0).view(np.uint32), f.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", [3, 4, 5, 6], ids=["rows", "window_rg4", "packed_rg4", "packed_rg8"])
+@pytest.mark.parametrize("fmt,sw,sh,tw,th", [("Y8", 640, 360, 1280, 720), ("Y16", 333, 211, 666, 422),
+                                             ("Y32", 200, 150, 400, 300), ("YUV420P8", 258, 130, 516, 260),
+                                             ("Y8", 100, 80, 400, 320)])
+def test_kernel_variants_match_oracle(gpu_pkg, O, fmt, sw, sh, tw, th, mode):
+    """The A/B kernel variants (row-streamed, other tile heights, packed v_pk_mul/v_pk_add) are bit-exact too."""
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=31337)
+    want = of.get_frame(src, threads=4)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    assert f.plan_info().periodic == 1 and f.plan_info().filter_size == 7
+    f.set_kernel_mode(mode)
+    got = f.get_frame(src)
+    assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} mode {mode}")
+    f.close()
