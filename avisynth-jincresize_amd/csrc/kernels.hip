@@ -620,12 +620,19 @@ template <typename T>
 int launch_gather_fs(const GatherArgs& ga, int total_blocks, hipStream_t stream) {
     switch (ga.plan.fs) {
         case 3: return launch_gather_t<T, 3>(ga, total_blocks, stream);
+        case 4: return launch_gather_t<T, 4>(ga, total_blocks, stream);
         case 5: return launch_gather_t<T, 5>(ga, total_blocks, stream);
+        case 6: return launch_gather_t<T, 6>(ga, total_blocks, stream);
         case 7: return launch_gather_t<T, 7>(ga, total_blocks, stream);
+        case 8: return launch_gather_t<T, 8>(ga, total_blocks, stream);
         case 9: return launch_gather_t<T, 9>(ga, total_blocks, stream);
+        case 10: return launch_gather_t<T, 10>(ga, total_blocks, stream);
         case 11: return launch_gather_t<T, 11>(ga, total_blocks, stream);
+        case 12: return launch_gather_t<T, 12>(ga, total_blocks, stream);
         case 13: return launch_gather_t<T, 13>(ga, total_blocks, stream);
+        case 14: return launch_gather_t<T, 14>(ga, total_blocks, stream);
         case 15: return launch_gather_t<T, 15>(ga, total_blocks, stream);
+        case 16: return launch_gather_t<T, 16>(ga, total_blocks, stream);
         case 17: return launch_gather_t<T, 17>(ga, total_blocks, stream);
         default: return launch_gather_t<T, 0>(ga, total_blocks, stream);
     }
