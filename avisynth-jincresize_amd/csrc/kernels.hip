@@ -244,6 +244,22 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     }
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in
+// linear-id order, so neighbouring linear ids land on different XCDs and every XCD would fetch its own copy
+// of the halo rows/columns shared by adjacent tiles.  Re-map the linear id so that each XCD walks a
+// contiguous run of tiles of the frame (bijective for any tile count; placement affects speed only).
+__device__ __forceinline__ void swizzled_tile(int& tx, int& ty) {
+    const int n = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    constexpr int kXcds = 8;
+    const int q = n / kXcds, rem = n % kXcds;
+    const int xcd = lin % kXcds, idx = lin / kXcds;
+    // XCD k owns q (+1 if k < rem) consecutive tiles starting at k*q + min(k, rem)
+    const int tile_id = xcd * q + (xcd < rem ? xcd : rem) + idx;
+    ty = tile_id / gridDim.x;
+    tx = tile_id - ty * gridDim.x;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Periodic interior kernel
 // ------------------------------------------------------------------------------------------------
@@ -266,8 +282,10 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i0 = blockIdx.x * kTileCols;
-    const int j0 = blockIdx.y * Cfg::kTileRows;
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
 
     // ---- stage the source tile as fp32 (each source sample converted once) ----
@@ -396,8 +414,10 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i0 = blockIdx.x * Cfg::kTileCols;
-    const int j0 = blockIdx.y * Cfg::kTileRows;
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * Cfg::kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
     {
         const int gx0 = a.min_sx + i0;
@@ -561,8 +581,10 @@ __global__ __launch_bounds__(RowsCfg<FS>::kThreads) void ewa_periodic_rows_kerne
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i0 = blockIdx.x * Cfg::kTileCols;
-    const int j0 = blockIdx.y * Cfg::kTileRows;
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * Cfg::kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
 
     {
