@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
             for (int lx = 0; lx < FS; ++lx) win[r][lx] = base[r * Cfg::kLdsPitch + lx];
 
         for (int g = 0; g < Cfg::kRowGroups; ++g) {
+            if (j0 + g * FS >= a.nj) break;  // wave-uniform: the bottom tiles usually need fewer groups
             const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
 #pragma unroll
             for (int u = 0; u < FS; ++u) {
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
             for (int lx = 0; lx < FS; ++lx) win[r][lx] = base[r * kPitch2 + lx];
 
         for (int g = 0; g < Cfg::kRowGroups; ++g) {
+            if (j0 + g * FS >= a.nj) break;
             const f32x2* gbase = base + (g * FS) * kPitch2;
 #pragma unroll
             for (int u = 0; u < FS; ++u) {
@@ -504,9 +506,9 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
 //     reference's sequential chain;
 //   * the LDS tile is stored as K column-planes (column c -> plane c % K, index c / K) so that the
 //     64 lanes of a wave, which are K columns apart, read consecutive LDS words (no bank conflicts).
-template <int FS>
+template <int FS, int KC = 4>
 struct RowsCfg {
-    static constexpr int K = 4;        // columns per lane
+    static constexpr int K = KC;       // columns per lane (4, or 3 when that wastes fewer overhanging columns)
     static constexpr int R = 4;        // rows per chunk (accumulators per lane = R * K)
     static constexpr int kChunks = 4;  // chunks per tile
     static constexpr int kTileRows = R * kChunks;
@@ -522,11 +524,11 @@ struct RowsCfg {
     static constexpr int kThreads = 64 * kWaves;
 };
 
-template <typename T, int FS, int OFF>
+template <typename T, int FS, int KC, int OFF>
 __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs, BufferRsrc drsrc,
                                           int dst_pitch, float peak, int y0, int ystep, int rows_valid, unsigned x0,
                                           unsigned xstep, int cols_valid) {
-    using Cfg = RowsCfg<FS>;
+    using Cfg = RowsCfg<FS, KC>;
     constexpr int K = Cfg::K, R = Cfg::R;
     float acc[R][K];
 #pragma unroll
@@ -573,9 +575,9 @@ __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsign
     }
 }
 
-template <typename T, int FS>
-__global__ __launch_bounds__(RowsCfg<FS>::kThreads) void ewa_periodic_rows_kernel(const PeriodicArgs a, const PlaneIO io) {
-    using Cfg = RowsCfg<FS>;
+template <typename T, int FS, int KC>
+__global__ __launch_bounds__(512) void ewa_periodic_rows_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = RowsCfg<FS, KC>;
     constexpr int K = Cfg::K, R = Cfg::R;
     __shared__ float tile[K * Cfg::kPlaneStride];
 
@@ -625,9 +627,9 @@ __global__ __launch_bounds__(RowsCfg<FS>::kThreads) void ewa_periodic_rows_kerne
         const int y0 = a.iy0 + a.py * j + q;
         const unsigned x0 = a.ix0 + a.px * (i0 + K * lane) + p;
         if (a.start_x[p] - a.min_sx)
-            rows_item<T, FS, 1>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+            rows_item<T, FS, KC, 1>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
         else
-            rows_item<T, FS, 0>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+            rows_item<T, FS, KC, 0>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
     }
 }
 
@@ -676,12 +678,21 @@ int launch_periodic_pk_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t 
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int FS, int KC>
+int launch_rows_k(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = RowsCfg<FS, KC>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_rows_kernel<T, FS, KC>), grid, dim3(Cfg::kThreads, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+// Tile width 256 (K = 4) or 192 (K = 3) columns: whichever leaves fewer overhanging (idle) lanes in the last tile
+// column; ties go to K = 4 (fewer LDS reads per tap).
 template <typename T, int FS>
 int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
-    using Cfg = RowsCfg<FS>;
-    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    hipLaunchKernelGGL((ewa_periodic_rows_kernel<T, FS>), grid, dim3(Cfg::kThreads, 1, 1), 0, stream, pa, io);
-    return static_cast<int>(hipGetLastError());
+    const long long cover4 = (pa.ni + 255) / 256 * 256LL, cover3 = (pa.ni + 191) / 192 * 192LL;
+    if (cover3 * 100 < cover4 * 97) return launch_rows_k<T, FS, 3>(pa, io, stream);
+    return launch_rows_k<T, FS, 4>(pa, io, stream);
 }
 
 template <typename T>
