@@ -93,15 +93,15 @@ struct GatherArgs {
     int blocks_a[4];  // blocks along the lane axis of each rectangle
     int lane_axis[4]; // 0: lanes run along x (wide rectangles), 1: along y (border columns)
     int stride[4];    // lane stride P: lane l of an item handles coordinate origin + P*l + residue
+    int lines[4];     // lines (rows for lane_axis 0, columns for lane_axis 1) per block
 };
 
 constexpr int kGatherLdsFloats = 6144;  // 24 KB source tile per block
-constexpr int kGatherLines = 4;         // lines (rows for lane_axis 0, columns for lane_axis 1) per block
 
 // Coefficient rows are padded to a multiple of 4 floats on the device (16-byte aligned rows).
 __host__ __device__ constexpr int padded_row(int fs) { return (fs + 3) & ~3; }
 
-// Any plan.  A block covers 64*P coordinates along the lane axis x 4 lines; its source footprint is
+// Any plan.  A block covers 64*P coordinates along the lane axis x 4..32 lines; its source footprint is
 // staged once in LDS as fp32.  Work items = (line, residue): the 64 lanes of an item are P apart, P
 // being the plan's dominant phase period, so that (nearly) all lanes of an item share one coefficient
 // set.  The item then runs a waterfall over the distinct sets actually present: the set of the first
@@ -124,10 +124,11 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     const int rx0 = a.rects.x0[r], ry0 = a.rects.y0[r];
     const int rx1 = rx0 + a.rects.w[r], ry1 = ry0 + a.rects.h[r];
     // block extent in output pixels (inclusive last pixel), all wave-uniform
-    const int bx0 = axis == 0 ? rx0 + ba * 64 * P : rx0 + bl * kGatherLines;
-    const int by0 = axis == 0 ? ry0 + bl * kGatherLines : ry0 + ba * 64 * P;
-    const int bx1 = min(bx0 + (axis == 0 ? 64 * P : kGatherLines), rx1) - 1;
-    const int by1 = min(by0 + (axis == 0 ? kGatherLines : 64 * P), ry1) - 1;
+    const int nlines = a.lines[r];
+    const int bx0 = axis == 0 ? rx0 + ba * 64 * P : rx0 + bl * nlines;
+    const int by0 = axis == 0 ? ry0 + bl * nlines : ry0 + ba * 64 * P;
+    const int bx1 = min(bx0 + (axis == 0 ? 64 * P : nlines), rx1) - 1;
+    const int by1 = min(by0 + (axis == 0 ? nlines : 64 * P), ry1) - 1;
 
     const int fs = FS ? FS : p.fs;
     const int fsp = FS ? padded_row(FS) : padded_row(p.fs);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     }
     __syncthreads();
 
-    const int nitems = kGatherLines * P;
+    const int nitems = nlines * P;
     for (int item = wave; item < nitems; item += 4) {
         const int line = item / P;
         const int res = item - line * P;
@@ -757,16 +758,27 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
         ga.blocks_a[r] = 1;
         ga.lane_axis[r] = 0;
         ga.stride[r] = 1;
+        ga.lines[r] = 4;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
             // Narrow rectangles (border columns) put the lanes along y so that a wave is not mostly idle.
             const int axis = rects.w[r] < 32 && rects.h[r] > rects.w[r] ? 1 : 0;
             const int P = axis == 0 ? plan.gather_period_x : plan.gather_period_y;
             const int along = axis == 0 ? rects.w[r] : rects.h[r];
             const int across = axis == 0 ? rects.h[r] : rects.w[r];
+            // More lines per block amortise the block's fixed cost (bounds, staging, barrier) and its halo;
+            // thin rectangles (the border frame) keep 4.
+            int nl = across >= 128 ? 32 : (across >= 64 ? 16 : (across >= 16 ? 8 : 4));
+            {   // ... as long as the block's source footprint still fits the LDS tile (down-scales widen it)
+                const double rx = static_cast<double>(plan.src_w) / plan.dst_w, ry = static_cast<double>(plan.src_h) / plan.dst_h;
+                const double r_along = axis == 0 ? rx : ry, r_across = axis == 0 ? ry : rx;
+                const double w_along = 64.0 * P * r_along + plan.fs + 2;
+                while (nl > 1 && w_along * (nl * r_across + plan.fs + 2) > 0.9 * kGatherLdsFloats) nl /= 2;
+            }
             ga.lane_axis[r] = axis;
             ga.stride[r] = P;
+            ga.lines[r] = nl;
             ga.blocks_a[r] = (along + 64 * P - 1) / (64 * P);
-            total += ga.blocks_a[r] * ((across + kGatherLines - 1) / kGatherLines);
+            total += ga.blocks_a[r] * ((across + nl - 1) / nl);
         }
     }
     ga.block_begin[4] = total;

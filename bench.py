@@ -196,14 +196,14 @@ def main():
     flt.set_profiling(True)
     flt.kernel_times()  # reset
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
