@@ -766,8 +766,13 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
             const int along = axis == 0 ? rects.w[r] : rects.h[r];
             const int across = axis == 0 ? rects.h[r] : rects.w[r];
             // More lines per block amortise the block's fixed cost (bounds, staging, barrier) and its halo;
-            // thin rectangles (the border frame) keep 4.
-            int nl = across >= 128 ? 32 : (across >= 64 ? 16 : (across >= 16 ? 8 : 4));
+            // thin rectangles (the border frame) get as many lines as they have.
+            int nl = 4;
+            while (nl < 32 && nl < across) nl *= 2;
+            // ... but keep enough blocks in flight for the chip (256 CUs): thin border rectangles of a small
+            // batch would otherwise collapse into a few hundred long-running blocks
+            while (nl > 4 && static_cast<long long>((along + 64 * P - 1) / (64 * P)) * ((across + nl - 1) / nl) * io.nframes < 1024)
+                nl /= 2;
             {   // ... as long as the block's source footprint still fits the LDS tile (down-scales widen it)
                 const double rx = static_cast<double>(plan.src_w) / plan.dst_w, ry = static_cast<double>(plan.src_h) / plan.dst_h;
                 const double r_along = axis == 0 ? rx : ry, r_across = axis == 0 ? ry : rx;
