@@ -27,6 +27,9 @@ SMALL_CASES = [
     ("Y8", 320, 180, 480, 270, {}),                                 # 1.5x: gather kernel everywhere
     ("Y8", 1920 // 4, 1080 // 4, 1280 // 4, 720 // 4, {}),          # downscale, fs 10
     ("Y8", 64, 48, 40, 30, {}),                                     # downscale, fs 11
+    ("Y8", 640, 480, 64, 48, {}),                                   # 10x downscale: fs 65, footprint beyond the LDS tile
+    ("Y16", 300, 200, 100, 50, dict(tap=4)),                        # anisotropic downscale (3x / 4x), fs 34
+    ("Y32", 256, 256, 128, 128, {}),                                # 2:1 downscale, fs 13, period 1 / source step 2
     ("Y8", 37, 23, 91, 50, dict(tap=3, blur=0.9, src_left=1.3, src_top=0.7, src_width=33.1, src_height=20.2)),
     ("Y8", 50, 40, 120, 96, dict(tap=4, blur=0.98, src_left=-2.5, src_top=1.25, src_width=55, src_height=41.5,
                                  quant_x=7, quant_y=13)),
