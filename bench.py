@@ -54,7 +54,7 @@ def shard_frames(total_frames: int, rank: int, world: int):
 
 def aggregate(elapsed_s: float, units: float, dist=None):
     """MAX over ranks of the elapsed time, SUM over ranks of the processed units."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return elapsed_s, units
     import torch
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
@@ -178,8 +178,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists in the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is always created, also for one rank, so that
+    # the N = 1 launch exercises the same RCCL barrier / reductions as N = 8
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
 
     pkg = entry.load_package()
@@ -195,21 +199,21 @@ def main():
     torch.cuda.synchronize()
     flt.set_profiling(True)
     flt.kernel_times()  # reset
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
 
     frames_done = float(B * args.steps)
-    elapsed_max, frames_all = aggregate(elapsed, frames_done, dist if world > 1 else None)
+    elapsed_max, frames_all = aggregate(elapsed, frames_done, dist if use_dist else None)
     mpix = frames_all * dw * dh / elapsed_max / 1e6
 
     if rank == 0:
@@ -263,7 +267,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     flt.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
