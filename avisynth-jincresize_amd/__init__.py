@@ -65,7 +65,8 @@ class PlanInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("src_width", "src_height", "dst_width", "dst_height", "filter_size", "num_sets",
                                        "periodic", "period_x", "period_y", "step_x", "step_y",
                                        "interior_x0", "interior_x1", "interior_y0", "interior_y1")] + \
-               [("plan_bytes", C.c_int64)]
+               [("plan_bytes", C.c_int64)] + \
+               [(n, C.c_int) for n in ("quasi", "quasi_period_x", "quasi_period_y", "quasi_step_x", "quasi_step_y")]
 
 
 ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_height": 1 << 3, "quant_x": 1 << 4,

@@ -51,6 +51,8 @@ struct DeviceTable {
     jinc::DevicePlan plan;
     bool use_periodic = false;
     jinc::PeriodicArgs periodic;
+    bool use_quasi = false;  // quasi-periodic interior kernel (affine window origins, drifting classes)
+    jinc::QuasiArgs quasi;
     jinc::RectList border_rects;  // gather work when the periodic kernel covers the interior
     jinc::RectList whole;         // gather work when it does not
 };
@@ -333,6 +335,8 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
     t.plan.gather_period_y = dominant_period(p.row_class);
 }
 
+jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end);
+
 // Decides how the output plane is split between the periodic kernel and the gather kernel.
 void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
     const int W = p.g.dst_w, H = p.g.dst_h;
@@ -377,8 +381,12 @@ void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
     t.periodic = pa;
     t.use_periodic = true;
 
-    const int x_end = p.ix0 + p.px * pa.ni;
-    const int y_end = p.iy0 + p.py * pa.nj;
+    t.border_rects = border_frame(p, p.ix0 + p.px * pa.ni, p.iy0 + p.py * pa.nj);
+}
+
+// The up-to-four rectangles around the interior block [ix0, x_end) x [iy0, y_end) of the output plane.
+jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end) {
+    const int W = p.g.dst_w, H = p.g.dst_h;
     jinc::RectList r;
     auto add = [&](int x0, int y0, int w, int h) {
         if (w <= 0 || h <= 0) return;
@@ -392,7 +400,51 @@ void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
     add(0, y_end, W, H - y_end);             // bottom rows
     add(0, p.iy0, p.ix0, y_end - p.iy0);     // left columns
     add(x_end, p.iy0, W - x_end, y_end - p.iy0);  // right columns
-    t.border_rects = r;
+    return r;
+}
+
+// Quasi-periodic interior (see kernels.h): used when the plan is not exactly periodic but its window
+// origins are affine per residue, or when forced for A/B runs.
+void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
+    t.use_quasi = false;
+    int px, py, sx, sy;
+    if (p.quasi) {
+        px = p.qpx, py = p.qpy, sx = p.qsx, sy = p.qsy;
+    } else if (p.periodic) {
+        px = p.px, py = p.py, sx = p.sx, sy = p.sy;
+    } else {
+        return;
+    }
+    if (!jinc::quasi_supported(p.fs, px, py, sx, sy, p.n_col_classes, p.n_row_classes)) return;
+    jinc::QuasiArgs qa;
+    qa.coeffs = t.plan.coeffs;
+    qa.col_class = t.plan.col_class;
+    qa.row_class = t.plan.row_class;
+    qa.interior_set = t.plan.interior_set;
+    qa.n_col_classes = p.n_col_classes;
+    qa.n_row_classes = p.n_row_classes;
+    qa.px = px, qa.py = py, qa.sx = sx, qa.sy = sy;
+    qa.ix0 = p.ix0, qa.iy0 = p.iy0;
+    qa.ni = (p.ix1 - p.ix0) / px;
+    qa.nj = (p.iy1 - p.iy0) / py;
+    if (qa.ni < 1 || qa.nj < 1) return;
+    int min_sx = INT32_MAX, max_sx = INT32_MIN, min_sy = INT32_MAX, max_sy = INT32_MIN;
+    for (int k = 0; k < px; ++k) {
+        qa.start_x[k] = p.col_start[p.ix0 + k];
+        min_sx = std::min(min_sx, qa.start_x[k]);
+        max_sx = std::max(max_sx, qa.start_x[k]);
+    }
+    for (int k = 0; k < py; ++k) {
+        qa.start_y[k] = p.row_start[p.iy0 + k];
+        min_sy = std::min(min_sy, qa.start_y[k]);
+        max_sy = std::max(max_sy, qa.start_y[k]);
+    }
+    qa.min_sx = min_sx, qa.min_sy = min_sy;
+    qa.src_w = p.g.src_w, qa.src_h = p.g.src_h, qa.dst_h = p.g.dst_h;
+    if (!jinc::quasi_configure(qa, p.fs, max_sx - min_sx, max_sy - min_sy)) return;
+    t.quasi = qa;
+    t.use_quasi = true;
+    if (!t.use_periodic) t.border_rects = border_frame(p, p.ix0 + px * qa.ni, p.iy0 + py * qa.nj);
 }
 
 void init_device(jinc_filter& f, int device) {
@@ -410,6 +462,7 @@ void init_device(jinc_filter& f, int device) {
     for (size_t i = 0; i < f.plans.size(); ++i) {
         upload_table(f.plans[i], f.tables[i], f.stream);
         plan_launches(f.plans[i], f.tables[i]);
+        plan_quasi(f.plans[i], f.tables[i]);
     }
 }
 
@@ -431,9 +484,17 @@ void ensure_frame_bufs(jinc_filter& f) {
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
              void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
     const int sb = f.vi_in.component_size;
+    // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
+    // kernel wherever it applies (also for exactly periodic plans)
+    auto wants_quasi = [&](const DeviceTable& t) {
+        return t.use_quasi && (f.kernel_mode == 7 || (f.kernel_mode != 1 && !t.use_periodic));
+    };
+    auto wants_periodic = [&](const DeviceTable& t) { return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7; };
     bool any_periodic = false;
-    for (int i = 0; i < f.planecount; ++i)
-        any_periodic |= f.tables[f.table_of_plane(i)].use_periodic && f.kernel_mode != 1;
+    for (int i = 0; i < f.planecount; ++i) {
+        const DeviceTable& t = f.tables[f.table_of_plane(i)];
+        any_periodic |= wants_periodic(t) || wants_quasi(t);
+    }
     // A/B on MI355X: overlapping wins 12 % on C3 (fs 17) and 2-3 % on C4 (fs 9), loses 4 % on C2 (fs 7).
     const bool want_overlap = f.overlap_border < 0 ? f.plans[0].fs >= 9 : f.overlap_border != 0;
     const bool fork = any_periodic && want_overlap;
@@ -461,7 +522,8 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         io.nframes = nframes;
         io.sample_bytes = sb;
         io.peak = f.peak;
-        const bool periodic = t.use_periodic && f.kernel_mode != 1;
+        const bool quasi = wants_quasi(t);
+        const bool periodic = !quasi && wants_periodic(t);
         auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
             EventPair ev;
             if (f.profiling) {
@@ -475,13 +537,17 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 sink.push_back(ev);
             }
         };
-        if (periodic) {
+        if (periodic || quasi) {
             if (t.border_rects.n > 0)
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
-            timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
-                return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode >= 3 ? f.kernel_mode - 2 : 0);
-            });
+            if (quasi)
+                timed(f.ev_periodic, stream, "quasi-periodic kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_quasi(t.quasi, t.plan.fs, io, s); });
+            else
+                timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
+                    return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode >= 3 ? f.kernel_mode - 2 : 0);
+                });
         } else {
             timed(f.ev_gather, stream, "gather kernel launch",
                   [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.whole, s); });
@@ -663,6 +729,11 @@ int jinc_filter_plan_info(const jinc_filter* f, int table, jinc_plan_info* out) 
     i.plan_bytes = static_cast<int64_t>(4) * (p->col_start.size() + p->row_start.size() + p->col_class.size() +
                                               p->row_class.size() + p->interior_set.size() + p->bcol_set.size() +
                                               p->brow_set.size() + p->coeffs.size());
+    i.quasi = p->quasi ? 1 : 0;
+    i.quasi_period_x = p->qpx;
+    i.quasi_period_y = p->qpy;
+    i.quasi_step_x = p->qsx;
+    i.quasi_step_y = p->qsy;
     *out = i;
     return JINC_OK;
 }
@@ -750,7 +821,7 @@ int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, fl
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 6) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 7) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

@@ -55,6 +55,30 @@ struct PeriodicArgs {
     int dst_h = 0;  // rows of the destination plane (bounds of the store descriptor)
 };
 
+// Quasi-periodic interior: the window origins are affine per residue (output pixel (ix0 + px*i + p,
+// iy0 + py*j + q) reads the source window at (start_x[p] + sx*i, start_y[q] + sy*j)) but the coefficient
+// set is looked up per row and per lane, because the phase classes of drifting ratios change along the axes.
+struct QuasiArgs {
+    const float* coeffs = nullptr;
+    const int32_t* col_class = nullptr;
+    const int32_t* row_class = nullptr;
+    const int32_t* interior_set = nullptr;
+    int n_col_classes = 0, n_row_classes = 0;
+    int px = 1, py = 1, sx = 1, sy = 1;
+    int ix0 = 0, iy0 = 0, ni = 0, nj = 0;
+    int start_x[8] = {0}, start_y[8] = {0};
+    int min_sx = 0, min_sy = 0;
+    int lds_cols = 0, lds_rows = 0, lds_pitch = 0;  // fp32 source tile staged per workgroup
+    int rg = 1;                                     // row groups (of fs output rows) per tile
+    int nwaves = 4;                                 // waves per workgroup (divides px*py evenly where possible)
+    int src_w = 0, src_h = 0, dst_h = 0;
+};
+
+bool quasi_supported(int fs, int px, int py, int sx, int sy, int n_col_classes, int n_row_classes);
+// Fills the tile geometry fields (lds_*, rg, nwaves) of `args`; returns false if no configuration fits.
+bool quasi_configure(QuasiArgs& args, int fs, int spread_x, int spread_y);
+int launch_quasi(const QuasiArgs& args, int fs, const PlaneIO& io, void* stream);
+
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);
 

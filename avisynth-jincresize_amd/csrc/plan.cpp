@@ -133,6 +133,27 @@ bool find_period(const std::vector<int32_t>& cls, const std::vector<int32_t>& st
     return false;
 }
 
+// Smallest period p (<= max_p) under which the window origins alone are affine over [i0, i1).
+bool find_affine_period(const std::vector<int32_t>& start, int i0, int i1, int max_p, int& period, int& advance) {
+    const int len = i1 - i0;
+    for (int p = 1; p <= max_p && 2 * p <= len; ++p) {
+        const int s = start[i0 + p] - start[i0];
+        if (s < 1) continue;
+        bool ok = true;
+        for (int i = i0; i + p < i1; ++i)
+            if (start[i + p] - start[i] != s) {
+                ok = false;
+                break;
+            }
+        if (ok) {
+            period = p;
+            advance = s;
+            return true;
+        }
+    }
+    return false;
+}
+
 }  // namespace
 
 PlanePlan build_plane_plan(const JincLut& lut, const TableGeometry& g) {
@@ -275,6 +296,15 @@ PlanePlan build_plane_plan(const JincLut& lut, const TableGeometry& g) {
             plan.py = py;
             plan.sx = sx;
             plan.sy = sy;
+        }
+        int qpx, qpy, qsx, qsy;
+        if (find_affine_period(plan.col_start, plan.ix0, plan.ix1, kMaxPeriod, qpx, qsx) &&
+            find_affine_period(plan.row_start, plan.iy0, plan.iy1, kMaxPeriod, qpy, qsy)) {
+            plan.quasi = true;
+            plan.qpx = qpx;
+            plan.qpy = qpy;
+            plan.qsx = qsx;
+            plan.qsy = qsy;
         }
     } else if (!cx || !cy) {
         plan.ix0 = plan.ix1 = plan.iy0 = plan.iy1 = 0;

@@ -55,6 +55,11 @@ struct PlanePlan {
     int ix0 = 0, ix1 = 0, iy0 = 0, iy1 = 0;
     bool periodic = false;
     int px = 0, py = 0, sx = 0, sy = 0;
+    // Weaker structure that also holds for ratios whose phases drift (1.5x, 3x: the reference accumulates
+    // positions in float): the window ORIGINS are exactly affine per residue, col_start[x+qpx] == col_start[x]+qsx
+    // (rows likewise), while the phase classes may change now and then along an axis.
+    bool quasi = false;
+    int qpx = 0, qpy = 0, qsx = 0, qsy = 0;
 
     int set_of(int x, int y) const {
         const int rc = row_class[y], cc = col_class[x];

@@ -175,6 +175,8 @@ typedef struct jinc_plan_info {
     int step_x, step_y;       /* source-pixel advance per period */
     int interior_x0, interior_x1, interior_y0, interior_y1; /* half-open interior rectangle */
     int64_t plan_bytes;   /* bytes of the device-resident plan for this table */
+    int quasi;            /* 1 when the window origins are affine per residue (quasi-periodic kernel applies) */
+    int quasi_period_x, quasi_period_y, quasi_step_x, quasi_step_y;
 } jinc_plan_info;
 
 /* table: 0 = luma / all planes, 1 = chroma table of subsampled formats (ref :552-558). */
@@ -194,7 +196,8 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
 
 /* Kernel selection override for tests/benchmarks: 0 = automatic, 1 = force the generic gather
  * kernel for every pixel, 2 = periodic fast kernel where the plan allows (same as automatic),
- * 3 = like 2 but always the row-streamed variant of the periodic kernel (A/B measurements). */
+ * 3..6 = A/B variants of the periodic kernels (row-streamed, other tile heights, packed math),
+ * 7 = the quasi-periodic kernel wherever it applies (it is the automatic choice only for drifting ratios). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* 1: the border gather kernel runs on a side stream concurrently with the periodic interior kernel
  * (fork/join by events around every call); 0: both on the caller's stream, back to back;

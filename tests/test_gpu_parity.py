@@ -268,7 +268,7 @@ def test_integer_conversion_ties(gpu_pkg):
     assert np.array_equal(gpu_pkg.debug_convert(f, np.float32, 0.0).view(np.uint32), f.view(np.uint32))
 
 
-@pytest.mark.parametrize("mode", [3, 4, 5, 6], ids=["rows", "window_rg4", "packed_rg4", "packed_rg8"])
+@pytest.mark.parametrize("mode", [3, 4, 5, 6, 7], ids=["rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi"])
 @pytest.mark.parametrize("fmt,sw,sh,tw,th", [("Y8", 640, 360, 1280, 720), ("Y16", 333, 211, 666, 422),
                                              ("Y32", 200, 150, 400, 300), ("YUV420P8", 258, 130, 516, 260),
                                              ("Y8", 100, 80, 400, 320)])
@@ -282,4 +282,35 @@ def test_kernel_variants_match_oracle(gpu_pkg, O, fmt, sw, sh, tw, th, mode):
     f.set_kernel_mode(mode)
     got = f.get_frame(src)
     assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} mode {mode}")
+    f.close()
+
+
+QUASI_CASES = [
+    ("Y8", 320, 180, 480, 270, {}, (3, 3, 2, 2)),                    # 1.5x: drifting phases, affine origins (period 3, step 2)
+    ("Y8", 1280 // 2, 720 // 2, 1920 // 2, 1080 // 2, {}, (3, 3, 2, 2)),
+    ("Y16", 211, 97, 633, 291, {}, (3, 3, 1, 1)),                    # 3x
+    ("Y32", 150, 120, 225, 180, dict(tap=4), (3, 3, 2, 2)),          # fs 9
+    ("YUV420P8", 256, 144, 384, 216, {}, (3, 3, 2, 2)),              # chroma table too
+    ("Y8", 240, 160, 640, 360, {}, None),                            # 8/3 x 9/4: whatever the plan finds
+    ("Y8", 300, 200, 400, 250, dict(tap=2), None),                   # 4/3 x 5/4
+]
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "gather"])
+@pytest.mark.parametrize("case", QUASI_CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
+def test_quasi_periodic_plans(gpu_pkg, O, case, mode):
+    """Ratios whose phase classes drift (the reference accumulates positions in float): the plan is not
+    periodic, but the window origins are affine, so the quasi-periodic kernel takes the interior."""
+    fmt, sw, sh, tw, th, kw, want_q = case
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=2718)
+    want = of.get_frame(src, threads=4)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    info = f.plan_info()
+    if want_q is not None:
+        assert info.periodic == 0 and info.quasi == 1
+        assert (info.quasi_period_x, info.quasi_period_y, info.quasi_step_x, info.quasi_step_y) == want_q
+    f.set_kernel_mode(mode)
+    got = f.get_frame(src)
+    assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th} mode {mode}")
     f.close()
