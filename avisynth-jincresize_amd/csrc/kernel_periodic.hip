@@ -1,0 +1,463 @@
+// kernel_periodic.hip -- interior kernels of exactly phase-periodic plans (integer up-scales):
+//   ewa_periodic_kernel       fs 7 / 9: one phase per wave, coefficients in SGPRs, source tile in LDS as fp32,
+//                             fs x fs register window sliding down the tile (compile-time rotation)
+//   ewa_periodic_pk_kernel    the same with two columns per lane on v_pk_mul_f32 / v_pk_add_f32 (A/B variant)
+//   ewa_periodic_rows_kernel  any odd fs <= 17: 4 x 4 chains per lane, ly-major loop, column-plane LDS layout
+// See device_common.hpp for the parity rules.
+#include "device_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace jinc {
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Periodic interior kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileCols = 64;  // source-aligned columns per tile = lanes of a wave
+
+// RG: row groups of FS rows per tile.  A/B on MI355X (C2): 8 groups 2.3 % faster than 4, 16 groups 10 % slower.
+template <int FS, int RG = (FS <= 7 ? 8 : 6)>
+struct PeriodicCfg {
+    static constexpr int kRowGroups = RG;
+    static constexpr int kTileRows = FS * kRowGroups;     // period-rows per tile (multiple of FS)
+    static constexpr int kLdsCols = kTileCols + FS;       // 64 + (FS-1) halo + 1 phase spread
+    static constexpr int kLdsPitch = kLdsCols + 1;        // odd pitch not needed for row reads; keeps staging writes spread
+    static constexpr int kLdsRows = kTileRows + FS;       // TJ + (FS-1) halo + 1 phase spread
+};
+
+template <typename T, int FS, int RG>
+__global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = PeriodicCfg<FS, RG>;
+    __shared__ float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+
+    // ---- stage the source tile as fp32 (each source sample converted once) ----
+    {
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        for (int r = wave; r < Cfg::kLdsRows; r += 4) {
+            int gy = gy0 + r;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int c = lane; c < Cfg::kLdsCols; c += 64) {
+                int gx = gx0 + c;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                tile[r * Cfg::kLdsPitch + c] = to_float(srow[gx]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nphase = a.px * a.py;
+    for (int ph = wave; ph < nphase; ph += 4) {
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+
+        // wave-uniform coefficients -> SGPRs
+        const JINC_CONSTANT float* cs =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
+        float cf[FS * FS];
+#pragma unroll
+        for (int k = 0; k < FS * FS; ++k) cf[k] = cs[(k / FS) * padded_row(FS) + (k % FS)];
+
+        const float* base = tile + (a.start_y[q] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[p] - a.min_sx) + lane;
+
+        const unsigned x = a.ix0 + a.px * (i0 + lane) + p;  // per-lane output column
+        if ((i0 + lane) >= a.ni) continue;                   // whole phase loop under one exec mask
+        const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                           static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+        const uint32_t xoff = x * static_cast<uint32_t>(sizeof(T));
+
+        float win[FS][FS];
+#pragma unroll
+        for (int r = 0; r < FS - 1; ++r)
+#pragma unroll
+            for (int lx = 0; lx < FS; ++lx) win[r][lx] = base[r * Cfg::kLdsPitch + lx];
+
+        for (int g = 0; g < Cfg::kRowGroups; ++g) {
+            if (j0 + g * FS >= a.nj) break;  // wave-uniform: the bottom tiles usually need fewer groups
+            const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#pragma unroll
+            for (int u = 0; u < FS; ++u) {
+                // newest window row: tile row g*FS + u + FS-1 -> slot (u + FS-1) % FS
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx)
+                    win[(u + FS - 1) % FS][lx] = gbase[(u + FS - 1) * Cfg::kLdsPitch + lx];
+
+                float acc = 0.f;
+#pragma unroll
+                for (int ly = 0; ly < FS; ++ly)
+#pragma unroll
+                    for (int lx = 0; lx < FS; ++lx) acc = acc + win[(u + ly) % FS][lx] * cf[ly * FS + lx];
+
+                const int j = j0 + g * FS + u;  // wave-uniform
+                if (j < a.nj) {
+                    const int y = a.iy0 + a.py * j + q;
+                    store_sample_buf<T>(drsrc, xoff, static_cast<uint32_t>(y) * io.dst_pitch, acc, io.peak);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, packed-math form (experimental A/B variant)
+// ------------------------------------------------------------------------------------------------
+// Same algorithm as ewa_periodic_kernel, but a lane owns TWO source-aligned columns 64 apart and keeps
+// both register windows as 2-vectors, so every tap is one v_pk_mul_f32 + one v_pk_add_f32 (two
+// independent IEEE products / sums per instruction; nothing is fused or reassociated: each half is
+// exactly the scalar chain).  The coefficient stays in an SGPR and is broadcast to both halves by op_sel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc-independent product of a 2-vector with ONE coefficient taken from the low (HI = false) or high half of
+// an aligned SGPR pair, broadcast to both halves by op_sel -- written as asm because the compiler otherwise
+// materialises every (c, c) splat as its own SGPR pair (98 SGPRs for fs = 7 -> spills).  Register-only VALU.
+// One kernel row (7 taps) of the packed chain as a single asm statement: acc += w[lx] * c[lx], lx = 0..6, each tap
+// v_pk_mul_f32 (coefficient = low or high half of an aligned SGPR pair, broadcast to both halves by op_sel)
+// followed by v_pk_add_f32 -- un-fused, in order.  One statement per row keeps the compiler's per-statement
+// boundary pad (one s_nop) at 1 per 14 instructions; register-only VALU, interlocked by hardware.
+__device__ __forceinline__ void pk_row7(f32x2& acc, const f32x2 (&w)[7], f32x2 p01, f32x2 p23, f32x2 p45, f32x2 p6x) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %9 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %10 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %6, %11 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %7, %11 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %8, %12 op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "s"(p01), "s"(p23), "s"(p45), "s"(p6x));
+}
+
+template <int FS, int RG>
+struct PeriodicPkCfg {
+    static constexpr int kRowGroups = RG;
+    static constexpr int kTileRows = FS * RG;
+    static constexpr int kTileCols = 128;
+    static constexpr int kSrcCols = kTileCols + FS;  // source columns staged per tile row
+    // LDS row = pairs: pair k = (source column k, source column 64 + k), k = 0 .. 64+FS-1, so that a lane's two
+    // windows (columns lane+lx and 64+lane+lx) arrive as one aligned ds_read_b64 -> one VGPR pair.
+    static constexpr int kPairsPerRow = 64 + FS;
+    static constexpr int kLdsPitch = 2 * kPairsPerRow + 2;  // floats; even (8-byte aligned rows)
+    static constexpr int kLdsRows = kTileRows + FS;
+};
+
+template <typename T, int FS, int RG>
+__global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = PeriodicPkCfg<FS, RG>;
+    __shared__ __attribute__((aligned(16))) float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * Cfg::kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    {
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        for (int r = wave; r < Cfg::kLdsRows; r += 4) {
+            int gy = gy0 + r;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+            float* trow = tile + r * Cfg::kLdsPitch;
+#pragma unroll
+            for (int c = lane; c < Cfg::kSrcCols; c += 64) {
+                int gx = gx0 + c;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                const float v = to_float(srow[gx]);
+                if (c < Cfg::kPairsPerRow) trow[2 * c] = v;        // first element of pair c
+                if (c >= 64) trow[2 * (c - 64) + 1] = v;           // second element of pair c - 64
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nphase = a.px * a.py;
+    for (int ph = wave; ph < nphase; ph += 4) {
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+        const JINC_CONSTANT float* cs =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
+        // coefficient rows as aligned 64-bit SGPR pairs (rows are padded to a multiple of 4 floats)
+        constexpr int kPairs = padded_row(FS) / 2;
+        const JINC_CONSTANT f32x2* cs2 = (const JINC_CONSTANT f32x2*)cs;
+        f32x2 cp[FS * kPairs];
+#pragma unroll
+        for (int k = 0; k < FS * kPairs; ++k) cp[k] = cs2[k];
+
+        const f32x2* base = reinterpret_cast<const f32x2*>(tile + (a.start_y[q] - a.min_sy) * Cfg::kLdsPitch) +
+                            (a.start_x[p] - a.min_sx) + lane;
+        constexpr int kPitch2 = Cfg::kLdsPitch / 2;  // row pitch in pairs
+        const int ia = i0 + lane;
+        if (ia >= a.ni) continue;
+        const bool b_ok = ia + 64 < a.ni;
+        const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                           static_cast<uint32_t>(io.dst_pitch) * a.dst_h);
+        const uint32_t xoff_a = (a.ix0 + a.px * ia + p) * static_cast<uint32_t>(sizeof(T));
+        const uint32_t xoff_b = xoff_a + 64u * a.px * static_cast<uint32_t>(sizeof(T));
+
+        f32x2 win[FS][FS];
+#pragma unroll
+        for (int r = 0; r < FS - 1; ++r)
+#pragma unroll
+            for (int lx = 0; lx < FS; ++lx) win[r][lx] = base[r * kPitch2 + lx];
+
+        for (int g = 0; g < Cfg::kRowGroups; ++g) {
+            if (j0 + g * FS >= a.nj) break;
+            const f32x2* gbase = base + (g * FS) * kPitch2;
+#pragma unroll
+            for (int u = 0; u < FS; ++u) {
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx) win[(u + FS - 1) % FS][lx] = gbase[(u + FS - 1) * kPitch2 + lx];
+                f32x2 acc = {0.f, 0.f};
+                static_assert(FS == 7, "packed variant is written for fs = 7");
+#pragma unroll
+                for (int ly = 0; ly < FS; ++ly)
+                    pk_row7(acc, win[(u + ly) % FS], cp[ly * kPairs], cp[ly * kPairs + 1], cp[ly * kPairs + 2], cp[ly * kPairs + 3]);
+                const int j = j0 + g * FS + u;
+                if (j < a.nj) {
+                    const uint32_t soff = static_cast<uint32_t>(a.iy0 + a.py * j + q) * io.dst_pitch;
+                    store_sample_buf<T>(drsrc, xoff_a, soff, acc.x, io.peak);
+                    if (b_ok) store_sample_buf<T>(drsrc, xoff_b, soff, acc.y, io.peak);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, row-streamed form (any filter size, used for fs > 9)
+// ------------------------------------------------------------------------------------------------
+// Same phase-uniform idea as ewa_periodic_kernel (one phase per wave => coefficients in SGPRs), but
+// sized for footprints whose fs x fs window does not fit the register file (fs = 17: 289 values):
+//   * a lane owns K = 4 consecutive source-aligned columns and R = 4 consecutive period-rows
+//     (16 independent accumulation chains), so one LDS row segment of fs+K-1 samples feeds K*fs taps;
+//   * the loop runs ly-major: the fs coefficients of kernel row ly sit in SGPRs and are reused by
+//     all 16 pixels; each pixel still sees its taps in (ly, lx) raster order, so every chain is the
+//     reference's sequential chain;
+//   * the LDS tile is stored as K column-planes (column c -> plane c % K, index c / K) so that the
+//     64 lanes of a wave, which are K columns apart, read consecutive LDS words (no bank conflicts).
+template <int FS, int KC = 4>
+struct RowsCfg {
+    static constexpr int K = KC;       // columns per lane (4, or 3 when that wastes fewer overhanging columns)
+    static constexpr int R = 4;        // rows per chunk (accumulators per lane = R * K)
+    static constexpr int kChunks = 4;  // chunks per tile
+    static constexpr int kTileRows = R * kChunks;
+    static constexpr int kTileCols = 64 * K;
+    static constexpr int kCols = kTileCols + FS;  // + (FS-1) halo + 1 phase spread
+    static constexpr int kPlaneMin = 64 + (FS + K - 1) / K + 1;
+    static constexpr int kPlane = ((kPlaneMin - 8 + 31) / 32) * 32 + 8;  // == 8 (mod 32): the K planes start on distinct banks
+    static constexpr int kRows = kTileRows + FS;  // + (FS-1) halo + 1 phase spread
+    // LDS layout [plane][row][index]: every ds_read of a lane stays within 255 dwords of one of K
+    // per-plane base registers (ds_read2_b32 immediate range), so the inner loop has no address VALU.
+    static constexpr int kPlaneStride = kRows * kPlane;  // kRows is odd -> plane bases fall on distinct banks
+    static constexpr int kWaves = 8;
+    static constexpr int kThreads = 64 * kWaves;
+};
+
+template <typename T, int FS, int KC, int OFF>
+__device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs, BufferRsrc drsrc,
+                                          int dst_pitch, float peak, int y0, int ystep, int rows_valid, unsigned x0,
+                                          unsigned xstep, int cols_valid) {
+    using Cfg = RowsCfg<FS, KC>;
+    constexpr int K = Cfg::K, R = Cfg::R;
+    float acc[R][K];
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj)
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[jj][k] = 0.f;
+
+    // One LDS word offset per plane, kept in its own VGPR (the empty asm stops the compiler from
+    // re-deriving plane bases as "base + large constant" with a VALU add in front of every read).
+    unsigned plane_off[K];
+#pragma unroll
+    for (int m = 0; m < K; ++m) {
+        plane_off[m] = base_off + m * Cfg::kPlaneStride;
+        asm volatile("" : "+v"(plane_off[m]));
+    }
+
+    for (int ly = 0; ly < FS; ++ly) {
+        float c[FS];
+#pragma unroll
+        for (int lx = 0; lx < FS; ++lx) c[lx] = cs[ly * padded_row(FS) + lx];
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            float seg[FS + K - 1];
+#pragma unroll
+            for (int u = 0; u < FS + K - 1; ++u)
+                seg[u] = tile[plane_off[(u + OFF) % K] + (jj * Cfg::kPlane + (u + OFF) / K)];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx) acc[jj][k] = acc[jj][k] + seg[k + lx] * c[lx];
+        }
+#pragma unroll
+        for (int m = 0; m < K; ++m) plane_off[m] += Cfg::kPlane;  // next kernel row
+    }
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj) {
+        if (jj < rows_valid) {  // wave-uniform
+            const uint32_t soff = static_cast<uint32_t>(y0 + jj * ystep) * dst_pitch;
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (k < cols_valid)
+                    store_sample_buf<T>(drsrc, (x0 + k * xstep) * static_cast<uint32_t>(sizeof(T)), soff, acc[jj][k], peak);
+        }
+    }
+}
+
+template <typename T, int FS, int KC>
+__global__ __launch_bounds__(512) void ewa_periodic_rows_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = RowsCfg<FS, KC>;
+    constexpr int K = Cfg::K, R = Cfg::R;
+    __shared__ float tile[K * Cfg::kPlaneStride];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * Cfg::kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+
+    {
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        for (int r = wave; r < Cfg::kRows; r += Cfg::kWaves) {
+            int gy = gy0 + r;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int c = lane; c < Cfg::kCols; c += 64) {
+                int gx = gx0 + c;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = to_float(srow[gx]);
+            }
+        }
+    }
+    __syncthreads();
+
+    const BufferRsrc dframe = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                        static_cast<uint32_t>(io.dst_pitch) * a.dst_h);
+    const int nphase = a.px * a.py;
+    const int nitems = nphase * Cfg::kChunks;
+    const int cols_valid = a.ni - (i0 + K * lane);  // per lane: how many of its K columns exist
+    if (cols_valid <= 0) return;
+    for (int item = wave; item < nitems; item += Cfg::kWaves) {
+        const int ch = item / nphase;
+        const int ph = item - ch * nphase;
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+        const int j = j0 + ch * R;  // first period-row of the chunk
+        const int rows_valid = a.nj - j;
+        if (rows_valid <= 0) continue;
+        const JINC_CONSTANT float* cs =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
+        const unsigned base = ((a.start_y[q] - a.min_sy) + ch * R) * Cfg::kPlane + lane;
+        const int y0 = a.iy0 + a.py * j + q;
+        const unsigned x0 = a.ix0 + a.px * (i0 + K * lane) + p;
+        if (a.start_x[p] - a.min_sx)
+            rows_item<T, FS, KC, 1>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+        else
+            rows_item<T, FS, KC, 0>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+    }
+}
+
+template <typename T, int FS, int RG = PeriodicCfg<FS>::kRowGroups>
+int launch_periodic_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicCfg<FS, RG>;
+    dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_kernel<T, FS, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <typename T, int FS, int RG>
+int launch_periodic_pk_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicPkCfg<FS, RG>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_pk_kernel<T, FS, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <typename T, int FS, int KC>
+int launch_rows_k(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = RowsCfg<FS, KC>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_rows_kernel<T, FS, KC>), grid, dim3(Cfg::kThreads, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+// Tile width 256 (K = 4) or 192 (K = 3) columns: whichever leaves fewer overhanging (idle) lanes in the last tile
+// column; ties go to K = 4 (fewer LDS reads per tap).
+template <typename T, int FS>
+int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    const long long cover4 = (pa.ni + 255) / 256 * 256LL, cover3 = (pa.ni + 191) / 192 * 192LL;
+    if (cover3 * 100 < cover4 * 97) return launch_rows_k<T, FS, 3>(pa, io, stream);
+    return launch_rows_k<T, FS, 4>(pa, io, stream);
+}
+
+template <typename T>
+int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
+    if (variant == 3 && fs == 7) return launch_periodic_pk_t<T, 7, 4>(pa, io, stream);
+    if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
+    if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);
+    if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 3>(pa, io, stream);
+    if (variant == 1) {
+        if (fs == 7) return launch_rows_t<T, 7>(pa, io, stream);
+        if (fs == 9) return launch_rows_t<T, 9>(pa, io, stream);
+    }
+    switch (fs) {
+        case 3: return launch_rows_t<T, 3>(pa, io, stream);
+        case 5: return launch_rows_t<T, 5>(pa, io, stream);
+        case 7: return launch_periodic_t<T, 7>(pa, io, stream);
+        case 9: return launch_periodic_t<T, 9>(pa, io, stream);
+        case 11: return launch_rows_t<T, 11>(pa, io, stream);
+        case 13: return launch_rows_t<T, 13>(pa, io, stream);
+        case 15: return launch_rows_t<T, 15>(pa, io, stream);
+        case 17: return launch_rows_t<T, 17>(pa, io, stream);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
+
+}  // namespace
+
+bool periodic_supported(int fs, int px, int py, int sx, int sy) {
+    if (sx != 1 || sy != 1) return false;
+    if (px < 1 || py < 1 || px > 8 || py > 8) return false;
+    return fs >= 3 && fs <= 17 && (fs & 1);  // taps 1..8 at >= 1x scale
+}
+
+int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant) {
+    if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (io.sample_bytes) {
+        case 1: return launch_periodic_fs<uint8_t>(args, fs, io, s, variant);
+        case 2: return launch_periodic_fs<uint16_t>(args, fs, io, s, variant);
+        default: return launch_periodic_fs<float>(args, fs, io, s, variant);
+    }
+}
+
+
+}  // namespace jinc

@@ -66,9 +66,10 @@ struct QuasiArgs {
     int n_col_classes = 0, n_row_classes = 0;
     int px = 1, py = 1, sx = 1, sy = 1;
     int ix0 = 0, iy0 = 0, ni = 0, nj = 0;
-    int start_x[8] = {0}, start_y[8] = {0};
+    int start_x[16] = {0}, start_y[16] = {0};
     int min_sx = 0, min_sy = 0;
     int lds_cols = 0, lds_rows = 0, lds_pitch = 0;  // fp32 source tile staged per workgroup
+    int lds_plane = 0;                              // words per column plane (sx planes per tile row)
     int rg = 1;                                     // row groups (of fs output rows) per tile
     int nwaves = 4;                                 // waves per workgroup (divides px*py evenly where possible)
     int src_w = 0, src_h = 0, dst_h = 0;

@@ -298,8 +298,9 @@ PlanePlan build_plane_plan(const JincLut& lut, const TableGeometry& g) {
             plan.sy = sy;
         }
         int qpx, qpy, qsx, qsy;
-        if (find_affine_period(plan.col_start, plan.ix0, plan.ix1, kMaxPeriod, qpx, qsx) &&
-            find_affine_period(plan.row_start, plan.iy0, plan.iy1, kMaxPeriod, qpy, qsy)) {
+        constexpr int kMaxAffinePeriod = 16;
+        if (find_affine_period(plan.col_start, plan.ix0, plan.ix1, kMaxAffinePeriod, qpx, qsx) &&
+            find_affine_period(plan.row_start, plan.iy0, plan.iy1, kMaxAffinePeriod, qpy, qsy)) {
             plan.quasi = true;
             plan.qpx = qpx;
             plan.qpy = qpy;

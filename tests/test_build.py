@@ -28,9 +28,11 @@ def test_library_loads_without_gpu_and_reports_devices(pkg):
 
 def test_no_fused_multiply_add_in_device_code(pkg):
     """The opt=0 result is defined by separate v_mul_f32 / v_add_f32."""
-    isa = open(pkg.ISA_PATH).read()
+    isa = "\n".join(open(p).read() for p in pkg.ISA_PATHS)
     kernels = re.findall(r"^(_ZN4jinc\S*kernel\S*):", isa, flags=re.M)
-    assert any("ewa_gather_kernel" in k for k in kernels) and any("ewa_periodic_kernel" in k for k in kernels)
+    for name in ("ewa_gather_kernel", "ewa_periodic_kernel", "ewa_periodic_rows_kernel", "ewa_periodic_pk_kernel",
+                 "ewa_quasi_kernel"):
+        assert any(name in k for k in kernels), name
     fused = re.findall(r"^\s+(v_fma_f32|v_fmac_f32|v_mad_f32|v_mac_f32|v_pk_fma_f32|v_fma_mix\w*|v_mfma\w*)\b", isa, flags=re.M)
     assert fused == [], f"fused ops in device code: {sorted(set(fused))}"
     assert len(re.findall(r"^\s+v_mul_f32", isa, flags=re.M)) > 100
