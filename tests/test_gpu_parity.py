@@ -293,6 +293,8 @@ QUASI_CASES = [
     ("YUV420P8", 256, 144, 384, 216, {}, (3, 3, 2, 2)),              # chroma table too
     ("Y8", 240, 160, 640, 360, {}, None),                            # 8/3 x 9/4: whatever the plan finds
     ("Y8", 300, 200, 400, 250, dict(tap=2), None),                   # 4/3 x 5/4
+    ("Y8", 360, 270, 480, 360, {}, None),                            # 4/3x: exactly periodic with source step 3
+    ("Y16", 240, 160, 640, 360, dict(tap=4), None),                  # 8/3 x 9/4, fs 9
 ]
 
 
