@@ -1,0 +1,3 @@
+// kernel_quasi_fs9.hip -- ewa_quasi_kernel instantiated for filter size 9 (see kernel_quasi_impl.inc).
+#define JINC_QUASI_FS 9
+#include "kernel_quasi_impl.inc"
