@@ -28,7 +28,7 @@ def pytest_configure(config):
 def pkg():
     """The product package (ctypes binding of libjincresize_hip.so). Builds it if the .so is missing."""
     p = entry.load_package()
-    if not (os.path.exists(p.LIB_PATH) and all(os.path.exists(x) for x in p.ISA_PATHS)):
+    if not os.path.exists(p.LIB_PATH):  # (the ISA listings are only needed by tests/test_build.py)
         p.build()
     p.lib()
     return p

@@ -28,6 +28,8 @@ def test_library_loads_without_gpu_and_reports_devices(pkg):
 
 def test_no_fused_multiply_add_in_device_code(pkg):
     """The opt=0 result is defined by separate v_mul_f32 / v_add_f32."""
+    if not all(os.path.exists(p) for p in pkg.ISA_PATHS):
+        pkg.build()
     isa = "\n".join(open(p).read() for p in pkg.ISA_PATHS)
     kernels = re.findall(r"^(_ZN4jinc\S*kernel\S*):", isa, flags=re.M)
     for name in ("ewa_gather_kernel", "ewa_periodic_kernel", "ewa_periodic_rows_kernel", "ewa_periodic_pk_kernel",
