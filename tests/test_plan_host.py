@@ -92,3 +92,28 @@ def test_host_only_instance_refuses_frames(pkg):
     with pytest.raises(pkg.JincError) as e:
         f.get_frame(src)
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("sw,sh,tw,th,exact,q", [
+    (1280, 720, 1920, 1080, False, (3, 3, 2, 2)),     # 1.5x: phases drift, origins affine
+    (640, 360, 1920, 1080, False, (3, 3, 1, 1)),      # 3x
+    (720, 480, 1920, 1080, False, (8, 9, 3, 4)),      # 8/3 x 9/4
+    (1440, 1080, 1920, 1440, True, (4, 4, 3, 3)),     # 4/3x: exact arithmetic (step 0.75), periodic with source step 3
+    (1920, 1080, 3840, 2160, True, (2, 2, 1, 1)),     # 2x
+    (1920, 1080, 1280, 720, True, (2, 2, 3, 3)),      # 2/3 down-scale
+])
+def test_quasi_periodic_structure(pkg, sw, sh, tw, th, exact, q):
+    """Plan analysis used to pick the interior kernel: exact periodicity vs affine window origins only."""
+    f = pkg.Filter(pkg.FORMATS["Y8"], sw, sh, tw, th, device=-1)
+    info = f.plan_info()
+    assert bool(info.periodic) == exact
+    assert info.quasi == 1
+    assert (info.quasi_period_x, info.quasi_period_y, info.quasi_step_x, info.quasi_step_y) == q
+    if exact:
+        assert (info.period_x, info.period_y, info.step_x, info.step_y) == q
+    # the affine property itself, re-checked from the dumped plan
+    sx, sy, _ = f.plan_dump()
+    for start, a0, a1, P, S in ((sx, info.interior_x0, info.interior_x1, q[0], q[2]),
+                                (sy, info.interior_y0, info.interior_y1, q[1], q[3])):
+        seg = start[a0:a1]
+        assert np.all(seg[P:] - seg[:-P] == S)
