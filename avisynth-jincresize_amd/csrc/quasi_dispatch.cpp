@@ -29,7 +29,7 @@ bool quasi_configure(QuasiArgs& a, int fs, int spread_x, int spread_y) {
         const int rows = a.sy * rg * fs + fs + spread_y;
         const size_t bytes = sizeof(float) * static_cast<size_t>(rows) * a.lds_pitch +
                              sizeof(int) * (static_cast<size_t>(a.n_col_classes) * a.n_row_classes + a.py * rg * fs);
-        if (bytes <= budget || rg == 1) {
+        if (bytes <= budget || (rg == 1 && bytes <= 60 * 1024)) {  // one workgroup may not exceed 64 KB of LDS
             a.rg = rg;
             a.lds_rows = rows;
             return true;
