@@ -316,3 +316,57 @@ def test_quasi_periodic_plans(gpu_pkg, O, case, mode):
     got = f.get_frame(src)
     assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th} mode {mode}")
     f.close()
+
+
+def _random_case(rng):
+    fmts = ["Y8", "Y10", "Y16", "Y32", "YUV420P8", "YUV422P16", "YUV444P8", "YUV411P8", "YUV420PS", "RGBP8", "RGBAP16",
+            "YUVA420P8", "RGBPS"]
+    fmt = fmts[rng.integers(len(fmts))]
+    sw = int(rng.integers(40, 140)) & ~3
+    sh = int(rng.integers(40, 110)) & ~1
+    kind = rng.integers(5)
+    if kind == 0:      # integer up-scale
+        r = int(rng.integers(2, 5)); tw, th = sw * r, sh * r
+    elif kind == 1:    # 1.5x / 3x style
+        tw, th = sw * 3 // 2 // 4 * 4, sh * 3 // 2 // 2 * 2
+    elif kind == 2:    # arbitrary up-scale
+        tw = int(sw * rng.uniform(1.0, 3.0)) // 4 * 4; th = int(sh * rng.uniform(1.0, 3.0)) // 2 * 2
+    elif kind == 3:    # mild down-scale
+        tw = max(16, int(sw * rng.uniform(0.5, 1.0)) // 4 * 4); th = max(16, int(sh * rng.uniform(0.5, 1.0)) // 2 * 2)
+    else:              # anisotropic
+        tw = int(sw * rng.uniform(0.7, 2.5)) // 4 * 4; th = int(sh * rng.uniform(0.7, 2.5)) // 2 * 2
+    kw = dict(tap=int(rng.integers(1, 9)))
+    if rng.random() < 0.4:
+        kw.update(quant_x=int(rng.integers(1, 257)), quant_y=int(rng.integers(1, 257)))
+    if rng.random() < 0.4:
+        kw["blur"] = float(np.round(rng.uniform(0.8, 1.25), 3))
+    if rng.random() < 0.5:
+        kw.update(src_left=float(np.round(rng.uniform(-3, 6), 2)), src_top=float(np.round(rng.uniform(-3, 6), 2)),
+                  src_width=float(np.round(sw - rng.uniform(0, 10), 2)), src_height=float(np.round(sh - rng.uniform(0, 10), 2)))
+    if "420" in fmt:
+        kw["cplace"] = ["mpeg2", "mpeg1", "topleft"][rng.integers(3)]
+    elif fmt.startswith("YUV4") and ("422" in fmt or "411" in fmt):
+        kw["cplace"] = ["mpeg2", "mpeg1"][rng.integers(2)]
+    return fmt, sw, sh, tw, th, kw
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_randomised_arguments(gpu_pkg, O, seed):
+    """Seeded sweep over formats, ratios, taps, quantisation, blur, crops and chroma siting: the HIP path
+    (automatic kernel choice) must equal the oracle bit for bit whatever structure the plan has."""
+    rng = np.random.default_rng(1000 + seed)
+    fmt, sw, sh, tw, th, kw = _random_case(rng)
+    try:
+        of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    except Exception:
+        pytest.skip("oracle rejects this geometry")
+    try:
+        f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    except gpu_pkg.JincError as e:
+        assert "smaller than the filter footprint" in str(e)   # the reference reads out of bounds there
+        return
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=seed)
+    want = of.get_frame(src, threads=2)
+    got = f.get_frame(src)
+    assert_planes_equal(got, want, f.out_dims(), what=f"seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}")
+    f.close()
