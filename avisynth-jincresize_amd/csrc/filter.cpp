@@ -444,7 +444,10 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     if (!jinc::quasi_configure(qa, p.fs, max_sx - min_sx, max_sy - min_sy)) return;
     t.quasi = qa;
     t.use_quasi = true;
-    if (!t.use_periodic) t.border_rects = border_frame(p, p.ix0 + px * qa.ni, p.iy0 + py * qa.nj);
+    if (!t.use_periodic) {
+        t.border_rects = border_frame(p, p.ix0 + px * qa.ni, p.iy0 + py * qa.nj);
+        t.border_rects.private_sets = !p.periodic;
+    }
 }
 
 void init_device(jinc_filter& f, int device) {

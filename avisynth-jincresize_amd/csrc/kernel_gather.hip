@@ -19,6 +19,7 @@ struct GatherArgs {
     int lane_axis[4]; // 0: lanes run along x (wide rectangles), 1: along y (border columns)
     int stride[4];    // lane stride P: lane l of an item handles coordinate origin + P*l + residue
     int lines[4];     // lines (rows for lane_axis 0, columns for lane_axis 1) per block
+    int max_passes;   // uniform-coefficient passes per item before the per-lane fallback
 };
 
 constexpr int kGatherLdsFloats = 6144;  // 24 KB source tile per block
@@ -110,10 +111,9 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
                         for (int lx = 0; lx < FS; ++lx) w[ly * FS + lx] = s[ly * pitch + lx];
                 }
                 unsigned long long todo = __ballot(active);
-                // at most kMaxPasses uniform passes; items whose lanes nearly all own a private set (border
+                // at most a.max_passes uniform passes; items whose lanes nearly all own a private set (border
                 // pixels of drifting ratios) finish with per-lane coefficient loads instead of 64 passes
-                constexpr int kMaxPasses = 4;
-                for (int pass = 0; todo && pass < kMaxPasses; ++pass) {
+                for (int pass = 0; todo && pass < a.max_passes; ++pass) {
                     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
                     const int u = __builtin_amdgcn_readlane(set, leader);
                     const bool mine = active && set == u;
@@ -251,6 +251,7 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
     ga.plan = plan;
     ga.io = io;
     ga.rects = rects;
+    ga.max_passes = rects.private_sets ? 0 : 4;
     int total = 0;
     for (int r = 0; r < 4; ++r) {
         ga.block_begin[r] = total;

@@ -39,6 +39,9 @@ struct PlaneIO {
 struct RectList {
     int n = 0;
     int x0[4] = {0, 0, 0, 0}, y0[4] = {0, 0, 0, 0}, w[4] = {0, 0, 0, 0}, h[4] = {0, 0, 0, 0};
+    // true for the border frame of a plan that is not exactly periodic: there nearly every pixel owns a
+    // private coefficient set, so the kernel skips the uniform passes and loads coefficients per lane
+    bool private_sets = false;
 };
 
 // Phase-periodic interior (see plan.h): output pixel (ix0 + px*i + p, iy0 + py*j + q) reads the
