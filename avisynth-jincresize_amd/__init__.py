@@ -77,7 +77,8 @@ EXPORTS = ["jinc_device_count", "jinc_last_error", "jinc_filter_create", "jinc_f
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert"]
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_filter_set_pipeline",
+           "jinc_filter_submit", "jinc_filter_wait"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -104,6 +105,9 @@ def lib():
         L.jinc_filter_get_frame.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4]
         L.jinc_filter_process_device.argtypes = [C.c_void_p, _P4, _I4, _S4, _P4, _I4, _S4, C.c_int, C.c_void_p]
         L.jinc_filter_sync.argtypes = [C.c_void_p]
+        L.jinc_filter_set_pipeline.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.jinc_filter_submit.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4, C.POINTER(C.c_longlong)]
+        L.jinc_filter_wait.argtypes = [C.c_void_p, C.c_longlong]
         L.jinc_alias_args.argtypes = [C.c_int, C.POINTER(Args), C.POINTER(Args)]
         L.jinc_filter_num_tables.argtypes = [C.c_void_p]
         L.jinc_filter_plan_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(PlanInfo)]
@@ -282,6 +286,23 @@ class Filter:
             dp[i], dpitch[i] = outs[i].ctypes.data, outs[i].strides[0]
         self._check(lib().jinc_filter_get_frame(self._h, sp, spitch, dp, dpitch))
         return outs
+
+    # -- look-ahead pipeline: several frames in flight per instance --
+    def set_pipeline(self, depth: int, register_host_buffers: bool = False) -> None:
+        self._check(lib().jinc_filter_set_pipeline(self._h, int(depth), int(register_host_buffers)))
+
+    def submit(self, src_planes: Sequence[np.ndarray], dst_planes: Sequence[np.ndarray]) -> int:
+        """Enqueue one frame; dst_planes (from alloc_plane) are filled when wait(ticket) returns."""
+        sp, spitch, dp, dpitch = _P4(), _I4(), _P4(), _I4()
+        for i in range(self.fmt.planes):
+            sp[i], spitch[i] = src_planes[i].ctypes.data, src_planes[i].strides[0]
+            dp[i], dpitch[i] = dst_planes[i].ctypes.data, dst_planes[i].strides[0]
+        t = C.c_longlong()
+        self._check(lib().jinc_filter_submit(self._h, sp, spitch, dp, dpitch, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int) -> None:
+        self._check(lib().jinc_filter_wait(self._h, C.c_longlong(ticket)))
 
     # -- device-resident batch (pointers are raw device addresses) --
     def process_device(self, src_ptrs, src_pitches, src_strides, dst_ptrs, dst_pitches, dst_strides, nframes: int,

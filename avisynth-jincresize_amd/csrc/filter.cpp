@@ -61,11 +61,21 @@ struct EventPair {
     hipEvent_t start = nullptr, stop = nullptr;
 };
 
-struct DeviceFrameBuf {  // staging planes for the host-pointer entry point
+struct DeviceFrameBuf {  // device staging planes of one in-flight frame (host-pointer entry points)
     void* src[4] = {nullptr, nullptr, nullptr, nullptr};
     void* dst[4] = {nullptr, nullptr, nullptr, nullptr};
     int src_pitch[4] = {0, 0, 0, 0};
     int dst_pitch[4] = {0, 0, 0, 0};
+    hipStream_t stream = nullptr;  // slot 0 uses the filter's stream, further slots own theirs
+    bool ready = false;
+    bool busy = false;             // work enqueued and not yet waited for
+    long long ticket = -1;
+};
+
+struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-ahead pipeline, opt-in)
+    char* base = nullptr;
+    size_t bytes = 0;
+    unsigned long long stamp = 0;
 };
 
 }  // namespace
@@ -86,8 +96,11 @@ struct jinc_filter {
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
     hipStream_t stream = nullptr;
     std::vector<DeviceTable> tables;
-    DeviceFrameBuf bufs;
-    bool bufs_ready = false;
+    std::vector<DeviceFrameBuf> slots = std::vector<DeviceFrameBuf>(1);  // frames in flight (pipeline depth)
+    long long next_ticket = 0;
+    bool register_host = false;
+    std::vector<PinnedRange> pinned;
+    unsigned long long pin_clock = 0;
     bool profiling = false;
     std::vector<EventPair> ev_periodic, ev_gather;  // recorded, not yet collected
     // The border gather kernel (load/store-issue bound) runs on a side stream next to the periodic
@@ -100,10 +113,14 @@ struct jinc_filter {
             (void)hipSetDevice(device);
             for (auto& t : tables)
                 if (t.blob) (void)hipFree(t.blob);
-            for (int i = 0; i < 4; ++i) {
-                if (bufs.src[i]) (void)hipFree(bufs.src[i]);
-                if (bufs.dst[i]) (void)hipFree(bufs.dst[i]);
+            for (size_t s = 0; s < slots.size(); ++s) {
+                for (int i = 0; i < 4; ++i) {
+                    if (slots[s].src[i]) (void)hipFree(slots[s].src[i]);
+                    if (slots[s].dst[i]) (void)hipFree(slots[s].dst[i]);
+                }
+                if (s > 0 && slots[s].stream) (void)hipStreamDestroy(slots[s].stream);
             }
+            for (auto& p : pinned) (void)hipHostUnregister(p.base);
             for (auto* v : {&ev_periodic, &ev_gather})
                 for (auto& e : *v) {
                     (void)hipEventDestroy(e.start);
@@ -469,20 +486,51 @@ void init_device(jinc_filter& f, int device) {
     }
 }
 
-void ensure_frame_bufs(jinc_filter& f) {
-    if (f.bufs_ready) return;
+void ensure_slot(jinc_filter& f, DeviceFrameBuf& s, bool own_stream) {
+    if (s.ready) return;
     const int sb = f.vi_in.component_size;
     for (int i = 0; i < f.planecount; ++i) {
         int sw, sh, dw, dh;
         f.plane_dims(f.vi_in, i, sw, sh);
         f.plane_dims(f.vi_out, i, dw, dh);
-        f.bufs.src_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(sw) * sb, 256));
-        f.bufs.dst_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(dw) * sb, 256));
-        hip_check(hipMalloc(&f.bufs.src[i], static_cast<size_t>(f.bufs.src_pitch[i]) * sh), "hipMalloc(src plane)");
-        hip_check(hipMalloc(&f.bufs.dst[i], static_cast<size_t>(f.bufs.dst_pitch[i]) * dh), "hipMalloc(dst plane)");
+        s.src_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(sw) * sb, 256));
+        s.dst_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(dw) * sb, 256));
+        hip_check(hipMalloc(&s.src[i], static_cast<size_t>(s.src_pitch[i]) * sh), "hipMalloc(src plane)");
+        hip_check(hipMalloc(&s.dst[i], static_cast<size_t>(s.dst_pitch[i]) * dh), "hipMalloc(dst plane)");
     }
-    f.bufs_ready = true;
+    if (own_stream)
+        hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+    else
+        s.stream = f.stream;
+    s.ready = true;
 }
+
+// Pins [p, p + bytes) once (cache keyed by address range, LRU of 64 ranges) so that the async copies of the
+// pipeline really are asynchronous.  Failure to register is not an error: the copy then takes the pageable path.
+void pin_host_range(jinc_filter& f, const void* p, size_t bytes) {
+    char* c = const_cast<char*>(static_cast<const char*>(p));
+    for (auto& r : f.pinned)
+        if (c >= r.base && c + bytes <= r.base + r.bytes) {
+            r.stamp = ++f.pin_clock;
+            return;
+        }
+    if (f.pinned.size() >= 64) {
+        size_t lru = 0;
+        for (size_t i = 1; i < f.pinned.size(); ++i)
+            if (f.pinned[i].stamp < f.pinned[lru].stamp) lru = i;
+        (void)hipHostUnregister(f.pinned[lru].base);
+        f.pinned.erase(f.pinned.begin() + lru);
+    }
+    if (hipHostRegister(c, bytes, hipHostRegisterDefault) == hipSuccess) {
+        f.pinned.push_back({c, bytes, ++f.pin_clock});
+    } else {
+        (void)hipGetLastError();  // clear; e.g. the range overlaps memory somebody else has registered
+    }
+}
+
+// Enqueues H2D -> kernels -> D2H of one frame on the slot's stream.
+void submit_frame(jinc_filter& f, DeviceFrameBuf& s, const void* const src[4], const int src_pitch[4], void* const dst[4],
+                  const int dst_pitch[4]);
 
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
              void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
@@ -562,6 +610,32 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     }
 }
 
+void submit_frame(jinc_filter& f, DeviceFrameBuf& s, const void* const src[4], const int src_pitch[4], void* const dst[4],
+                  const int dst_pitch[4]) {
+    const int sb = f.vi_in.component_size;
+    for (int i = 0; i < f.planecount; ++i) {
+        if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
+        int sw, sh, dw, dh;
+        f.plane_dims(f.vi_in, i, sw, sh);
+        f.plane_dims(f.vi_out, i, dw, dh);
+        if (f.register_host) {
+            pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb);
+            pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb);
+        }
+        hip_check(hipMemcpy2DAsync(s.src[i], s.src_pitch[i], src[i], src_pitch[i], static_cast<size_t>(sw) * sb, sh,
+                                   hipMemcpyHostToDevice, s.stream),
+                  "H2D copy");
+    }
+    enqueue(f, s.src, s.src_pitch, nullptr, s.dst, s.dst_pitch, nullptr, 1, s.stream);
+    for (int i = 0; i < f.planecount; ++i) {
+        int dw, dh;
+        f.plane_dims(f.vi_out, i, dw, dh);
+        hip_check(hipMemcpy2DAsync(dst[i], dst_pitch[i], s.dst[i], s.dst_pitch[i], static_cast<size_t>(dw) * sb, dh,
+                                   hipMemcpyDeviceToHost, s.stream),
+                  "D2H copy");
+    }
+}
+
 template <typename Fn>
 int guarded(Fn&& fn) {
     try {
@@ -635,25 +709,71 @@ int jinc_filter_get_frame(jinc_filter* f, const void* const src[4], const int sr
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        ensure_frame_bufs(*f);
-        const int sb = f->vi_in.component_size;
-        for (int i = 0; i < f->planecount; ++i) {
-            if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
-            int sw, sh;
-            f->plane_dims(f->vi_in, i, sw, sh);
-            hip_check(hipMemcpy2DAsync(f->bufs.src[i], f->bufs.src_pitch[i], src[i], src_pitch[i],
-                                       static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, f->stream),
-                      "H2D copy");
+        for (auto& s : f->slots)  // a synchronous frame must not overtake frames still in the pipeline
+            if (s.busy) {
+                hip_check(hipStreamSynchronize(s.stream), "stream sync");
+                s.busy = false;
+            }
+        DeviceFrameBuf& s = f->slots[0];
+        ensure_slot(*f, s, false);
+        submit_frame(*f, s, src, src_pitch, dst, dst_pitch);
+        hip_check(hipStreamSynchronize(s.stream), "stream sync");
+    });
+}
+
+int jinc_filter_set_pipeline(jinc_filter* f, int depth, int register_host_buffers) {
+    if (!f || depth < 1 || depth > 16) return fail(JINC_ERR_INVALID_ARG, "JincResize: pipeline depth must be 1..16.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        for (auto& s : f->slots)
+            if (s.busy) {
+                hip_check(hipStreamSynchronize(s.stream), "stream sync");
+                s.busy = false;
+            }
+        if (static_cast<size_t>(depth) > f->slots.size()) f->slots.resize(depth);
+        f->register_host = register_host_buffers != 0;
+        if (!f->register_host) {
+            for (auto& p : f->pinned) (void)hipHostUnregister(p.base);
+            f->pinned.clear();
         }
-        enqueue(*f, f->bufs.src, f->bufs.src_pitch, nullptr, f->bufs.dst, f->bufs.dst_pitch, nullptr, 1, f->stream);
-        for (int i = 0; i < f->planecount; ++i) {
-            int dw, dh;
-            f->plane_dims(f->vi_out, i, dw, dh);
-            hip_check(hipMemcpy2DAsync(dst[i], dst_pitch[i], f->bufs.dst[i], f->bufs.dst_pitch[i],
-                                       static_cast<size_t>(dw) * sb, dh, hipMemcpyDeviceToHost, f->stream),
-                      "D2H copy");
+    });
+}
+
+int jinc_filter_submit(jinc_filter* f, const void* const src[4], const int src_pitch[4], void* const dst[4],
+                       const int dst_pitch[4], long long* ticket) {
+    if (!f || !src || !dst || !src_pitch || !dst_pitch || !ticket) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        const long long t = f->next_ticket;
+        const size_t k = static_cast<size_t>(t % static_cast<long long>(f->slots.size()));
+        DeviceFrameBuf& s = f->slots[k];
+        ensure_slot(*f, s, k != 0);
+        if (s.busy) {  // the slot's previous frame has to be finished before its buffers are reused
+            hip_check(hipStreamSynchronize(s.stream), "stream sync");
+            s.busy = false;
         }
-        hip_check(hipStreamSynchronize(f->stream), "stream sync");
+        submit_frame(*f, s, src, src_pitch, dst, dst_pitch);
+        s.busy = true;
+        s.ticket = t;
+        *ticket = t;
+        ++f->next_ticket;
+    });
+}
+
+int jinc_filter_wait(jinc_filter* f, long long ticket) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        for (auto& s : f->slots)
+            if (s.busy && s.ticket == ticket) {
+                hip_check(hipStreamSynchronize(s.stream), "stream sync");
+                s.busy = false;
+                return;
+            }
+        // unknown or already completed ticket: nothing to wait for (its slot has been reused or waited on)
     });
 }
 

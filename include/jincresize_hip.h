@@ -145,6 +145,22 @@ JINC_API int jinc_filter_chroma_location(const jinc_filter *f);
 JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], const int src_pitch[4],
                                    void *const dst[4], const int dst_pitch[4]);
 
+/* ---- Look-ahead pipeline around GetFrame (frame transport) -------------------------
+ * A host that knows which frames come next (a plugin that prefetches fi->child frames n+1..n+k, a batch tool)
+ * keeps up to `depth` frames in flight per instance: jinc_filter_submit enqueues H2D -> kernels -> D2H of one
+ * frame on its own stream and returns a ticket at once; jinc_filter_wait blocks until that frame's destination
+ * planes are complete.  src and dst must stay valid and untouched until the wait returns.  Frames are
+ * independent, so completion order does not matter for results.
+ * register_host_buffers != 0: every plane buffer seen is pinned with hipHostRegister (cached by address range,
+ * LRU of 64) so that the copies really are asynchronous and overlap; the caller then guarantees that such
+ * buffers stay allocated until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0).  With pageable
+ * buffers the pipeline still works but the copies serialise on the host.
+ * jinc_filter_get_frame == submit + wait on slot 0 (after draining frames still in flight). */
+JINC_API int jinc_filter_set_pipeline(jinc_filter *f, int depth, int register_host_buffers);
+JINC_API int jinc_filter_submit(jinc_filter *f, const void *const src[4], const int src_pitch[4], void *const dst[4],
+                                const int dst_pitch[4], long long *ticket);
+JINC_API int jinc_filter_wait(jinc_filter *f, long long ticket);
+
 /* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t; NULL is
  * the HIP null stream, i.e. ordered with the caller's default-stream work), for a batch of `nframes` independent frames (frames are the
  * sharding unit; no frame reads another).  Plane i of frame n starts at

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--threads", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--seconds", type=float, default=3.0)
+    ap.add_argument("--pipeline", type=int, nargs="*", default=[], help="also time ONE host thread with these pipeline depths")
     a = ap.parse_args()
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, _ = bench.CONFIGS[a.config]
@@ -57,6 +58,46 @@ def main():
         print(json.dumps({"config": a.config, "threads": nt, "frames_per_s": round(fps, 1),
                           "Mpix_per_s": round(fps * dw * dh / 1e6, 1),
                           "host_GB_per_s": round(fps * bench.algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh) / 1e9, 2)}))
+    for depth in a.pipeline:
+        for register in (False, True):
+            pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, a.seconds, a.config)
+
+
+def pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, seconds, config):
+    f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
+    f.set_pipeline(depth, register)
+    rng = np.random.default_rng(2)
+    nbuf = depth + 1
+    srcs, dsts = [], []
+    for _ in range(nbuf):
+        s = []
+        for (w, h) in fmt.plane_dims(sw, sh):
+            p = pkg.alloc_plane(w, h, fmt.dtype)
+            p[:] = (rng.random(p.shape) * (255 if fmt.sample_bytes == 1 else 1)).astype(fmt.dtype)
+            s.append(p)
+        srcs.append(s)
+        dsts.append([pkg.alloc_plane(w, h, fmt.dtype) for (w, h) in fmt.plane_dims(dw, dh)])
+    tickets = []
+    for k in range(nbuf):  # warm-up: allocations, registration
+        tickets.append(f.submit(srcs[k % nbuf], dsts[k % nbuf]))
+        if len(tickets) >= depth:
+            f.wait(tickets.pop(0))
+    while tickets:
+        f.wait(tickets.pop(0))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        tickets.append(f.submit(srcs[n % nbuf], dsts[n % nbuf]))
+        if len(tickets) >= depth:
+            f.wait(tickets.pop(0))
+        n += 1
+    while tickets:
+        f.wait(tickets.pop(0))
+    el = time.perf_counter() - t0
+    fps = n / el
+    print(json.dumps({"config": config, "threads": 1, "pipeline_depth": depth, "registered_host_buffers": register,
+                      "frames_per_s": round(fps, 1), "Mpix_per_s": round(fps * dw * dh / 1e6, 1),
+                      "host_GB_per_s": round(fps * bench.algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh) / 1e9, 2)}))
+    f.close()
 
 
 if __name__ == "__main__":

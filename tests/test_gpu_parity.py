@@ -370,3 +370,32 @@ def test_randomised_arguments(gpu_pkg, O, seed):
     got = f.get_frame(src)
     assert_planes_equal(got, want, f.out_dims(), what=f"seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}")
     f.close()
+
+
+@pytest.mark.parametrize("register", [False, True], ids=["pageable", "registered"])
+def test_frame_pipeline(gpu_pkg, O, register):
+    """Look-ahead pipeline: several frames in flight per instance, collected out of order; every frame must
+    equal the synchronous GetFrame result (and the oracle)."""
+    fmt, sw, sh, tw, th = "YUV420P8", 200, 120, 400, 240
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    f.set_pipeline(3, register)
+    n = 10
+    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=500 + k) for k in range(n)]
+    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
+    tickets = [None] * n
+    for k in range(n):
+        tickets[k] = f.submit(srcs[k], dsts[k])
+        if k >= 2:
+            f.wait(tickets[k - 2])
+    for k in (n - 1, n - 2):      # out of order on purpose
+        f.wait(tickets[k])
+    f.wait(tickets[0])            # waiting twice is harmless
+    for k in range(n):
+        assert_planes_equal(dsts[k], of.get_frame(srcs[k], threads=2), f.out_dims(), what=f"frame {k}")
+    # the synchronous entry point still works afterwards and drains the pipeline first
+    t = f.submit(srcs[0], dsts[0])
+    got = f.get_frame(srcs[1])
+    assert_planes_equal(got, of.get_frame(srcs[1]), f.out_dims())
+    f.wait(t)
+    f.close()
