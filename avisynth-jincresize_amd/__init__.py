@@ -73,7 +73,7 @@ ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_hei
             "quant_y": 1 << 5, "tap": 1 << 6, "blur": 1 << 7, "cplace": 1 << 8, "threads": 1 << 9, "opt": 1 << 10,
             "initial_capacity": 1 << 11, "initial_factor": 1 << 12}
 
-EXPORTS = ["jinc_device_count", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
+EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode",

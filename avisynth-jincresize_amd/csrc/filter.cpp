@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstring>
 #include <memory>
@@ -666,6 +667,13 @@ int jinc_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) return 0;
     return count;
+}
+
+int jinc_pick_device(void) {
+    static std::atomic<unsigned> counter{0};
+    const int n = jinc_device_count();
+    if (n <= 0) return -1;
+    return static_cast<int>(counter.fetch_add(1) % static_cast<unsigned>(n));
 }
 
 const char* jinc_last_error(void) { return g_last_error.c_str(); }

@@ -117,6 +117,12 @@ typedef struct jinc_filter jinc_filter;
 /* Number of usable HIP devices (0 when there is none); replaces nothing, used to shard frames. */
 JINC_API int jinc_device_count(void);
 
+/* Round-robin device index for hosts that create one filter instance per worker thread (AviSynth Prefetch(N),
+ * MT_MULTI_INSTANCE, ref :649-652): successive calls return 0, 1, ..., jinc_device_count()-1, 0, ... so that the
+ * instances -- and with them the frames, which are independent units -- spread over the GPUs of the node with no
+ * data exchanged between devices.  Returns -1 when there is no device. */
+JINC_API int jinc_pick_device(void);
+
 /* Message of the last failure on the calling thread ("" if none). */
 JINC_API const char *jinc_last_error(void);
 

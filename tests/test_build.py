@@ -24,6 +24,8 @@ def test_library_exports_every_declared_symbol(pkg):
 def test_library_loads_without_gpu_and_reports_devices(pkg):
     n = pkg.device_count()  # hipGetDeviceCount: 0 on the CPU box, no crash
     assert n >= 0
+    picks = [pkg.lib().jinc_pick_device() for _ in range(5)]
+    assert picks == ([-1] * 5 if n == 0 else [k % n for k in range(picks[0], picks[0] + 5)])
 
 
 def test_no_fused_multiply_add_in_device_code(pkg):
