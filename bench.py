@@ -238,7 +238,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get(args.config, {})
+                if "hbm_bytes_per_launch" in rec:  # PMC figure, scaled to this run's frames per launch
+                    traffic = int(rec["hbm_bytes_per_launch"] * B / rec.get("frames_per_launch", B))
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
