@@ -559,6 +559,10 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         DeviceTable& t = f.tables[f.table_of_plane(i)];
         if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
         if (src_pitch[i] % sb || dst_pitch[i] % sb) throw ArgError("JincResize: plane pitch is not a multiple of the sample size.");
+        if (reinterpret_cast<uintptr_t>(src[i]) % sb || reinterpret_cast<uintptr_t>(dst[i]) % sb)
+            throw ArgError("JincResize: plane pointer is not aligned to the sample size.");
+        if (src_fs && nframes > 1 && src_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
+        if (dst_fs && nframes > 1 && dst_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
         if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(t.plan.src_w) * sb ||
             static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(t.plan.dst_w) * sb)
             throw ArgError("JincResize: plane pitch is smaller than the row size.");

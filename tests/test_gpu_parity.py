@@ -399,3 +399,20 @@ def test_frame_pipeline(gpu_pkg, O, register):
     assert_planes_equal(got, of.get_frame(srcs[1]), f.out_dims())
     f.wait(t)
     f.close()
+
+
+def test_device_entry_rejects_bad_layouts(gpu_pkg):
+    """Misaligned pointers / pitches are refused with a message instead of faulting on the device."""
+    torch = pytest.importorskip("torch")
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS["Y16"], 64, 48, 128, 96, device=0)
+    src = torch.zeros((48, 64), dtype=torch.int16, device="cuda")
+    dst = torch.zeros((96, 128), dtype=torch.int16, device="cuda")
+    ok = dict(src_ptrs=[src.data_ptr()], src_pitches=[128], src_strides=[0], dst_ptrs=[dst.data_ptr()], dst_pitches=[256],
+              dst_strides=[0], nframes=1)
+    f.process_device(**ok)
+    for bad in (dict(src_ptrs=[src.data_ptr() + 1]), dict(dst_pitches=[255]), dict(src_pitches=[126]), dict(nframes=0),
+                dict(dst_ptrs=[0])):
+        with pytest.raises(gpu_pkg.JincError):
+            f.process_device(**{**ok, **bad})
+    torch.cuda.synchronize()
+    f.close()
