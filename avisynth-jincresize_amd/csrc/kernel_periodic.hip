@@ -422,7 +422,7 @@ int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStr
     if (variant == 3 && fs == 7) return launch_periodic_pk_t<T, 7, 4>(pa, io, stream);
     if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
     if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);
-    if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 3>(pa, io, stream);
+    if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 9>(pa, io, stream);
     if (variant == 1) {
         if (fs == 7) return launch_rows_t<T, 7>(pa, io, stream);
         if (fs == 9) return launch_rows_t<T, 9>(pa, io, stream);

@@ -40,6 +40,7 @@ CONFIGS = {
     "C3": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=8, cplace="mpeg2"), 16),
     "C4": ("RGBPS", 3840, 2160, 7680, 4320, dict(tap=4, blur=0.98), 8),
     # not a BASELINE.json config: a non-periodic ratio (1.5x, float drift => gather kernel for every pixel)
+    "C1": ("Y8", 640, 360, 1280, 720, dict(tap=3), 256),     # BASELINE configs[0] shape (the reference's CPU case), on the GPU
     "N15": ("Y8", 1280, 720, 1920, 1080, dict(tap=3), 64),
     "D23": ("Y8", 1920, 1080, 1280, 720, dict(tap=3), 64),   # 2/3 down-scale: fs = 10, period 2, source step 3
     "N3": ("Y8", 1280, 720, 3840, 2160, dict(tap=3), 64),     # 3x: drifting phases, quasi-periodic kernel
