@@ -25,11 +25,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libjincresize_hip.so")
-ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_periodic", "kernel_quasi_fs7", "kernel_quasi_fs9")]
+ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_periodic", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
+                       "kernel_quasi_exact_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
 
 
-def build(jobs: int = 4) -> str:
+def build(jobs: int = 6) -> str:
     """Compile the HIP/C++ library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     r = subprocess.run(["make", "-C", _HERE, f"-j{jobs}"], capture_output=True, text=True)
     if r.returncode != 0:

@@ -442,6 +442,7 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     qa.n_col_classes = p.n_col_classes;
     qa.n_row_classes = p.n_row_classes;
     qa.px = px, qa.py = py, qa.sx = sx, qa.sy = sy;
+    qa.exact = p.periodic ? 1 : 0;
     qa.ix0 = p.ix0, qa.iy0 = p.iy0;
     qa.ni = (p.ix1 - p.ix0) / px;
     qa.nj = (p.iy1 - p.iy0) / py;
@@ -459,6 +460,11 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     }
     qa.min_sx = min_sx, qa.min_sy = min_sy;
     qa.src_w = p.g.src_w, qa.src_h = p.g.src_h, qa.dst_h = p.g.dst_h;
+    if (qa.exact)
+        for (int q = 0; q < py; ++q)
+            for (int r = 0; r < px; ++r)
+                qa.phase_set[q * px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
+                                                          p.col_class[p.ix0 + r]];
     if (!jinc::quasi_configure(qa, p.fs, max_sx - min_sx, max_sy - min_sy)) return;
     t.quasi = qa;
     t.use_quasi = true;
@@ -539,9 +545,11 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
     // kernel wherever it applies (also for exactly periodic plans)
     auto wants_quasi = [&](const DeviceTable& t) {
-        return t.use_quasi && (f.kernel_mode == 7 || (f.kernel_mode != 1 && !t.use_periodic));
+        return t.use_quasi && (f.kernel_mode == 7 || f.kernel_mode == 8 || (f.kernel_mode != 1 && !t.use_periodic));
     };
-    auto wants_periodic = [&](const DeviceTable& t) { return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7; };
+    auto wants_periodic = [&](const DeviceTable& t) {
+        return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8;
+    };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
@@ -598,8 +606,11 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
             if (quasi)
-                timed(f.ev_periodic, stream, "quasi-periodic kernel launch",
-                      [&](hipStream_t s) { return jinc::launch_quasi(t.quasi, t.plan.fs, io, s); });
+                timed(f.ev_periodic, stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
+                    jinc::QuasiArgs qa = t.quasi;
+                    if (f.kernel_mode == 8) qa.exact = 0;  // A/B: per-row lookup variant on an exactly periodic plan
+                    return jinc::launch_quasi(qa, t.plan.fs, io, s);
+                });
             else
                 timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
                     return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode >= 3 ? f.kernel_mode - 2 : 0);
@@ -956,7 +967,7 @@ int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, fl
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 7) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 8) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

@@ -75,8 +75,19 @@ struct QuasiArgs {
     int lds_plane = 0;                              // words per column plane (sx planes per tile row)
     int rg = 1;                                     // row groups (of fs output rows) per tile
     int nwaves = 4;                                 // waves per workgroup (divides px*py evenly where possible)
+    int exact = 0;                                  // plan is exactly periodic: one set per phase, no per-row lookup
+    int phase_set[256] = {0};                       // exact plans: set id of phase q*px + p
     int src_w = 0, src_h = 0, dst_h = 0;
 };
+
+// LDS row layout of the quasi-periodic kernel, a compile-time function of (filter size, source step) so that every
+// LDS offset of its inner loop is an immediate: sx column planes of quasi_plane_words() words each.
+constexpr int quasi_tile_cols(int fs, int sx) { return sx * 64 + fs + sx; }  // 64 lanes + window + phase spread <= sx
+constexpr int quasi_plane_words(int fs, int sx) {
+    const int w = (quasi_tile_cols(fs, sx) + sx - 1) / sx + 1;
+    return (sx == 2 || sx == 4) ? ((w + 15) / 32) * 32 + (sx == 2 ? 16 : 8) : w;  // even steps: planes on distinct banks
+}
+constexpr int quasi_pitch_words(int fs, int sx) { return sx * quasi_plane_words(fs, sx); }
 
 bool quasi_supported(int fs, int px, int py, int sx, int sy, int n_col_classes, int n_row_classes);
 // Fills the tile geometry fields (lds_*, rg, nwaves) of `args`; returns false if no configuration fits.

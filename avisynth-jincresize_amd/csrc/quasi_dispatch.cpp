@@ -8,6 +8,8 @@ namespace jinc {
 
 int launch_quasi_fs7(const QuasiArgs& args, const PlaneIO& io, void* stream);  // kernel_quasi_fs7.hip
 int launch_quasi_fs9(const QuasiArgs& args, const PlaneIO& io, void* stream);  // kernel_quasi_fs9.hip
+int launch_quasi_exact_fs7(const QuasiArgs& args, const PlaneIO& io, void* stream);  // kernel_quasi_exact_fs7.hip
+int launch_quasi_exact_fs9(const QuasiArgs& args, const PlaneIO& io, void* stream);  // kernel_quasi_exact_fs9.hip
 
 bool quasi_supported(int fs, int px, int py, int sx, int sy, int n_col_classes, int n_row_classes) {
     if (fs != 7 && fs != 9) return false;                                  // register window; taps 3 and 4
@@ -19,10 +21,10 @@ bool quasi_supported(int fs, int px, int py, int sx, int sy, int n_col_classes, 
 bool quasi_configure(QuasiArgs& a, int fs, int spread_x, int spread_y) {
     const int nphase = a.px * a.py;
     a.nwaves = nphase % 4 == 0 ? 4 : (nphase % 3 == 0 ? 3 : (nphase % 2 == 0 ? 2 : (nphase >= 4 ? 4 : nphase)));
+    if (spread_x > a.sx) return false;  // the compile-time tile width allows a phase spread of one source step
     a.lds_cols = a.sx * 64 + fs + spread_x;
-    a.lds_plane = (a.lds_cols + a.sx - 1) / a.sx + 1;
-    if (a.sx == 2 || a.sx == 4) a.lds_plane = ((a.lds_plane + 15) / 32) * 32 + (a.sx == 2 ? 16 : 8);  // planes on distinct banks
-    a.lds_pitch = a.sx * a.lds_plane;
+    a.lds_plane = quasi_plane_words(fs, a.sx);
+    a.lds_pitch = quasi_pitch_words(fs, a.sx);
     size_t budget = 20 * 1024;  // A/B on 1.5x: 20 KB 180 Gpix/s, 30 KB 160, 40 KB 134 (occupancy beats tile size)
     if (const char* e = std::getenv("JINC_QUASI_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
     for (int rg = 8; rg >= 1; --rg) {
@@ -41,8 +43,8 @@ bool quasi_configure(QuasiArgs& a, int fs, int spread_x, int spread_y) {
 int launch_quasi(const QuasiArgs& args, int fs, const PlaneIO& io, void* stream) {
     if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
     switch (fs) {
-        case 7: return launch_quasi_fs7(args, io, stream);
-        case 9: return launch_quasi_fs9(args, io, stream);
+        case 7: return args.exact ? launch_quasi_exact_fs7(args, io, stream) : launch_quasi_fs7(args, io, stream);
+        case 9: return args.exact ? launch_quasi_exact_fs9(args, io, stream) : launch_quasi_fs9(args, io, stream);
         default: return 1;  // hipErrorInvalidValue
     }
 }
