@@ -249,11 +249,11 @@ def main():
             else f"Mpix/s ({args.config})",
             "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {1: "u8", 2: "u16", 4: "f32"}[sb] + "->f32 accumulate",
+            "vs_baseline": None, "dtype": "f32",  # arithmetic type of the path (un-fused fp32 accumulate over u8/u16/f32 samples)
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {sw}x{sh}->{dw}x{dh} {fmt_name} tap={kw['tap']}"
                                    + (f" blur={kw['blur']}" if 'blur' in kw else ""),
-                       "frames_per_step_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "sample_type": {1: "u8", 2: "u16", 4: "f32"}[sb], "frames_per_step_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "kernel": dom_name, "filter_size": fs, "plan_sets": info.num_sets,
                        "plan_bytes": int(info.plan_bytes)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
