@@ -232,6 +232,7 @@ def main():
         bytes_frame = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
         fs = info.filter_size
         samples_frame = sum(w * h for (w, h) in ddims)
+        src_bytes_frame = sum(w * h for (w, h) in fmt.plane_dims(sw, sh)) * sb
         n_planes = fmt.planes
         if per_n > 0:
             dom_name, dom_ms, dom_n = "ewa_periodic_kernel", per_ms, per_n
@@ -271,6 +272,8 @@ def main():
                          "binding_roof": "un-fused fp32 VALU (v_mul_f32+v_add_f32 per tap; FMA/MFMA would break bit-exactness)",
                          "valu_achieved_Tops": round(valu_ops / 1e12, 2), "valu_peak_Tops": VALU_UNFUSED_PEAK / 1e12,
                          "valu_frac": round(valu_ops / VALU_UNFUSED_PEAK, 4),
+                         # the north_star's "HBM-read" reading: source bytes only (each source sample once)
+                         "hbm_read_frac": round(src_bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "border_kernel_ms_per_step": round(gat_ms / args.steps, 4) if per_n > 0 else None},
         }
         if world == 1 and not args.no_cpu_baseline:
