@@ -117,3 +117,12 @@ def test_quasi_periodic_structure(pkg, sw, sh, tw, th, exact, q):
                                 (sy, info.interior_y0, info.interior_y1, q[1], q[3])):
         seg = start[a0:a1]
         assert np.all(seg[P:] - seg[:-P] == S)
+
+
+def test_create_on_missing_device_fails_loudly(pkg):
+    """Without a usable HIP device the filter cannot be created for frame work (no silent CPU fallback)."""
+    n = pkg.device_count()
+    with pytest.raises(pkg.JincError) as e:
+        pkg.Filter(pkg.FORMATS["Y8"], 64, 48, 128, 96, device=n + 3)   # never a valid index
+    assert e.value.code in (-2, -3)
+    assert "HIP" in str(e.value) or "device" in str(e.value)
