@@ -416,3 +416,19 @@ def test_device_entry_rejects_bad_layouts(gpu_pkg):
             f.process_device(**{**ok, **bad})
     torch.cuda.synchronize()
     f.close()
+
+
+@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 7, 8],
+                         ids=["gather", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_lookup"])
+def test_every_kernel_reproduces_the_reference_crc_at_full_size(gpu_pkg, O, mode):
+    """C2 at full size through every kernel family: the crc32 of the reference's own opt=0 output."""
+    k = next(x for x in KAT["outputs"] if x["name"] == "C2")
+    src = O.lcg_frame(O.FORMATS[k["format"]], *k["src"])
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[k["format"]], k["src"][0], k["src"][1], k["dst"][0], k["dst"][1], device=0, **k["args"])
+    f.set_kernel_mode(mode)
+    got = f.get_frame(src)
+    crc = 0
+    for p, (w, h) in zip(got, f.out_dims()):
+        crc = zlib.crc32(np.ascontiguousarray(p[:h, :w]).tobytes(), crc)
+    assert f"{crc & 0xFFFFFFFF:08x}" == k["crc32"]
+    f.close()
