@@ -44,6 +44,7 @@ CONFIGS = {
     "N15": ("Y8", 1280, 720, 1920, 1080, dict(tap=3), 64),
     "D23": ("Y8", 1920, 1080, 1280, 720, dict(tap=3), 64),   # 2/3 down-scale: fs = 10, period 2, source step 3
     "N3": ("Y8", 1280, 720, 3840, 2160, dict(tap=3), 64),     # 3x: drifting phases, quasi-periodic kernel
+    "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 16),  # 1.5x with Jinc256: fs 17, drifting -> gather kernel
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 64),   # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 32),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables
 }
