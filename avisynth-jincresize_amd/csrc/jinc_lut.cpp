@@ -101,8 +101,14 @@ double jinc_large_arg(double x2) {
     const double y2 = M_PI * M_PI * x2;
     const double xp = std::sqrt(y2);
     const double inv = 64.0 / y2;
-    const double s = std::sin(xp);
-    const double c = std::cos(xp);
+    // glibc's sin() and sincos() differ by one ulp at some arguments, and GCC at -O2 and above merges the
+    // reference's sin(xp)/cos(xp) pair into one sincos() call (clang does not).  The reference's CMake Release build
+    // with GCC is the parity target, so sincos() is called explicitly (through a volatile pointer: GCC -O0 lowers the
+    // builtin back into sin() + cos()): the table no longer depends on the compiler that builds this file
+    // (DESIGN.md section 2).
+    void (*volatile glibc_sincos)(double, double*, double*) = ::sincos;
+    double s, c;
+    glibc_sincos(xp, &s, &c);
     const double amp = std::sqrt(xp / M_PI) * 2.0 / y2;
     const double rc = ratio_of_polys(pc, qc, inv);
     const double rs = ratio_of_polys(ps, qs, inv);

@@ -11,6 +11,7 @@
  * through oracle_cyl_bessel_j1() in bessel_shim.cpp -- the same library routine the reference
  * binds -- and pinned by the tap 5/6/7/8/12/16 LUT hashes of SURVEY.md 7.3 item 5.
  */
+#define _GNU_SOURCE /* sincos() */
 #include "jinc_oracle.h"
 
 #include <math.h>
@@ -100,8 +101,13 @@ static double jinc_sqr_asymptotic(double x2)
     const double y2 = M_PI * M_PI * x2;
     const double xp = sqrt(y2);
     const double y2p = 64.0 / y2;
-    const double sx = sin(xp);
-    const double cx = cos(xp);
+    /* GCC -O2/-O3 (the reference's CMake Release build) merges sin(xp) and cos(xp) into one sincos() call, whose
+       glibc result differs from sin()/cos() by one ulp at some arguments; call it explicitly, and through a volatile
+       pointer because GCC -O0 lowers the sincos builtin back into sin() + cos(), so that the oracle does not depend on
+       its own optimisation level. */
+    void (*volatile glibc_sincos)(double, double *, double *) = sincos;
+    double sx, cx;
+    glibc_sincos(xp, &sx, &cx);
     const double rc = eval_rational(PC, QC, y2p, 7);
     const double rs = eval_rational(PS, QS, y2p, 7);
     return (sqrt(xp / M_PI) * 2.0 / y2) * (rc * (sx - cx) + (8.0 / xp) * rs * (sx + cx));

@@ -126,3 +126,44 @@ def test_create_on_missing_device_fails_loudly(pkg):
         pkg.Filter(pkg.FORMATS["Y8"], 64, 48, 128, 96, device=n + 3)   # never a valid index
     assert e.value.code in (-2, -3)
     assert "HIP" in str(e.value) or "device" in str(e.value)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_plan_matches_reference_tables_random_geometry(pkg, O, seed):
+    """Seeded random geometry (sizes, ratios incl. down-scales, taps 1..16, quantisation, blur, crops, formats):
+    the compact plan expands to the oracle's reference-layout tables bit for bit."""
+    rng = np.random.default_rng(7000 + seed)
+    fmt = ["Y8", "YUV420P8", "YUV422P16", "YUV411P8", "RGBPS"][rng.integers(5)]
+    sw = int(rng.integers(48, 200)) & ~3
+    sh = int(rng.integers(48, 160)) & ~1
+    tw = max(16, int(sw * rng.uniform(0.4, 3.5)) & ~3)
+    th = max(16, int(sh * rng.uniform(0.4, 3.5)) & ~1)
+    kw = dict(tap=int(rng.integers(1, 17)))
+    if rng.random() < 0.5:
+        kw.update(quant_x=int(rng.integers(1, 257)), quant_y=int(rng.integers(1, 257)))
+    if rng.random() < 0.5:
+        kw["blur"] = float(np.round(rng.uniform(0.7, 1.3), 3))
+    if rng.random() < 0.5:
+        kw.update(src_left=float(np.round(rng.uniform(-4, 8), 3)), src_top=float(np.round(rng.uniform(-4, 8), 3)),
+                  src_width=float(np.round(sw - rng.uniform(0, 12), 3)), src_height=float(np.round(sh - rng.uniform(0, 12), 3)))
+    if fmt == "YUV420P8":
+        kw["cplace"] = ["mpeg2", "mpeg1", "topleft"][rng.integers(3)]
+    try:
+        _compare(pkg, O, fmt, sw, sh, tw, th, kw)
+    except pkg.JincError as e:
+        assert "smaller than the filter footprint" in str(e)   # heavy down-scale with many taps: reference UB
+
+
+def test_lut_matches_oracle_over_taps_and_blurs(pkg, O):
+    """The 1024-entry double LUT (ref JincResize.cpp:255-275) of product and oracle, every tap 1..16 x 25 blurs:
+    covers the Taylor, libstdc++ cyl_bessel_j and asymptotic branches on many arguments.  (The asymptotic branch
+    is where sin()/cos() vs sincos() differ by an ulp in glibc -- both sides call sincos(), like the reference's
+    GCC Release build does after optimisation)"""
+    blurs = [1.0] + [float(b) for b in np.round(np.linspace(0.55, 1.45, 24), 3)]
+    for tap in range(1, 17):
+        for blur in blurs:
+            f = pkg.Filter(pkg.FORMATS["Y8"], 256, 256, 512, 512, device=-1, tap=tap, blur=blur)
+            a = f.lut()
+            f.close()
+            b = O.make_lut(tap, blur)
+            assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (tap, blur)
