@@ -55,6 +55,9 @@ struct DeviceTable {
     bool use_quasi = false;  // quasi-periodic interior kernel (affine window origins, drifting classes)
     jinc::QuasiArgs quasi;
     jinc::RectList border_rects;  // gather work when the periodic kernel covers the interior
+    bool use_direct = false;      // exactly periodic, any filter size / source step (kernel_direct.hip)
+    jinc::DirectArgs direct;
+    jinc::RectList direct_border_rects;
     jinc::RectList whole;         // gather work when it does not
 };
 
@@ -327,7 +330,7 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
             std::memcpy(&padded[(static_cast<size_t>(s) * p.fs + ly) * fsp], p.set_ptr(s) + static_cast<size_t>(ly) * p.fs,
                         sizeof(float) * p.fs);
     const size_t i_co = add(padded.data(), padded.size() * 4);
-    t.bytes = align_up(off, 256);
+    t.bytes = align_up(off, 256) + 256;  // slack: kernel_direct.hip fetches whole coefficient blocks (<= 16 floats)
     hip_check(hipMalloc(&t.blob, t.bytes), "hipMalloc(plan)");
     char* base = static_cast<char*>(t.blob);
     for (const Piece& pc : pieces)
@@ -474,6 +477,40 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     }
 }
 
+// Exactly periodic plans the register/LDS kernels do not cover (down-scales, taps > 8): kernel_direct.hip.
+void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
+    t.use_direct = false;
+    if (!p.periodic || !jinc::direct_supported(p.fs, p.px, p.py, p.sx, p.sy)) return;
+    jinc::DirectArgs da;
+    da.coeffs = t.plan.coeffs;
+    da.fs = p.fs;
+    da.coeff_row = (p.fs + 3) & ~3;
+    da.px = p.px, da.py = p.py, da.sx = p.sx, da.sy = p.sy;
+    da.ix0 = p.ix0, da.iy0 = p.iy0;
+    da.ni = (p.ix1 - p.ix0) / p.px;
+    da.nj = (p.iy1 - p.iy0) / p.py;
+    int max_sy = INT32_MIN;
+    for (int k = 0; k < p.px; ++k) da.start_x[k] = p.col_start[p.ix0 + k];
+    for (int k = 0; k < p.py; ++k) {
+        da.start_y[k] = p.row_start[p.iy0 + k];
+        max_sy = std::max(max_sy, da.start_y[k]);
+    }
+    // The kernel fetches whole 4-column segments with 16-byte loads, up to kDirectOverreadBytes past the last
+    // sample it uses.  Keeping its windows out of the LAST source row keeps every such fetch inside the plane
+    // (enqueue() checks that the pitch is at least that large); the rows given up here join the border frame.
+    da.row_clamp = p.g.src_h - 2;
+    while (da.nj > 0 && max_sy + p.sy * (da.nj - 1) + p.fs - 1 > da.row_clamp) --da.nj;
+    if (da.ni < 1 || da.nj < 1 || da.row_clamp < 0) return;
+    for (int q = 0; q < p.py; ++q)
+        for (int r = 0; r < p.px; ++r)
+            da.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
+                                                  p.col_class[p.ix0 + r]];
+    da.dst_h = p.g.dst_h;
+    t.direct = da;
+    t.use_direct = true;
+    t.direct_border_rects = border_frame(p, p.ix0 + p.px * da.ni, p.iy0 + p.py * da.nj);
+}
+
 void init_device(jinc_filter& f, int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -490,6 +527,7 @@ void init_device(jinc_filter& f, int device) {
         upload_table(f.plans[i], f.tables[i], f.stream);
         plan_launches(f.plans[i], f.tables[i]);
         plan_quasi(f.plans[i], f.tables[i]);
+        plan_direct(f.plans[i], f.tables[i]);
     }
 }
 
@@ -550,10 +588,16 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     auto wants_periodic = [&](const DeviceTable& t) {
         return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8;
     };
+    // kernel_mode 9: the direct kernel wherever it applies; otherwise it takes the exactly periodic plans the
+    // register/LDS kernels do not cover.  Its 16-byte fetches need a pitch of at least kDirectOverreadBytes.
+    auto wants_direct = [&](const DeviceTable& t, int pitch) {
+        if (!t.use_direct || pitch < jinc::kDirectOverreadBytes || f.kernel_mode == 1) return false;
+        return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
+    };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        any_periodic |= wants_periodic(t) || wants_quasi(t);
+        any_periodic |= wants_periodic(t) || wants_quasi(t) || wants_direct(t, src_pitch[i]);
     }
     // A/B on MI355X: overlapping wins 12 % on C3 (fs 17) and 2-3 % on C4 (fs 9), loses 4 % on C2 (fs 7).
     const bool want_overlap = f.overlap_border < 0 ? f.plans[0].fs >= 9 : f.overlap_border != 0;
@@ -586,8 +630,9 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         io.nframes = nframes;
         io.sample_bytes = sb;
         io.peak = f.peak;
-        const bool quasi = wants_quasi(t);
-        const bool periodic = !quasi && wants_periodic(t);
+        const bool direct = wants_direct(t, src_pitch[i]);
+        const bool quasi = !direct && wants_quasi(t);
+        const bool periodic = !direct && !quasi && wants_periodic(t);
         auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
             EventPair ev;
             if (f.profiling) {
@@ -601,7 +646,13 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 sink.push_back(ev);
             }
         };
-        if (periodic || quasi) {
+        if (direct) {
+            if (t.direct_border_rects.n > 0)
+                timed(f.ev_gather, border_stream, "border kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.direct_border_rects, s); });
+            timed(f.ev_periodic, stream, "direct periodic kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_direct(t.direct, io, s); });
+        } else if (periodic || quasi) {
             if (t.border_rects.n > 0)
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
@@ -967,7 +1018,7 @@ int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, fl
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 8) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 9) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

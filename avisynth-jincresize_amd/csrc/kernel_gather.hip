@@ -24,6 +24,36 @@ struct GatherArgs {
 
 constexpr int kGatherLdsFloats = 6144;  // 24 KB source tile per block
 
+// One sequential chain of fs x fs taps with a run-time filter size: samples from the LDS tile (STAGED) or from
+// memory, coefficients through `c` (wave-uniform constant-address-space pointer -> scalar loads into SGPRs, or a
+// per-lane pointer), eight per step; rows are padded to a multiple of 4 floats and the allocation has slack, so a
+// whole step may always be fetched.  Taps are visited in (ly, lx) raster order.
+template <typename T, bool STAGED, typename CoeffPtr>
+__device__ __forceinline__ float chain_runtime(float acc, const float* s_lds, int lds_pitch, const char* s_glb, int src_pitch,
+                                               CoeffPtr c, int fs, int fsp) {
+    for (int ly = 0; ly < fs; ++ly) {
+        const T* g = reinterpret_cast<const T*>(s_glb);
+        for (int lx = 0; lx < fs; lx += 8) {
+            float cf[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cf[t] = c[lx + t];
+            const int n = fs - lx;  // wave-uniform
+            if (n >= 8) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc = acc + (STAGED ? s_lds[lx + t] : to_float(g[lx + t])) * cf[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 7; ++t)
+                    if (t < n) acc = acc + (STAGED ? s_lds[lx + t] : to_float(g[lx + t])) * cf[t];
+            }
+        }
+        s_lds += lds_pitch;
+        s_glb += src_pitch;
+        c += fsp;
+    }
+    return acc;
+}
+
 // Any plan.  A block covers 64*P coordinates along the lane axis x 4..32 lines; its source footprint is
 // staged once in LDS as fp32.  Work items = (line, residue): the 64 lanes of an item are P apart, P
 // being the plan's dominant phase period, so that (nearly) all lanes of an item share one coefficient
@@ -161,24 +191,31 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
             }
         }
         if (FS == 0 || !staged) {
-            // Fallback: run-time filter size (even sizes of down-scales, fs > 17) or a source footprint
-            // larger than the LDS tile: per-lane loads through L1/L2.
-            const float* c = p.coeffs + static_cast<size_t>(set) * fs * fsp;
-            if (staged) {
-                const float* s = tile + (sy - ty0) * pitch + (sx - tx0);
-                for (int ly = 0; ly < fs; ++ly) {
-                    for (int lx = 0; lx < fs; ++lx) acc = acc + s[lx] * c[lx];
-                    s += pitch;
-                    c += fsp;
+            // Run-time filter size (fs > 17: taps 9..16, strong down-scales) or a source footprint larger than the
+            // LDS tile (samples then come through L1/L2): the same waterfall over the distinct coefficient sets of
+            // the item, coefficients in SGPRs eight at a time.
+            const float* s_lds = tile + (sy - ty0) * pitch + (sx - tx0);
+            const char* s_glb = sframe + static_cast<size_t>(sy) * a.io.src_pitch + static_cast<size_t>(sx) * sizeof(T);
+            unsigned long long todo = __ballot(active);
+            for (int pass = 0; todo && pass < a.max_passes; ++pass) {
+                const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+                const int u = __builtin_amdgcn_readlane(set, leader);
+                const bool mine = active && set == u;
+                const JINC_CONSTANT float* cs = (const JINC_CONSTANT float*)(p.coeffs + static_cast<size_t>(u) * fs * fsp);
+                if (mine) {
+                    if (staged)
+                        acc = chain_runtime<T, true>(acc, s_lds, pitch, s_glb, a.io.src_pitch, cs, fs, fsp);
+                    else
+                        acc = chain_runtime<T, false>(acc, s_lds, pitch, s_glb, a.io.src_pitch, cs, fs, fsp);
                 }
-            } else {
-                const char* srow = sframe + static_cast<size_t>(sy) * a.io.src_pitch + static_cast<size_t>(sx) * sizeof(T);
-                for (int ly = 0; ly < fs; ++ly) {
-                    const T* s = reinterpret_cast<const T*>(srow);
-                    for (int lx = 0; lx < fs; ++lx) acc = acc + to_float(s[lx]) * c[lx];
-                    srow += a.io.src_pitch;
-                    c += fsp;
-                }
+                todo &= ~__ballot(mine);
+            }
+            if (active && ((todo >> lane) & 1ull)) {  // private sets: per-lane coefficient loads
+                const float* c = p.coeffs + static_cast<size_t>(set) * fs * fsp;
+                if (staged)
+                    acc = chain_runtime<T, true>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
+                else
+                    acc = chain_runtime<T, false>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
             }
         }
         if (active) {
@@ -260,8 +297,9 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
         ga.stride[r] = 1;
         ga.lines[r] = 4;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
-            // Narrow rectangles (border columns) put the lanes along y so that a wave is not mostly idle.
-            const int axis = rects.w[r] < 32 && rects.h[r] > rects.w[r] ? 1 : 0;
+            // Narrow rectangles (border columns, up to ~fs wide) put the lanes along y: a wave is then not mostly
+            // idle, and its lanes share the border column's coefficient sets (along x every lane would own one).
+            const int axis = rects.w[r] < 64 && rects.h[r] > rects.w[r] ? 1 : 0;
             const int P = axis == 0 ? plan.gather_period_x : plan.gather_period_y;
             const int along = axis == 0 ? rects.w[r] : rects.h[r];
             const int across = axis == 0 ? rects.h[r] : rects.w[r];

@@ -94,6 +94,25 @@ bool quasi_supported(int fs, int px, int py, int sx, int sy, int n_col_classes, 
 bool quasi_configure(QuasiArgs& args, int fs, int spread_x, int spread_y);
 int launch_quasi(const QuasiArgs& args, int fs, const PlaneIO& io, void* stream);
 
+// Exactly periodic interior of any filter size and source step 1..4 (kernel_direct.hip): output pixel
+// (ix0 + px*i + p, iy0 + py*j + q) reads the source window at (start_x[p] + sx*i, start_y[q] + sy*j) with
+// coefficient set set[q*px + p]; no LDS, row segments are read from memory in the source format.
+struct DirectArgs {
+    const float* coeffs = nullptr;
+    int fs = 0, coeff_row = 0;   // filter size; floats per coefficient row on the device (padded_row(fs))
+    int px = 1, py = 1, sx = 1, sy = 1;
+    int ix0 = 0, iy0 = 0, ni = 0, nj = 0;
+    int start_x[16] = {0}, start_y[16] = {0};
+    int set[256] = {0};
+    int row_clamp = 0;           // src_h - 2: no segment starts in the last source row (see filter.cpp plan_direct)
+    int dst_h = 0;
+};
+// Segments may be fetched up to this many bytes past their last used sample (whole K-column segments of partially
+// valid lanes + load granularity); the host keeps them inside the plane (min pitch, last source row excluded).
+constexpr int kDirectOverreadBytes = 128;
+bool direct_supported(int fs, int px, int py, int sx, int sy);
+int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream);
+
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);
 

@@ -47,6 +47,10 @@ CONFIGS = {
     "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 16),  # 1.5x with Jinc256: fs 17, drifting -> gather kernel
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 64),   # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 32),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables
+    "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 32),   # 1/2 down-scale: fs = 13, period 1, source step 2
+    "D13": ("Y8", 3840, 2160, 1280, 720, dict(tap=3), 32),    # 1/3 down-scale: fs = 20, period 1, source step 3
+    "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 16),    # Jinc144: fs = 13
+    "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 4),   # tap 16: fs = 33 (1089 taps)
 }
 
 
@@ -178,6 +182,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
+    ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
     args = ap.parse_args()
 
     import torch
@@ -205,6 +210,8 @@ def main():
     B = args.frames or default_frames
     flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, local_rank, 12345 + rank * B)
     flt.set_kernel_mode(args.kernel_mode)
+    if args.border_overlap >= 0:
+        flt.set_border_overlap(bool(args.border_overlap))
     info = flt.plan_info(0)
     sb = fmt.sample_bytes
 

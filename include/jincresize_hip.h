@@ -219,7 +219,9 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
 /* Kernel selection override for tests/benchmarks: 0 = automatic, 1 = force the generic gather
  * kernel for every pixel, 2 = periodic fast kernel where the plan allows (same as automatic),
  * 3..6 = A/B variants of the periodic kernels (row-streamed, other tile heights, packed math),
- * 7 = the quasi-periodic kernel wherever it applies (it is the automatic choice only for drifting ratios). */
+ * 7 = the quasi-periodic kernel wherever it applies (it is the automatic choice only for drifting ratios),
+ * 8 = its per-row lookup variant on exactly periodic plans too, 9 = the direct (no-LDS) periodic kernel wherever
+ * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* 1: the border gather kernel runs on a side stream concurrently with the periodic interior kernel
  * (fork/join by events around every call); 0: both on the caller's stream, back to back;

@@ -268,7 +268,7 @@ def test_integer_conversion_ties(gpu_pkg):
     assert np.array_equal(gpu_pkg.debug_convert(f, np.float32, 0.0).view(np.uint32), f.view(np.uint32))
 
 
-@pytest.mark.parametrize("mode", [3, 4, 5, 6, 7], ids=["rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi"])
+@pytest.mark.parametrize("mode", [3, 4, 5, 6, 7, 9], ids=["rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi", "direct"])
 @pytest.mark.parametrize("fmt,sw,sh,tw,th", [("Y8", 640, 360, 1280, 720), ("Y16", 333, 211, 666, 422),
                                              ("Y32", 200, 150, 400, 300), ("YUV420P8", 258, 130, 516, 260),
                                              ("Y8", 100, 80, 400, 320)])
@@ -315,6 +315,68 @@ def test_quasi_periodic_plans(gpu_pkg, O, case, mode):
     f.set_kernel_mode(mode)
     got = f.get_frame(src)
     assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th} mode {mode}")
+    f.close()
+
+
+# exactly periodic plans outside the register/LDS kernels: (case, expected (px, py, sx, sy) or None)
+DIRECT_CASES = [
+    ("Y8", 384, 216, 192, 108, {}, (1, 1, 2, 2)),                    # 1/2: fs 13
+    ("Y16", 384, 216, 128, 72, {}, (1, 1, 3, 3)),                    # 1/3: fs 20
+    ("Y32", 384, 216, 256, 144, {}, (2, 2, 3, 3)),                   # 2/3: fs 10, period 2
+    ("Y8", 480, 270, 320, 180, {}, (2, 2, 3, 3)),
+    ("Y8", 400, 300, 200, 100, {}, (1, 1, 2, 3)),                    # anisotropic 1/2 x 1/3: fs 20
+    ("Y16", 300, 200, 100, 50, dict(tap=4), (1, 1, 3, 4)),           # 1/3 x 1/4: fs 34
+    ("Y10", 320, 200, 160, 100, dict(tap=2), (1, 1, 2, 2)),          # fs 9 with a source step, peak 1023
+    ("Y8", 1100, 100, 550, 50, {}, (1, 1, 2, 2)),                    # several 256-column tiles, ragged right edge
+    ("YUV420P8", 512, 288, 256, 144, {}, (1, 1, 2, 2)),              # chroma table as well
+    ("RGBPS", 256, 144, 128, 72, dict(tap=4), (1, 1, 2, 2)),         # fs 17, float planes
+    ("Y8", 300, 200, 600, 400, dict(tap=12), (2, 2, 1, 1)),          # fs 25
+    ("Y16", 200, 120, 400, 240, dict(tap=16), (2, 2, 1, 1)),         # fs 33
+    ("Y32", 160, 100, 640, 400, dict(tap=10), (4, 4, 1, 1)),         # 4x tap 10: fs 21, 16 phases
+    ("Y8", 128, 128, 128, 128, dict(src_left=0.5, src_top=0.25), (1, 1, 1, 1)),   # pure shift
+    ("Y8", 320, 180, 256, 144, {}, (4, 4, 5, 5)),                    # 4/5: source step 5 -> not covered, gather kernel
+]
+
+
+@pytest.mark.parametrize("mode", [0, 9, 1], ids=["auto", "direct", "gather"])
+@pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
+def test_direct_periodic_kernel(gpu_pkg, O, case, mode):
+    """Down-scales and large taps whose plans are exactly periodic (any filter size, source step <= 4) run on
+    ewa_periodic_direct_kernel (no LDS, row segments fetched in the source format): bit-exact like the rest."""
+    fmt, sw, sh, tw, th, kw, want_p = case
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=1618)
+    want = of.get_frame(src, threads=4)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    info = f.plan_info()
+    assert info.periodic == 1
+    assert (info.period_x, info.period_y, info.step_x, info.step_y) == want_p
+    f.set_kernel_mode(mode)
+    got = f.get_frame(src)
+    assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th} mode {mode}")
+    f.close()
+
+
+def test_direct_kernel_tight_pitch_device_batch(gpu_pkg, O):
+    """Device entry with pitch == row size (no padding at all) and a batch of frames: the direct kernel's 16-byte
+    fetches stay inside the planes (last source row left to the border kernel) and every frame matches."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th = "Y8", 200, 120, 100, 60
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    assert f.plan_info().periodic == 1 and f.plan_info().step_x == 2
+    n = 5
+    frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=900 + i) for i in range(n)]
+    src = torch.from_numpy(np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])).cuda().contiguous()
+    dst = torch.zeros((n, th, tw), dtype=torch.uint8, device="cuda")
+    assert src.stride(1) == sw and dst.stride(1) == tw                    # pitch == row size
+    stream = torch.cuda.current_stream()
+    f.process_device([src.data_ptr()], [sw], [sw * sh], [dst.data_ptr()], [tw], [tw * th], n, stream=stream.cuda_stream)
+    stream.synchronize()
+    out = dst.cpu().numpy()
+    for i in range(n):
+        want = of.get_frame(frames[i], threads=4)
+        assert np.array_equal(out[i], want[0][:th, :tw]), f"frame {i}"
     f.close()
 
 
@@ -418,8 +480,8 @@ def test_device_entry_rejects_bad_layouts(gpu_pkg):
     f.close()
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 7, 8],
-                         ids=["gather", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_lookup"])
+@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 7, 8, 9],
+                         ids=["gather", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_lookup", "direct"])
 def test_every_kernel_reproduces_the_reference_crc_at_full_size(gpu_pkg, O, mode):
     """C2 at full size through every kernel family: the crc32 of the reference's own opt=0 output."""
     k = next(x for x in KAT["outputs"] if x["name"] == "C2")
