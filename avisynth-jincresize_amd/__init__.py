@@ -77,7 +77,7 @@ ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_hei
 EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
-           "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode",
+           "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_filter_set_pipeline",
            "jinc_filter_submit", "jinc_filter_wait"]
 
@@ -119,6 +119,9 @@ def lib():
         L.jinc_filter_lut.argtypes = [C.c_void_p, C.c_void_p]
         L.jinc_filter_set_kernel_mode.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_set_border_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_set_border_strips.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_interior_kernel.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_interior_kernel.restype = C.c_char_p
         L.jinc_debug_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
         L.jinc_filter_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
@@ -314,6 +317,13 @@ class Filter:
             dp[i], dpitch[i], ds[i] = dst_ptrs[i], dst_pitches[i], dst_strides[i]
         self._check(lib().jinc_filter_process_device(self._h, sp, spitch, ss, dp, dpitch, ds, int(nframes),
                                                      C.c_void_p(stream)))
+
+    def interior_kernel(self, table: int = 0) -> str:
+        return lib().jinc_filter_interior_kernel(self._h, int(table)).decode()
+
+    def set_border_strips(self, enable: bool) -> None:
+        """Border rows/columns of exactly periodic plans on the direct kernel (default) or on the gather kernel."""
+        self._check(lib().jinc_filter_set_border_strips(self._h, int(bool(enable))))
 
     def set_border_overlap(self, enable) -> None:
         """True / False, or None for the automatic choice."""

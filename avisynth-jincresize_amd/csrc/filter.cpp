@@ -56,8 +56,9 @@ struct DeviceTable {
     jinc::QuasiArgs quasi;
     jinc::RectList border_rects;  // gather work when the periodic kernel covers the interior
     bool use_direct = false;      // exactly periodic, any filter size / source step (kernel_direct.hip)
-    jinc::DirectArgs direct;
-    jinc::RectList direct_border_rects;
+    jinc::DirectArgs direct;      // interior
+    jinc::DirectArgs row_strips;  // border rows of the same plan over the interior's columns (any interior kernel)
+    jinc::RectList column_rects;  // what is left for the gather kernel then: left / right columns, full height
     jinc::RectList whole;         // gather work when it does not
 };
 
@@ -95,6 +96,7 @@ struct jinc_filter {
     jinc::JincLut lut;
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
+    int border_strips = 1;  // border rows/columns of exactly periodic plans on kernel_direct.hip (0: gather kernel)
     int overlap_border = -1;  // -1: automatic (side stream when the border frame is heavy: fs > 9), 0: off, 1: on
 
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
@@ -477,7 +479,8 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     }
 }
 
-// Exactly periodic plans the register/LDS kernels do not cover (down-scales, taps > 8): kernel_direct.hip.
+// Exactly periodic plans: kernel_direct.hip can take the interior (it is the choice for down-scales and taps > 8,
+// which the register/LDS kernels do not cover) and, for every interior kernel, the border rows and columns.
 void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     t.use_direct = false;
     if (!p.periodic || !jinc::direct_supported(p.fs, p.px, p.py, p.sx, p.sy)) return;
@@ -489,26 +492,48 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     da.ix0 = p.ix0, da.iy0 = p.iy0;
     da.ni = (p.ix1 - p.ix0) / p.px;
     da.nj = (p.iy1 - p.iy0) / p.py;
-    int max_sy = INT32_MIN;
+    if (da.ni < 1 || da.nj < 1) return;
     for (int k = 0; k < p.px; ++k) da.start_x[k] = p.col_start[p.ix0 + k];
-    for (int k = 0; k < p.py; ++k) {
-        da.start_y[k] = p.row_start[p.iy0 + k];
-        max_sy = std::max(max_sy, da.start_y[k]);
-    }
-    // The kernel fetches whole 4-column segments with 16-byte loads, up to kDirectOverreadBytes past the last
-    // sample it uses.  Keeping its windows out of the LAST source row keeps every such fetch inside the plane
-    // (enqueue() checks that the pitch is at least that large); the rows given up here join the border frame.
-    da.row_clamp = p.g.src_h - 2;
-    while (da.nj > 0 && max_sy + p.sy * (da.nj - 1) + p.fs - 1 > da.row_clamp) --da.nj;
-    if (da.ni < 1 || da.nj < 1 || da.row_clamp < 0) return;
+    for (int k = 0; k < p.py; ++k) da.start_y[k] = p.row_start[p.iy0 + k];
+    da.dst_h = p.g.dst_h;
+    da.plan = t.plan;
+    const int x_end = p.ix0 + p.px * da.ni, y_end = p.iy0 + p.py * da.nj;
+    const int W = p.g.dst_w, H = p.g.dst_h;
+
+    t.row_strips = da;
+    t.row_strips.line0[0] = 0, t.row_strips.line_n[0] = p.iy0;
+    t.row_strips.line0[1] = y_end, t.row_strips.line_n[1] = H - y_end;
+    jinc::RectList c;
+    auto add = [&](int x0, int y0, int w, int h) {
+        if (w <= 0 || h <= 0) return;
+        c.x0[c.n] = x0, c.y0[c.n] = y0, c.w[c.n] = w, c.h[c.n] = h;
+        ++c.n;
+    };
+    add(0, 0, p.ix0, H);
+    add(x_end, 0, W - x_end, H);
+    t.column_rects = c;
+
     for (int q = 0; q < p.py; ++q)
         for (int r = 0; r < p.px; ++r)
             da.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
                                                   p.col_class[p.ix0 + r]];
-    da.dst_h = p.g.dst_h;
     t.direct = da;
     t.use_direct = true;
-    t.direct_border_rects = border_frame(p, p.ix0 + p.px * da.ni, p.iy0 + p.py * da.nj);
+    if (!t.use_periodic && !t.use_quasi) t.border_rects = border_frame(p, x_end, y_end);  // fallback border (gather)
+}
+
+// kernel_direct.hip fetches whole segments as naturally aligned dwords through a buffer resource that ends with the
+// aligned dword holding the plane's last sample, so it cannot touch memory outside the plane's own dwords.  It needs
+// 4-byte multiples for pitch and frame stride (the plane base may be anywhere) and 32-bit offsets.
+bool direct_fetch_is_safe(size_t frame_stride, int nframes, uint64_t plane_bytes, int pitch, int fs) {
+    if (plane_bytes + static_cast<uint64_t>(pitch) * (fs + 16) + 64 >= (1ull << 32)) return false;
+    if (pitch % 4 != 0) return false;
+    return nframes <= 1 || frame_stride % 4 == 0;
+}
+// Readable bytes from the aligned-down plane base: up to the end of the aligned dword that holds the last sample.
+uint32_t direct_src_bytes(const void* base, uint64_t plane_bytes) {
+    const uint64_t mis = reinterpret_cast<uintptr_t>(base) & 3u;
+    return static_cast<uint32_t>((mis + plane_bytes + 3) & ~3ull);
 }
 
 void init_device(jinc_filter& f, int device) {
@@ -588,16 +613,22 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     auto wants_periodic = [&](const DeviceTable& t) {
         return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8;
     };
-    // kernel_mode 9: the direct kernel wherever it applies; otherwise it takes the exactly periodic plans the
-    // register/LDS kernels do not cover.  Its 16-byte fetches need a pitch of at least kDirectOverreadBytes.
-    auto wants_direct = [&](const DeviceTable& t, int pitch) {
-        if (!t.use_direct || pitch < jinc::kDirectOverreadBytes || f.kernel_mode == 1) return false;
+    // Is kernel_direct.hip usable for plane i (interior and border strips)?  See direct_fetch_is_safe().
+    auto direct_ok = [&](const DeviceTable& t, int i) {
+        if (!t.use_direct || f.kernel_mode == 1) return false;
+        const uint64_t plane_bytes = static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb;
+        return direct_fetch_is_safe(src_fs ? src_fs[i] : 0, nframes, plane_bytes, src_pitch[i], t.plan.fs);
+    };
+    // kernel_mode 9: the direct kernel wherever it applies; otherwise it takes the interior of the exactly periodic
+    // plans the register/LDS kernels do not cover.
+    auto wants_direct = [&](const DeviceTable& t, int i) {
+        if (!direct_ok(t, i)) return false;
         return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
     };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        any_periodic |= wants_periodic(t) || wants_quasi(t) || wants_direct(t, src_pitch[i]);
+        any_periodic |= wants_periodic(t) || wants_quasi(t) || wants_direct(t, i);
     }
     // A/B on MI355X: overlapping wins 12 % on C3 (fs 17) and 2-3 % on C4 (fs 9), loses 4 % on C2 (fs 7).
     const bool want_overlap = f.overlap_border < 0 ? f.plans[0].fs >= 9 : f.overlap_border != 0;
@@ -630,7 +661,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         io.nframes = nframes;
         io.sample_bytes = sb;
         io.peak = f.peak;
-        const bool direct = wants_direct(t, src_pitch[i]);
+        const bool direct = wants_direct(t, i);
         const bool quasi = !direct && wants_quasi(t);
         const bool periodic = !direct && !quasi && wants_periodic(t);
         auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
@@ -646,17 +677,30 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 sink.push_back(ev);
             }
         };
-        if (direct) {
-            if (t.direct_border_rects.n > 0)
-                timed(f.ev_gather, border_stream, "border kernel launch",
-                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.direct_border_rects, s); });
-            timed(f.ev_periodic, stream, "direct periodic kernel launch",
-                  [&](hipStream_t s) { return jinc::launch_direct(t.direct, io, s); });
-        } else if (periodic || quasi) {
-            if (t.border_rects.n > 0)
+        if (direct || periodic || quasi) {
+            // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
+            const bool strips = f.border_strips != 0 && direct_ok(t, i);
+            if (strips) {
+                jinc::DirectArgs rs = t.row_strips;
+                rs.src_bytes = direct_src_bytes(
+                    src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                timed(f.ev_gather, border_stream, "border row kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
+                if (t.column_rects.n > 0)
+                    timed(f.ev_gather, border_stream, "border column kernel launch",
+                          [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
+            } else if (t.border_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
-            if (quasi)
+            }
+            if (direct)
+                timed(f.ev_periodic, stream, "direct periodic kernel launch", [&](hipStream_t s) {
+                    jinc::DirectArgs da = t.direct;
+                    da.src_bytes = direct_src_bytes(
+                        src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                    return jinc::launch_direct(da, io, s);
+                });
+            else if (quasi)
                 timed(f.ev_periodic, stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
                     jinc::QuasiArgs qa = t.quasi;
                     if (f.kernel_mode == 8) qa.exact = 0;  // A/B: per-row lookup variant on an exactly periodic plan
@@ -1015,6 +1059,30 @@ int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, fl
         (void)hipFree(d_in);
         (void)hipFree(d_out);
     });
+}
+
+const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
+    if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return "";
+    const DeviceTable& t = f->tables[table];
+    const int m = f->kernel_mode;
+    const bool quasi = t.use_quasi && (m == 7 || m == 8 || (m != 1 && !t.use_periodic));
+    const bool periodic = t.use_periodic && m != 1 && m != 7 && m != 8;
+    if (t.use_direct && m != 1 && (m == 9 || (!periodic && !quasi))) return "ewa_direct_kernel";
+    if (quasi) return "ewa_quasi_kernel";
+    if (periodic) {
+        const int fs = t.plan.fs;
+        if (m == 5 || m == 6) return fs == 7 ? "ewa_periodic_pk_kernel" : "ewa_periodic_kernel";
+        if (m == 3 || (fs != 7 && fs != 9)) return "ewa_periodic_rows_kernel";
+        return "ewa_periodic_kernel";
+    }
+    return "ewa_gather_kernel";
+}
+
+int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    f->border_strips = enable != 0;
+    g_last_error.clear();
+    return JINC_OK;
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {

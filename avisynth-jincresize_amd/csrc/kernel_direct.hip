@@ -1,13 +1,22 @@
-// kernel_direct.hip -- interior kernel of exactly phase-periodic plans of ANY filter size and source step:
-// integer and rational down-scales (1/2: fs 13 step 2, 1/3: fs 20 step 3, 2/3: fs 10 step 3 period 2, ...) and the
-// up-scales whose footprint exceeds the register/LDS kernels of kernel_periodic.hip (taps 9..16: fs 19..33).
+// kernel_direct.hip -- ewa_direct_kernel: exactly phase-periodic plans of ANY filter size and source step 1..4,
+// without an LDS tile.  Two roles (template parameter MODE):
+//   kDirectInterior  the interior of plans the register/LDS kernels of kernel_periodic.hip do not cover: integer and
+//                    rational down-scales (1/2: fs 13 step 2, 1/3: fs 20 step 3, 2/3: fs 10 step 3 period 2, ...)
+//                    and up-scales with taps 9..16 (fs 19..33);
+//   kDirectRowStrip  the top/bottom border rows of EVERY exactly periodic plan (interior column range): a border row
+//                    is an interior row with its own window origin and its own coefficient set per column phase.
+// The left/right border columns (full height, corners included) stay with the gather kernel: lanes would have to run
+// along y there, one cache line per lane and fetch -- measured 3x slower than the gather kernel's LDS staging.
 // See device_common.hpp for the parity rules.
 //
-// Why no LDS tile here: a down-scale by s reads s*s source samples per output sample, so an fp32 LDS tile for the
+// Why no LDS tile: a down-scale by s reads s*s source samples per output sample, so an fp32 LDS tile for the
 // 16 chains x 64 lanes of one wave costs 36 KB at s = 3 before the (fs-1)-wide halo -- two waves per CU.  Instead
 // every lane reads the row segment its K adjacent output columns share straight from memory in the SOURCE format
-// (u8: 1 byte per sample) with 16-byte loads, converts it in registers, and the L1/L2 caches supply the vertical
-// reuse (fs / step times per source row).  At full VALU rate that is <= 13 B/clk/CU of cache traffic for u8.
+// (u8: 1 byte per sample) with 16-byte buffer loads, converts it in registers, and the L1/L2 caches supply the
+// vertical reuse (fs / step times per source row).  At full VALU rate that is <= 13 B/clk/CU of cache traffic for u8.
+// Buffer loads are bounds-checked by the hardware against the plane's size and only naturally aligned dwords are
+// fetched, so the whole-segment fetches (up to a block of taps past the window, and whole 4-column segments of
+// partially valid lanes) can never leave the aligned dwords that hold the plane.
 #include "device_common.hpp"
 
 #pragma clang fp contract(off)
@@ -15,27 +24,50 @@
 namespace jinc {
 namespace {
 
-constexpr int kDirectK = 4;  // adjacent output columns (of one phase) per lane: they share one row segment
-constexpr int kDirectR = 4;  // output rows (of one phase) per lane => 16 independent chains per lane
+enum : int { kDirectInterior = 0, kDirectRowStrip = 1 };
 
-// Taps per block of the lx loop.  A block's segment (B + SX*(K-1) samples) is what a lane holds in registers.
-template <typename T>
-struct DirectBlock {
-    static constexpr int B = sizeof(T) == 1 ? 16 : 8;
+// Chains per lane.  K adjacent output columns of one phase share a row segment; R output rows of one phase share
+// the coefficients (a strip row owns a coefficient set: R = 1).
+// B: taps per step of the lx loop -- a step's segment (B + SX*(K-1) samples) is what a lane holds in registers.
+// D: steps whose segments are fetched together before any of them is computed.  The interior has enough waves in
+// flight to hide the fetch latency by switching; the strip launches do not.
+template <typename T, int MODE>
+struct DirectShape {
+    static constexpr int K = 4;
+    static constexpr int R = MODE == kDirectInterior ? 4 : 1;
+    static constexpr int B = (MODE == kDirectInterior && sizeof(T) == 1) ? 16 : 8;
+    static constexpr int D = MODE == kDirectInterior ? 1 : 4;
 };
 
-// Row segment of a lane in the source format: RW dwords fetched as 16/8/4-byte pieces from an address that is
-// aligned to the sample size only.  Fewer than 4 bytes past the last sample of the segment are touched.
-template <int RW>
-__device__ __forceinline__ void load_raw(const char* p, uint32_t (&raw)[RW]) {
+// Row segment of a lane in the source format: RW dwords starting at byte offset voffset + shift (+ soffset), where
+// voffset and soffset are multiples of 4 and shift = 0..3 is the lane's misalignment.  Only naturally aligned
+// dwords are fetched (16/8/4-byte pieces) and funnel-shifted into place (v_alignbyte_b32), so nothing outside the
+// aligned dwords that hold the plane's samples is ever touched: the buffer resource bounds the rest.
+template <int RW, bool SHIFT>
+__device__ __forceinline__ void load_raw(BufferRsrc rsrc, uint32_t voffset, uint32_t shift, uint32_t soffset, uint32_t (&raw)[RW]) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    constexpr int NW = SHIFT ? RW + 1 : RW;
+    uint32_t ld[NW];
     int w = 0;
 #pragma unroll
-    for (; w + 4 <= RW; w += 4) __builtin_memcpy(&raw[w], p + 4 * w, 16);
-    if constexpr (RW % 4 >= 2) {
-        __builtin_memcpy(&raw[w], p + 4 * w, 8);
+    for (; w + 4 <= NW; w += 4) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset + 4 * w, soffset, 0);
+        ld[w] = v.x, ld[w + 1] = v.y, ld[w + 2] = v.z, ld[w + 3] = v.w;
+    }
+    if constexpr (NW % 4 >= 2) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset + 4 * w, soffset, 0);
+        ld[w] = v.x, ld[w + 1] = v.y;
         w += 2;
     }
-    if constexpr (RW % 2 == 1) __builtin_memcpy(&raw[w], p + 4 * w, 4);
+    if constexpr (NW % 2 == 1) ld[w] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset + 4 * w, soffset, 0);
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        if constexpr (SHIFT)
+            raw[i] = __builtin_amdgcn_alignbyte(ld[i + 1], ld[i], shift);
+        else
+            raw[i] = ld[i];
+    }
 }
 
 template <typename T, int NS, int RW>
@@ -52,81 +84,145 @@ __device__ __forceinline__ void convert_segment(const uint32_t (&raw)[RW], float
     }
 }
 
-template <typename T, int SX>
-struct DirectGeom {
-    static constexpr int B = DirectBlock<T>::B;
-    static constexpr int NSB = B + SX * (kDirectK - 1);                       // samples of a full block's segment
-    static constexpr int RW = (NSB * static_cast<int>(sizeof(T)) + 3) / 4;   // ... in dwords
-};
-
 // NT taps (lx = lx0 .. lx0+NT-1) of kernel row ly for all R x K chains of the lane, from segments already in
 // registers.  Every chain still meets its taps in (ly, lx) raster order: steps run in lx order inside ly order.
-template <typename T, int SX, int NT, int RW, int NC>
-__device__ __forceinline__ void mac_rows(float (&acc)[kDirectR][kDirectK], const uint32_t (&raw)[kDirectR][RW],
-                                         const float (&cf)[NC]) {
-    constexpr int NS = NT + SX * (kDirectK - 1);
+template <typename T, int SX, int NT, int R, int K, int RW, int NC>
+__device__ __forceinline__ void mac_rows(float (&acc)[R][K], const uint32_t (&raw)[R][RW], const float (&cf)[NC]) {
+    constexpr int NS = NT + SX * (K - 1);
 #pragma unroll
-    for (int jj = 0; jj < kDirectR; ++jj) {
+    for (int jj = 0; jj < R; ++jj) {
+        // The tail variants (NT = 1 .. B-1) share their conversions and products with the full step; left alone, the
+        // compiler hoists all of them above the variant ladder (hundreds of live VGPRs).  Passing the raw words
+        // through an empty asm makes them private to this variant.
+        uint32_t rw[RW];
+#pragma unroll
+        for (int w = 0; w < RW; ++w) {
+            rw[w] = raw[jj][w];
+            asm volatile("" : "+v"(rw[w]));
+        }
         float seg[NS];
-        convert_segment<T, NS, RW>(raw[jj], seg);
+        convert_segment<T, NS, RW>(rw, seg);
 #pragma unroll
-        for (int k = 0; k < kDirectK; ++k)
+        for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[jj][k] = acc[jj][k] + seg[SX * k + t] * cf[t];
     }
 }
 
-// remaining >= B: a full block; otherwise the tail of the kernel row with a compile-time tap count
-template <typename T, int SX, int NT, int RW, int NC>
+// remaining >= B: a full step; otherwise the tail of the kernel row with a compile-time tap count
+template <typename T, int SX, int NT, int R, int K, int RW, int NC>
 struct MacSelect {
-    static __device__ __forceinline__ void run(int remaining, float (&acc)[kDirectR][kDirectK],
-                                               const uint32_t (&raw)[kDirectR][RW], const float (&cf)[NC]) {
+    static __device__ __forceinline__ void run(int remaining, float (&acc)[R][K], const uint32_t (&raw)[R][RW],
+                                               const float (&cf)[NC]) {
         if (remaining >= NT)
-            mac_rows<T, SX, NT, RW, NC>(acc, raw, cf);
+            mac_rows<T, SX, NT, R, K, RW, NC>(acc, raw, cf);
         else
-            MacSelect<T, SX, NT - 1, RW, NC>::run(remaining, acc, raw, cf);
+            MacSelect<T, SX, NT - 1, R, K, RW, NC>::run(remaining, acc, raw, cf);
     }
 };
-template <typename T, int SX, int RW, int NC>
-struct MacSelect<T, SX, 0, RW, NC> {
-    static __device__ __forceinline__ void run(int, float (&)[kDirectR][kDirectK], const uint32_t (&)[kDirectR][RW],
-                                               const float (&)[NC]) {}
+template <typename T, int SX, int R, int K, int RW, int NC>
+struct MacSelect<T, SX, 0, R, K, RW, NC> {
+    static __device__ __forceinline__ void run(int, float (&)[R][K], const uint32_t (&)[R][RW], const float (&)[NC]) {}
 };
 
-// One wave = one item: phase (p, q) x 64*K period-columns x R period-rows.  The four waves of a workgroup take
-// consecutive items (phases of one row chunk first, then the next chunk), so they share source rows in the L1.
-// A kernel row is walked in steps of B taps (+ one shorter tail step); PIPE: the segments and coefficients of
-// step n+1 are fetched into a second register set before step n is computed (the waves of a SIMD are too few --
-// about 100 VGPRs each -- to hide the fetch latency by switching alone).
-template <typename T, int SX, bool PIPE>
-__global__ __launch_bounds__(256) void ewa_periodic_direct_kernel(const DirectArgs a, const PlaneIO io) {
-    using G = DirectGeom<T, SX>;
-    constexpr int B = G::B, RW = G::RW;
-    constexpr int K = kDirectK, R = kDirectR;
+__device__ __forceinline__ int plan_int(const int32_t* base, size_t index) {  // wave-uniform table lookup -> s_load
+    return ((const JINC_CONSTANT int32_t*)base)[index];
+}
+
+// One wave = one item.
+//   interior : phase (p, q) x 256 period-columns (4 per lane) x 4 period-rows;
+//   row strip: output row y x column phase p x 256 period-columns (4 per lane, 1 row);
+// The four waves of a workgroup take consecutive items (phases of one row chunk / strip line first), so they share
+// source rows in the L1.  A kernel row is walked in steps of B taps plus one shorter tail step.
+template <typename T, int SX, int MODE>
+__global__ __launch_bounds__(256) void ewa_direct_kernel(const DirectArgs a, const PlaneIO io) {
+    using Shape = DirectShape<T, MODE>;
+    constexpr int B = Shape::B, D = Shape::D;
+    constexpr int K = Shape::K, R = Shape::R;
+    constexpr int NSB = B + SX * (K - 1);                                 // samples of a full step's segment
+    constexpr int RW = (NSB * static_cast<int>(sizeof(T)) + 3) / 4;       // ... in dwords
+    constexpr uint32_t SB = static_cast<uint32_t>(sizeof(T));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int tile_x, tile_y;
-    swizzled_tile(tile_x, tile_y);
-    const int nphase = a.px * a.py;
-    const int item = tile_y * 4 + wave;
-    const int ch = item / nphase;
-    const int ph = item - ch * nphase;
-    const int q = ph / a.px;
-    const int p = ph - q * a.px;
-    const int j = ch * R;  // first period-row of the chunk
-    const int rows_valid = a.nj - j;
-    if (rows_valid <= 0) return;  // wave-uniform
-    const int i_lane = tile_x * (64 * K) + K * lane;
-    const int cols_valid = a.ni - i_lane;
-    if (cols_valid <= 0) return;
-
+    int tile_a, tile_b;
+    swizzled_tile(tile_a, tile_b);  // tile_a: along the lane axis; tile_b: groups of 4 items
+    const int item = tile_b * 4 + wave;
     const size_t frame = blockIdx.z;
-    const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
-    const JINC_CONSTANT float* cs =
-        (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (static_cast<size_t>(a.fs) * a.coeff_row));
-    const uint32_t lane_off = static_cast<uint32_t>(a.start_x[p] + SX * i_lane) * static_cast<uint32_t>(sizeof(T));
-    const int row0 = a.start_y[q] + a.sy * j;
+    const uint32_t pitch = static_cast<uint32_t>(io.src_pitch);
     const int fs = a.fs;
+
+    // ---- which chains does this lane own? ----
+    int set;                 // wave-uniform coefficient set
+    uint32_t voff[R];        // per-lane byte offset of the segments of its R rows (without ly / lx)
+    uint32_t soff0;          // wave-uniform byte offset of kernel row 0, tap 0
+    uint32_t srow_step;      // wave-uniform byte distance between the lane's R rows (interior only)
+    bool row_ok[R];          // chain rows that exist
+    int cols_valid = K;      // chain columns that exist
+    uint32_t dst_voff[R];    // per-lane byte offset of the first output sample of each row
+    uint32_t dst_soff[R];    // wave-uniform part
+    uint32_t dst_xstep = 0;  // bytes between the K output columns
+    bool lane_ok;            // the lane owns at least one chain (checked after the wave-uniform set-up below: a
+                             // divergent exit in front of it would push every uniform value into VGPRs)
+    if constexpr (MODE == kDirectInterior) {
+        const int nphase = a.px * a.py;
+        const int ch = item / nphase;
+        const int ph = item - ch * nphase;
+        const int q = ph / a.px;
+        const int p = ph - q * a.px;
+        const int j = ch * R;  // first period-row of the chunk
+        if (j >= a.nj) return;  // wave-uniform
+        const int i_lane = tile_a * (64 * K) + K * lane;
+        cols_valid = a.ni - i_lane;
+        lane_ok = cols_valid > 0;
+        set = a.set[ph];
+        soff0 = static_cast<uint32_t>(a.start_y[q] + a.sy * j) * pitch;
+        srow_step = static_cast<uint32_t>(a.sy) * pitch;
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+            voff[jj] = static_cast<uint32_t>(a.start_x[p] + SX * i_lane) * SB;
+            row_ok[jj] = j + jj < a.nj;
+            dst_voff[jj] = static_cast<uint32_t>(a.ix0 + a.px * i_lane + p) * SB;
+            dst_soff[jj] = static_cast<uint32_t>(a.iy0 + a.py * (j + jj) + q) * static_cast<uint32_t>(io.dst_pitch);
+        }
+        dst_xstep = static_cast<uint32_t>(a.px) * SB;
+    } else if constexpr (MODE == kDirectRowStrip) {
+        const int line = item / a.px;
+        const int p = item - line * a.px;
+        if (line >= a.line_n[0] + a.line_n[1]) return;
+        const int y = line < a.line_n[0] ? a.line0[0] + line : a.line0[1] + (line - a.line_n[0]);
+        const int i_lane = tile_a * (64 * K) + K * lane;
+        cols_valid = a.ni - i_lane;
+        lane_ok = cols_valid > 0;
+        const int xr = a.ix0 + p;  // representative column of the phase
+        const int rc = plan_int(a.plan.row_class, y);
+        set = rc < 0 ? plan_int(a.plan.brow_set, static_cast<size_t>(~rc) * a.plan.dst_w + xr)
+                     : plan_int(a.plan.interior_set, static_cast<size_t>(rc) * a.plan.n_col_classes + plan_int(a.plan.col_class, xr));
+        soff0 = static_cast<uint32_t>(plan_int(a.plan.row_start, y)) * pitch;
+        srow_step = 0;
+        voff[0] = static_cast<uint32_t>(a.start_x[p] + SX * i_lane) * SB;
+        row_ok[0] = true;
+        dst_voff[0] = static_cast<uint32_t>(a.ix0 + a.px * i_lane + p) * SB;
+        dst_soff[0] = static_cast<uint32_t>(y) * static_cast<uint32_t>(io.dst_pitch);
+        dst_xstep = static_cast<uint32_t>(a.px) * SB;
+    }
+
+    // Split every segment address into an aligned part and the lane's byte shift.  The host guarantees that the
+    // pitch and the frame stride are multiples of 4; the plane's own misalignment (base & 3) joins the lane offset.
+    constexpr bool kShift = sizeof(T) < 4;
+    const uintptr_t plane = reinterpret_cast<uintptr_t>(io.src) + frame * io.src_frame_stride;
+    const uint32_t mis = static_cast<uint32_t>(plane & 3u) + (soff0 & 3u);
+    soff0 &= ~3u;
+    uint32_t shift[R];
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj) {
+        const uint32_t v = voff[jj] + mis;
+        shift[jj] = v & 3u;
+        voff[jj] = v & ~3u;
+    }
+    const BufferRsrc srsrc = make_rsrc(reinterpret_cast<char*>(plane & ~static_cast<uintptr_t>(3)), a.src_bytes);
+    if (!lane_ok) return;
+    const JINC_CONSTANT float* cs =
+        (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(set) * (static_cast<size_t>(fs) * a.coeff_row));
 
     float acc[R][K];
 #pragma unroll
@@ -134,102 +230,83 @@ __global__ __launch_bounds__(256) void ewa_periodic_direct_kernel(const DirectAr
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[jj][k] = 0.f;
 
-    // segments + coefficients of the step at kernel row fly, first tap flx
-    auto fetch = [&](uint32_t (&raw)[R][RW], float (&cf)[B], int fly, int flx) __attribute__((always_inline)) {
+    // steps in (ly, lx) raster order: step s covers kernel row s / nsx, taps (s % nsx) * B ...
+    const int nsx = (fs + B - 1) / B;
+    const int nsteps = fs * nsx;
+    int ly = 0, lxi = 0;  // coordinates of the next step to fetch
+#pragma unroll 1
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+        uint32_t raw[D][R][RW];
+        float cf[D][B];
+        int rem[D];
 #pragma unroll
-        for (int jj = 0; jj < R; ++jj) {
-            int r = row0 + a.sy * jj + fly;
-            r = r < a.row_clamp ? r : a.row_clamp;  // rows of chains that do not exist (jj >= rows_valid)
-            const char* rowp = sbase + static_cast<size_t>(r) * io.src_pitch + flx * static_cast<int>(sizeof(T));
-            load_raw<RW>(rowp + lane_off, raw[jj]);
-        }
-        const JINC_CONSTANT float* c = cs + static_cast<size_t>(fly) * a.coeff_row + flx;
+        for (int d = 0; d < D; ++d) {
+            if (D == 1 || s0 + d < nsteps) {  // wave-uniform
+                const int lx = lxi * B;
+                const uint32_t srow = soff0 + static_cast<uint32_t>(ly) * pitch + static_cast<uint32_t>(lx) * SB;
 #pragma unroll
-        for (int t = 0; t < B; ++t) cf[t] = c[t];  // wave-uniform -> SGPRs (the allocation has slack past the last row)
-    };
-
-    if constexpr (PIPE) {
-        uint32_t raw_a[R][RW], raw_b[R][RW];
-        float cf_a[B], cf_b[B];
-        int ly = 0, lx = 0;
-        fetch(raw_a, cf_a, 0, 0);
-        while (true) {
-            int nly = ly, nlx = lx + B;
-            if (nlx >= fs) nlx = 0, ++nly;
-            const bool more_b = nly < fs;
-            if (more_b) fetch(raw_b, cf_b, nly, nlx);
-            MacSelect<T, SX, B, RW, B>::run(fs - lx, acc, raw_a, cf_a);
-            if (!more_b) break;
-            ly = nly, lx = nlx;
-            nlx = lx + B;
-            if (nlx >= fs) nlx = 0, ++nly;
-            const bool more_a = nly < fs;
-            if (more_a) fetch(raw_a, cf_a, nly, nlx);
-            MacSelect<T, SX, B, RW, B>::run(fs - lx, acc, raw_b, cf_b);
-            if (!more_a) break;
-            ly = nly, lx = nlx;
-        }
-    } else {
-        for (int ly = 0; ly < fs; ++ly)
-            for (int lx = 0; lx < fs; lx += B) {
-                uint32_t raw[R][RW];
-                float cf[B];
-                fetch(raw, cf, ly, lx);
-                MacSelect<T, SX, B, RW, B>::run(fs - lx, acc, raw, cf);
+                for (int jj = 0; jj < R; ++jj)
+                    load_raw<RW, kShift>(srsrc, voff[jj], shift[jj], srow + static_cast<uint32_t>(jj) * srow_step, raw[d][jj]);
+                const JINC_CONSTANT float* c = cs + static_cast<size_t>(ly) * a.coeff_row + lx;
+#pragma unroll
+                for (int t = 0; t < B; ++t) cf[d][t] = c[t];  // wave-uniform -> SGPRs (the allocation has slack past the last row)
+                rem[d] = fs - lx;
+                if (++lxi == nsx) lxi = 0, ++ly;
             }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (D == 1 || s0 + d < nsteps) MacSelect<T, SX, B, R, K, RW, B>::run(rem[d], acc, raw[d], cf[d]);
     }
 
     const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
                                        static_cast<uint32_t>(io.dst_pitch) * a.dst_h);
-    const unsigned x0 = a.ix0 + a.px * i_lane + p;
-    const int y0 = a.iy0 + a.py * j + q;
 #pragma unroll
     for (int jj = 0; jj < R; ++jj) {
-        if (jj < rows_valid) {  // wave-uniform
-            const uint32_t soff = static_cast<uint32_t>(y0 + jj * a.py) * io.dst_pitch;
+        if (row_ok[jj]) {  // wave-uniform
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                if (k < cols_valid)
-                    store_sample_buf<T>(drsrc, (x0 + k * a.px) * static_cast<uint32_t>(sizeof(T)), soff, acc[jj][k], io.peak);
+                if (k < cols_valid) store_sample_buf<T>(drsrc, dst_voff[jj] + k * dst_xstep, dst_soff[jj], acc[jj][k], io.peak);
         }
     }
 }
 
-// PIPE default: integer planes (their raw segments are 1/4 or 1/2 the size of the converted ones); float planes
-// would need 2 x 4 x 20 VGPRs for the second register set.  JINC_DIRECT_PIPE=0/1 overrides for A/B runs.
-template <typename T>
-bool direct_pipe_default() {
-    static const int env = [] {
-        const char* e = std::getenv("JINC_DIRECT_PIPE");
-        return e ? std::atoi(e) : -1;
-    }();
-    if (sizeof(T) == 4) return false;
-    return env < 0 ? true : env != 0;
-}
-
-template <typename T, int SX>
+template <typename T, int SX, int MODE>
 int launch_direct_t(const DirectArgs& da, const PlaneIO& io, hipStream_t stream) {
-    const int nchunks = (da.nj + kDirectR - 1) / kDirectR;
-    const int items = nchunks * da.px * da.py;
-    dim3 grid((da.ni + 64 * kDirectK - 1) / (64 * kDirectK), (items + 3) / 4, io.nframes);
-    if constexpr (sizeof(T) != 4) {
-        if (direct_pipe_default<T>()) {
-            hipLaunchKernelGGL((ewa_periodic_direct_kernel<T, SX, true>), grid, dim3(256, 1, 1), 0, stream, da, io);
-            return static_cast<int>(hipGetLastError());
-        }
+    constexpr int K = DirectShape<T, MODE>::K, R = DirectShape<T, MODE>::R;
+    int tiles, items;
+    if (MODE == kDirectInterior) {
+        tiles = (da.ni + 64 * K - 1) / (64 * K);
+        items = (da.nj + R - 1) / R * da.px * da.py;
+    } else {
+        tiles = (da.ni + 64 * K - 1) / (64 * K);
+        items = (da.line_n[0] + da.line_n[1]) * da.px;
     }
-    hipLaunchKernelGGL((ewa_periodic_direct_kernel<T, SX, false>), grid, dim3(256, 1, 1), 0, stream, da, io);
+    if (tiles <= 0 || items <= 0) return 0;
+    dim3 grid(tiles, (items + 3) / 4, io.nframes);
+    hipLaunchKernelGGL((ewa_direct_kernel<T, SX, MODE>), grid, dim3(256, 1, 1), 0, stream, da, io);
     return static_cast<int>(hipGetLastError());
 }
 
-template <typename T>
+template <typename T, int MODE>
 int launch_direct_sx(const DirectArgs& da, const PlaneIO& io, hipStream_t stream) {
     switch (da.sx) {
-        case 1: return launch_direct_t<T, 1>(da, io, stream);
-        case 2: return launch_direct_t<T, 2>(da, io, stream);
-        case 3: return launch_direct_t<T, 3>(da, io, stream);
-        case 4: return launch_direct_t<T, 4>(da, io, stream);
+        case 1: return launch_direct_t<T, 1, MODE>(da, io, stream);
+        case 2: return launch_direct_t<T, 2, MODE>(da, io, stream);
+        case 3: return launch_direct_t<T, 3, MODE>(da, io, stream);
+        case 4: return launch_direct_t<T, 4, MODE>(da, io, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
+template <int MODE>
+int launch_direct_mode(const DirectArgs& args, const PlaneIO& io, void* stream) {
+    if (io.nframes <= 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (io.sample_bytes) {
+        case 1: return launch_direct_sx<uint8_t, MODE>(args, io, s);
+        case 2: return launch_direct_sx<uint16_t, MODE>(args, io, s);
+        default: return launch_direct_sx<float, MODE>(args, io, s);
     }
 }
 
@@ -241,13 +318,13 @@ bool direct_supported(int fs, int px, int py, int sx, int sy) {
 }
 
 int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream) {
-    if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (io.sample_bytes) {
-        case 1: return launch_direct_sx<uint8_t>(args, io, s);
-        case 2: return launch_direct_sx<uint16_t>(args, io, s);
-        default: return launch_direct_sx<float>(args, io, s);
-    }
+    if (args.ni <= 0 || args.nj <= 0) return 0;
+    return launch_direct_mode<kDirectInterior>(args, io, stream);
+}
+
+int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream) {
+    if (args.ni <= 0) return 0;
+    return launch_direct_mode<kDirectRowStrip>(args, io, stream);
 }
 
 }  // namespace jinc

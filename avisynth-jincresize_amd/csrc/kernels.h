@@ -94,24 +94,27 @@ bool quasi_supported(int fs, int px, int py, int sx, int sy, int n_col_classes, 
 bool quasi_configure(QuasiArgs& args, int fs, int spread_x, int spread_y);
 int launch_quasi(const QuasiArgs& args, int fs, const PlaneIO& io, void* stream);
 
-// Exactly periodic interior of any filter size and source step 1..4 (kernel_direct.hip): output pixel
-// (ix0 + px*i + p, iy0 + py*j + q) reads the source window at (start_x[p] + sx*i, start_y[q] + sy*j) with
-// coefficient set set[q*px + p]; no LDS, row segments are read from memory in the source format.
+// Exactly periodic plans of any filter size and source step 1..4 (kernel_direct.hip; no LDS, row segments are read
+// from memory in the source format with bounds-checked buffer loads).
+//   interior  : output pixel (ix0 + px*i + p, iy0 + py*j + q), i < ni, j < nj, reads the source window at
+//               (start_x[p] + sx*i, start_y[q] + sy*j) with coefficient set set[q*px + p];
+//   row strips: the output rows line0[k] .. line0[k]+line_n[k]-1 (k = 0, 1: above / below the interior) over the
+//               interior's column range; window row and coefficient set come from the plan tables per row and phase.
 struct DirectArgs {
     const float* coeffs = nullptr;
     int fs = 0, coeff_row = 0;   // filter size; floats per coefficient row on the device (padded_row(fs))
     int px = 1, py = 1, sx = 1, sy = 1;
     int ix0 = 0, iy0 = 0, ni = 0, nj = 0;
     int start_x[16] = {0}, start_y[16] = {0};
-    int set[256] = {0};
-    int row_clamp = 0;           // src_h - 2: no segment starts in the last source row (see filter.cpp plan_direct)
+    int set[256] = {0};          // interior only
+    int line0[2] = {0, 0}, line_n[2] = {0, 0};  // strips only
+    DevicePlan plan;             // strips only: row/column tables
+    uint32_t src_bytes = 0;      // readable bytes from the aligned-down base of one source plane (filter.cpp direct_src_bytes)
     int dst_h = 0;
 };
-// Segments may be fetched up to this many bytes past their last used sample (whole K-column segments of partially
-// valid lanes + load granularity); the host keeps them inside the plane (min pitch, last source row excluded).
-constexpr int kDirectOverreadBytes = 128;
 bool direct_supported(int fs, int px, int py, int sx, int sy);
 int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream);
+int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream);
 
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);

@@ -244,7 +244,7 @@ def main():
         src_bytes_frame = sum(w * h for (w, h) in fmt.plane_dims(sw, sh)) * sb
         n_planes = fmt.planes
         if per_n > 0:
-            dom_name, dom_ms, dom_n = "ewa_periodic_kernel", per_ms, per_n
+            dom_name, dom_ms, dom_n = flt.interior_kernel(0), per_ms, per_n
         else:
             dom_name, dom_ms, dom_n = "ewa_gather_kernel", gat_ms, gat_n
         # one launch per plane per step; algorithmic bytes of a launch = the batch's bytes for that plane,

@@ -223,6 +223,11 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * 8 = its per-row lookup variant on exactly periodic plans too, 9 = the direct (no-LDS) periodic kernel wherever
  * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
+/* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
+JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);
+/* Border frame of exactly periodic plans: 1 (default) = rows and columns on the direct kernel, corners on the
+ * gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */
+JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
 /* 1: the border gather kernel runs on a side stream concurrently with the periodic interior kernel
  * (fork/join by events around every call); 0: both on the caller's stream, back to back;
  * -1 (default): automatic -- side stream when the filter footprint is 9 or larger. */

@@ -357,11 +357,12 @@ def test_direct_periodic_kernel(gpu_pkg, O, case, mode):
     f.close()
 
 
-def test_direct_kernel_tight_pitch_device_batch(gpu_pkg, O):
-    """Device entry with pitch == row size (no padding at all) and a batch of frames: the direct kernel's 16-byte
-    fetches stay inside the planes (last source row left to the border kernel) and every frame matches."""
+@pytest.mark.parametrize("sw", [200, 202], ids=["pitch200", "pitch202_not_multiple_of_4"])
+def test_direct_kernel_tight_pitch_device_batch(gpu_pkg, O, sw):
+    """Device entry with pitch == row size (no padding at all) and a batch of frames: the direct kernel fetches
+    aligned dwords inside the plane only; a pitch that is not a multiple of 4 falls back to the gather kernel."""
     torch = pytest.importorskip("torch")
-    fmt, sw, sh, tw, th = "Y8", 200, 120, 100, 60
+    fmt, sh, tw, th = "Y8", 120, sw // 2, 60
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     assert f.plan_info().periodic == 1 and f.plan_info().step_x == 2
@@ -377,6 +378,60 @@ def test_direct_kernel_tight_pitch_device_batch(gpu_pkg, O):
     for i in range(n):
         want = of.get_frame(frames[i], threads=4)
         assert np.array_equal(out[i], want[0][:th, :tw]), f"frame {i}"
+    f.close()
+
+
+STRIP_CASES = [
+    ("Y8", 640, 360, 1280, 720, {}),                  # C1 shape, window kernel interior
+    ("YUV420P16", 160, 96, 320, 192, dict(tap=8, cplace="mpeg2")),   # C3 in miniature, row-streamed interior
+    ("RGBPS", 200, 100, 400, 200, dict(tap=4, blur=0.98)),            # C4 in miniature
+    ("Y8", 360, 270, 480, 360, {}),                   # 4/3x: exact quasi kernel interior, source step 3
+    ("Y16", 384, 216, 128, 72, {}),                   # 1/3 down-scale, direct interior
+    ("Y8", 300, 200, 600, 400, dict(tap=12)),         # fs 25
+    ("Y8", 131, 77, 262, 154, {}),                    # ragged sizes
+    ("Y8", 133, 79, 399, 237, dict(tap=2)),           # 3x, may drift -> whatever the plan finds
+]
+
+
+@pytest.mark.parametrize("strips", [True, False], ids=["strips", "gather_border"])
+@pytest.mark.parametrize("case", STRIP_CASES, ids=_id)
+def test_border_strips_and_gather_border_agree_with_oracle(gpu_pkg, O, case, strips):
+    """The border frame of exactly periodic plans runs as row/column strips on ewa_direct_kernel (+ corners on the
+    gather kernel) by default; the all-gather border stays available.  Both are bit-exact."""
+    fmt, sw, sh, tw, th, kw = case
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=777)
+    want = of.get_frame(src, threads=4)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    f.set_border_strips(strips)
+    got = f.get_frame(src)
+    assert_planes_equal(got, want, f.out_dims(), what=f"{_id(case)} strips={strips}")
+    f.close()
+
+
+def test_plane_ending_on_a_page_boundary(gpu_pkg, O):
+    """ewa_direct_kernel fetches naturally aligned dwords only, bounded by the dword that holds the plane's last
+    sample: planes that end on (or within 3 bytes of) a 4 KiB page boundary, at every base misalignment, are served
+    without touching the next page and without losing the last samples."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th = "Y8", 200, 120, 100, 60
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    frame = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=4096)
+    want = of.get_frame(frame, threads=4)[0][:th, :tw]
+    plane = np.ascontiguousarray(frame[0][:sh, :sw])
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    pool = torch.zeros(4 * 4096 + sw * sh, dtype=torch.uint8, device="cuda")
+    dst = torch.zeros((th, tw), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+    for slack in (0, 1, 2, 3, 4, 2048):   # bytes between the plane's end and the next page boundary
+        off = (-(pool.data_ptr() + sw * sh + slack)) % 4096
+        view = pool[off:off + sw * sh]
+        assert (view.data_ptr() + sw * sh + slack) % 4096 == 0
+        view.copy_(torch.from_numpy(plane.reshape(-1)))
+        dst.zero_()
+        f.process_device([view.data_ptr()], [sw], [0], [dst.data_ptr()], [tw], [0], 1, stream=stream.cuda_stream)
+        stream.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), want), f"slack {slack}"
     f.close()
 
 
