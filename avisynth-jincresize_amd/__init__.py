@@ -25,7 +25,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libjincresize_hip.so")
-ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_periodic", "kernel_direct", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
+ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_periodic", "kernel_direct", "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
                        "kernel_quasi_exact_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
 
@@ -321,9 +321,9 @@ class Filter:
     def interior_kernel(self, table: int = 0) -> str:
         return lib().jinc_filter_interior_kernel(self._h, int(table)).decode()
 
-    def set_border_strips(self, enable: bool) -> None:
-        """Border rows/columns of exactly periodic plans on the direct kernel (default) or on the gather kernel."""
-        self._check(lib().jinc_filter_set_border_strips(self._h, int(bool(enable))))
+    def set_border_strips(self, mode) -> None:
+        """Border frame of exactly periodic plans: True/1 strip kernels (default), 2 rows only, False/0 gather kernel."""
+        self._check(lib().jinc_filter_set_border_strips(self._h, int(mode)))
 
     def set_border_overlap(self, enable) -> None:
         """True / False, or None for the automatic choice."""

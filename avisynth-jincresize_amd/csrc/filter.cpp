@@ -58,7 +58,10 @@ struct DeviceTable {
     bool use_direct = false;      // exactly periodic, any filter size / source step (kernel_direct.hip)
     jinc::DirectArgs direct;      // interior
     jinc::DirectArgs row_strips;  // border rows of the same plan over the interior's columns (any interior kernel)
-    jinc::RectList column_rects;  // what is left for the gather kernel then: left / right columns, full height
+    bool use_colstrip = false;    // border columns over the interior's rows on kernel_colstrip.hip
+    jinc::ColStripArgs col_strips;
+    jinc::RectList corner_rects;  // ... then only the corners are left for the gather kernel
+    jinc::RectList column_rects;  // otherwise: left / right columns, full height, on the gather kernel
     jinc::RectList whole;         // gather work when it does not
 };
 
@@ -512,6 +515,39 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     add(0, 0, p.ix0, H);
     add(x_end, 0, W - x_end, H);
     t.column_rects = c;
+    c = jinc::RectList{};
+    add(0, 0, p.ix0, p.iy0);
+    add(x_end, 0, W - x_end, p.iy0);
+    add(0, y_end, p.ix0, H - y_end);
+    add(x_end, y_end, W - x_end, H - y_end);
+    c.private_sets = true;  // corner pixels own a coefficient set each
+    t.corner_rects = c;
+
+    jinc::ColStripArgs ca;
+    ca.coeffs = t.plan.coeffs;
+    ca.fs = p.fs, ca.coeff_row = da.coeff_row;
+    ca.py = p.py, ca.sy = p.sy, ca.iy0 = p.iy0, ca.nj = da.nj;
+    int min_sy = INT32_MAX, max_sy = INT32_MIN;
+    for (int k = 0; k < p.py; ++k) {
+        ca.start_y[k] = da.start_y[k];
+        min_sy = std::min(min_sy, da.start_y[k]);
+        max_sy = std::max(max_sy, da.start_y[k]);
+    }
+    ca.min_sy = min_sy, ca.spread_y = max_sy - min_sy;
+    ca.x0[0] = 0, ca.nx[0] = p.ix0;
+    ca.x0[1] = x_end, ca.nx[1] = W - x_end;
+    for (int s = 0; s < 2; ++s) {
+        if (ca.nx[s] <= 0) continue;
+        int lo = INT32_MAX, hi = INT32_MIN;  // window origins are non-decreasing in x, but do not rely on it
+        for (int x = ca.x0[s]; x < ca.x0[s] + ca.nx[s]; ++x) {
+            lo = std::min(lo, p.col_start[x]);
+            hi = std::max(hi, p.col_start[x] + p.fs);
+        }
+        ca.src_c0[s] = lo, ca.src_w[s] = hi - lo;
+    }
+    ca.plan = t.plan;
+    t.use_colstrip = jinc::colstrip_configure(ca);
+    t.col_strips = ca;
 
     for (int q = 0; q < p.py; ++q)
         for (int r = 0; r < p.px; ++r)
@@ -630,8 +666,9 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
         any_periodic |= wants_periodic(t) || wants_quasi(t) || wants_direct(t, i);
     }
-    // A/B on MI355X: overlapping wins 12 % on C3 (fs 17) and 2-3 % on C4 (fs 9), loses 4 % on C2 (fs 7).
-    const bool want_overlap = f.overlap_border < 0 ? f.plans[0].fs >= 9 : f.overlap_border != 0;
+    // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
+    // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
+    const bool want_overlap = f.overlap_border != 0;
     const bool fork = any_periodic && want_overlap;
     if (fork) {  // border work may start once everything already queued on `stream` is done
         hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");
@@ -686,9 +723,16 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                     src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
                 timed(f.ev_gather, border_stream, "border row kernel launch",
                       [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
-                if (t.column_rects.n > 0)
+                if (t.use_colstrip && f.border_strips != 2) {
+                    timed(f.ev_gather, border_stream, "border column kernel launch",
+                          [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
+                    if (t.corner_rects.n > 0)
+                        timed(f.ev_gather, border_stream, "corner kernel launch",
+                              [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
+                } else if (t.column_rects.n > 0) {
                     timed(f.ev_gather, border_stream, "border column kernel launch",
                           [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
+                }
             } else if (t.border_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
@@ -1080,7 +1124,7 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
 
 int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
-    f->border_strips = enable != 0;
+    f->border_strips = enable < 0 ? 1 : enable > 2 ? 1 : enable;  // 2: rows as strips, columns on the gather kernel
     g_last_error.clear();
     return JINC_OK;
 }

@@ -116,6 +116,23 @@ bool direct_supported(int fs, int px, int py, int sx, int sy);
 int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream);
 int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream);
 
+// Left / right border columns of an exactly periodic plan over the interior's row range (kernel_colstrip.hip):
+// item = (output column x, row phase q), lanes = 64 consecutive period-rows, source footprint staged in LDS.
+struct ColStripArgs {
+    const float* coeffs = nullptr;
+    int fs = 0, coeff_row = 0;
+    int py = 1, sy = 1, iy0 = 0, nj = 0;
+    int start_y[16] = {0};
+    int min_sy = 0, spread_y = 0;          // min over phases of start_y, max - min
+    int x0[2] = {0, 0}, nx[2] = {0, 0};    // output column runs: left, right
+    int src_c0[2] = {0, 0}, src_w[2] = {0, 0};  // source columns their windows cover
+    int groups[2] = {0, 0}, group_cols = 1;     // blocks per run, columns per block (colstrip_configure)
+    int col_shift = 0;                          // staging: 1 << col_shift lanes per source row
+    DevicePlan plan;
+};
+bool colstrip_configure(ColStripArgs& args);
+int launch_colstrip(const ColStripArgs& args, const PlaneIO& io, void* stream);
+
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);
 

@@ -225,12 +225,12 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
 JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);
-/* Border frame of exactly periodic plans: 1 (default) = rows and columns on the direct kernel, corners on the
- * gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */
+/* Border frame of exactly periodic plans: 1 (default) = rows and columns on the strip kernels, corners on the
+ * gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel; 0 = everything on the
+ * gather kernel (A/B measurements, tests). */
 JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
-/* 1: the border gather kernel runs on a side stream concurrently with the periodic interior kernel
- * (fork/join by events around every call); 0: both on the caller's stream, back to back;
- * -1 (default): automatic -- side stream when the filter footprint is 9 or larger. */
+/* 1 or -1 (default): the border kernels run on a side stream concurrently with the interior kernel
+ * (fork/join by events around every call); 0: all on the caller's stream, back to back. */
 JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
 
 /* Test hook: runs the kernels' own sum -> sample conversion (clamp to [0, peak], round-half-even, store;

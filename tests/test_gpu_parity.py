@@ -393,7 +393,7 @@ STRIP_CASES = [
 ]
 
 
-@pytest.mark.parametrize("strips", [True, False], ids=["strips", "gather_border"])
+@pytest.mark.parametrize("strips", [1, 2, 0], ids=["strips", "row_strips_only", "gather_border"])
 @pytest.mark.parametrize("case", STRIP_CASES, ids=_id)
 def test_border_strips_and_gather_border_agree_with_oracle(gpu_pkg, O, case, strips):
     """The border frame of exactly periodic plans runs as row/column strips on ewa_direct_kernel (+ corners on the
