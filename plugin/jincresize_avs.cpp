@@ -1,0 +1,286 @@
+// jincresize_avs.cpp -- the AviSynth+ C-API plugin shell around libjincresize_hip.so.
+//
+// Registers JincResize and Jinc36/64/144/256Resize with the reference's parameter strings
+// (/root/reference/src/JincResize.cpp:1042-1111), parses script arguments the way Create_JincResize does
+// (:654-792), and implements the AVS_FilterInfo callbacks (GetFrame :603-630, cache hints :649-652, free :632-647)
+// on top of the C ABI in include/jincresize_hip.h.  All resampling happens behind that ABI on the GPU; there is no CPU
+// path in this file.
+//
+// Build (needs the AviSynth+ SDK header, which this repository does not ship):
+//   g++ -std=c++17 -shared -fPIC plugin/jincresize_avs.cpp -Iinclude -I<avisynth sdk>/include
+//       -Lavisynth-jincresize_amd/lib -ljincresize_hip -o libjincresize.so
+// In this repository it is compiled only against tests/mock_avs/avisynth_c.h (a self-written subset of the API, for
+// the mock-host tests in tests/test_plugin_mock_host.py); see INTEGRATION.md section 6 for what that does and does not
+// prove.
+#include "avisynth_c.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "jincresize_hip.h"
+
+namespace {
+
+struct Pending {  // one frame in flight in the look-ahead ring
+    AVS_VideoFrame* src = nullptr;
+    AVS_VideoFrame* dst = nullptr;
+    long long ticket = -1;
+    int frame = -1;
+};
+
+struct Instance {
+    jinc_filter* filter = nullptr;
+    int chroma_location = -1;     // value written to _ChromaLocation, -1: format without sub-sampled chroma
+    int lookahead = 1;            // frames in flight (JINCRESIZE_LOOKAHEAD, default 1 = the reference's synchronous GetFrame)
+    std::vector<Pending> ring;
+    int next_submit = 0;          // next frame number to submit when access is sequential
+    std::string error;            // storage for fi->error
+};
+
+// Argument positions of JincResize (ref :656-674).
+enum : int { A_CLIP, A_WIDTH, A_HEIGHT, A_SRC_LEFT, A_SRC_TOP, A_SRC_WIDTH, A_SRC_HEIGHT, A_QUANT_X, A_QUANT_Y, A_TAP, A_BLUR,
+             A_CPLACE, A_THREADS, A_OPT, A_INITIAL_CAPACITY, A_INITIAL_FACTOR };
+
+const int kPlanesYuv[4] = {AVS_PLANAR_Y, AVS_PLANAR_U, AVS_PLANAR_V, AVS_PLANAR_A};   // processing order, ref :539-541
+const int kPlanesRgb[4] = {AVS_PLANAR_G, AVS_PLANAR_B, AVS_PLANAR_R, AVS_PLANAR_A};
+
+void plane_pointers(const AVS_VideoInfo* vi, AVS_VideoFrame* src, AVS_VideoFrame* dst, const void* sp[4], int spitch[4],
+                    void* dp[4], int dpitch[4]) {
+    const int* order = avs_is_rgb(vi) ? kPlanesRgb : kPlanesYuv;
+    const int n = avs_num_components(vi);
+    for (int i = 0; i < 4; ++i) {
+        sp[i] = nullptr, dp[i] = nullptr, spitch[i] = 0, dpitch[i] = 0;
+        if (i >= n) continue;
+        sp[i] = avs_get_read_ptr_p(src, order[i]);
+        spitch[i] = avs_get_pitch_p(src, order[i]);
+        dp[i] = avs_get_write_ptr_p(dst, order[i]);
+        dpitch[i] = avs_get_pitch_p(dst, order[i]);
+    }
+}
+
+void finish_frame(AVS_FilterInfo* fi, Instance* inst, AVS_VideoFrame* src, AVS_VideoFrame* dst) {
+    if (inst->chroma_location >= 0)  // ref :617-625: int property, mode 0 = replace
+        avs_prop_set_int(fi->env, avs_get_frame_props_rw(fi->env, dst), "_ChromaLocation", inst->chroma_location, 0);
+    avs_release_video_frame(src);    // ref :627
+}
+
+AVS_VideoFrame* report(AVS_FilterInfo* fi, Instance* inst, AVS_VideoFrame* src, AVS_VideoFrame* dst) {
+    inst->error = jinc_last_error();  // no CPU fallback: the failure goes to the host
+    fi->error = inst->error.c_str();
+    if (src) avs_release_video_frame(src);
+    return dst;
+}
+
+// ref :603-630, synchronous form
+AVS_VideoFrame* get_frame_sync(AVS_FilterInfo* fi, Instance* inst, int n) {
+    AVS_VideoFrame* src = avs_get_frame(fi->child, n);
+    if (!src) return nullptr;  // ref :610-611
+    AVS_VideoFrame* dst = avs_new_video_frame_p(fi->env, &fi->vi, src);  // inherits the frame properties, ref :613
+    const void* sp[4];
+    void* dp[4];
+    int spitch[4], dpitch[4];
+    plane_pointers(&fi->vi, src, dst, sp, spitch, dp, dpitch);
+    if (jinc_filter_get_frame(inst->filter, sp, spitch, dp, dpitch) != JINC_OK) return report(fi, inst, src, dst);
+    finish_frame(fi, inst, src, dst);
+    return dst;
+}
+
+// Look-ahead form: frames n .. n+depth-1 are in flight on the filter's
+// pipeline slots; sequential access is assumed, anything else drains the ring first.
+AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
+    const int depth = inst->lookahead;
+    const int last = fi->vi.num_frames - 1;
+    Pending& want = inst->ring[n % depth];
+    if (want.frame != n) {  // seek: wait for and drop whatever is in flight
+        for (Pending& p : inst->ring) {
+            if (p.frame < 0) continue;
+            jinc_filter_wait(inst->filter, p.ticket);
+            avs_release_video_frame(p.src);
+            avs_release_video_frame(p.dst);
+            p = Pending{};
+        }
+        inst->next_submit = n;
+    }
+    for (int k = std::max(inst->next_submit, n); k <= std::min(n + depth - 1, last); ++k) {
+        Pending& p = inst->ring[k % depth];
+        p.src = avs_get_frame(fi->child, k);
+        if (!p.src) break;
+        p.dst = avs_new_video_frame_p(fi->env, &fi->vi, p.src);
+        const void* sp[4];
+        void* dp[4];
+        int spitch[4], dpitch[4];
+        plane_pointers(&fi->vi, p.src, p.dst, sp, spitch, dp, dpitch);
+        if (jinc_filter_submit(inst->filter, sp, spitch, dp, dpitch, &p.ticket) != JINC_OK) {
+            AVS_VideoFrame* dst = p.dst;
+            AVS_VideoFrame* src = p.src;
+            p = Pending{};
+            return report(fi, inst, src, dst);
+        }
+        p.frame = k;
+        inst->next_submit = k + 1;
+    }
+    if (want.frame != n) return nullptr;  // the child had no frame n
+    if (jinc_filter_wait(inst->filter, want.ticket) != JINC_OK) {
+        AVS_VideoFrame* dst = want.dst;
+        AVS_VideoFrame* src = want.src;
+        want = Pending{};
+        return report(fi, inst, src, dst);
+    }
+    AVS_VideoFrame* dst = want.dst;
+    finish_frame(fi, inst, want.src, dst);
+    want = Pending{};
+    return dst;
+}
+
+AVS_VideoFrame* AVSC_CC jinc_get_frame(AVS_FilterInfo* fi, int n) {
+    Instance* inst = static_cast<Instance*>(fi->user_data);
+    return inst->lookahead > 1 ? get_frame_lookahead(fi, inst, n) : get_frame_sync(fi, inst, n);
+}
+
+// ref :649-652: one instance per worker thread
+int AVSC_CC jinc_set_cache_hints(AVS_FilterInfo*, int cachehints, int) {
+    return cachehints == AVS_CACHE_GET_MTMODE ? 2 /* MT_MULTI_INSTANCE */ : 0;
+}
+
+void AVSC_CC jinc_free(AVS_FilterInfo* fi) {  // ref :632-647
+    Instance* inst = static_cast<Instance*>(fi->user_data);
+    if (!inst) return;
+    for (Pending& p : inst->ring) {
+        if (p.frame < 0) continue;
+        jinc_filter_wait(inst->filter, p.ticket);
+        avs_release_video_frame(p.src);
+        avs_release_video_frame(p.dst);
+    }
+    jinc_filter_free(inst->filter);
+    delete inst;
+    fi->user_data = nullptr;
+}
+
+AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, void*) {
+    AVS_FilterInfo* fi = nullptr;
+    AVS_Clip* clip = avs_new_c_filter(env, &fi, avs_array_elt(args, A_CLIP), 1);  // ref :679
+    AVS_VideoInfo* vi = &fi->vi;
+    auto fail = [&](const char* msg) {  // ref :682-687
+        avs_release_clip(clip);
+        return avs_new_value_error(msg);
+    };
+
+    // AviSynth+ interface 9.2 (r3688) or later, ref :689-698
+    static const char kTooOld[] = "JincResize: AviSynth+ version must be r3688 or later.";
+    if (avs_check_version(env, 9) != 0) return fail(kTooOld);
+    if (avs_check_version(env, 10) != 0 && avs_get_env_property(env, AVS_AEP_INTERFACE_BUGFIX) < 2) return fail(kTooOld);
+
+    jinc_video_info jvi;
+    std::memset(&jvi, 0, sizeof jvi);
+    jvi.width = vi->width;
+    jvi.height = vi->height;
+    jvi.bits_per_component = avs_bits_per_component(vi);
+    jvi.component_size = avs_component_size(vi);
+    jvi.num_components = avs_num_components(vi);
+    jvi.is_planar = avs_is_planar(vi) ? 1 : 0;
+    jvi.is_rgb = avs_is_rgb(vi) ? 1 : 0;
+    const bool has_chroma = jvi.is_planar && !jvi.is_rgb && jvi.num_components > 1;
+    jvi.sub_w = has_chroma ? avs_get_plane_width_subsampling(vi, AVS_PLANAR_U) : 0;    // ref :833
+    jvi.sub_h = has_chroma ? avs_get_plane_height_subsampling(vi, AVS_PLANAR_U) : 0;   // ref :834
+
+    jinc_args a;
+    std::memset(&a, 0, sizeof a);
+    auto given = [&](int idx, unsigned bit) {
+        const bool d = avs_defined(avs_array_elt(args, idx)) != 0;
+        if (d) a.defined |= bit;
+        return d;
+    };
+    a.target_width = avs_as_int(avs_array_elt(args, A_WIDTH));
+    a.target_height = avs_as_int(avs_array_elt(args, A_HEIGHT));
+    if (given(A_SRC_LEFT, JINC_ARG_SRC_LEFT)) a.src_left = avs_as_float(avs_array_elt(args, A_SRC_LEFT));
+    if (given(A_SRC_TOP, JINC_ARG_SRC_TOP)) a.src_top = avs_as_float(avs_array_elt(args, A_SRC_TOP));
+    if (given(A_SRC_WIDTH, JINC_ARG_SRC_WIDTH)) a.src_width = avs_as_float(avs_array_elt(args, A_SRC_WIDTH));
+    if (given(A_SRC_HEIGHT, JINC_ARG_SRC_HEIGHT)) a.src_height = avs_as_float(avs_array_elt(args, A_SRC_HEIGHT));
+    if (given(A_QUANT_X, JINC_ARG_QUANT_X)) a.quant_x = avs_as_int(avs_array_elt(args, A_QUANT_X));
+    if (given(A_QUANT_Y, JINC_ARG_QUANT_Y)) a.quant_y = avs_as_int(avs_array_elt(args, A_QUANT_Y));
+    if (given(A_TAP, JINC_ARG_TAP)) a.tap = avs_as_int(avs_array_elt(args, A_TAP));
+    if (given(A_BLUR, JINC_ARG_BLUR)) a.blur = avs_as_float(avs_array_elt(args, A_BLUR));
+    if (given(A_CPLACE, JINC_ARG_CPLACE)) a.cplace = avs_as_string(avs_array_elt(args, A_CPLACE));
+    if (given(A_THREADS, JINC_ARG_THREADS)) a.threads = avs_as_int(avs_array_elt(args, A_THREADS));
+    if (given(A_OPT, JINC_ARG_OPT)) a.opt = avs_as_int(avs_array_elt(args, A_OPT));
+    if (given(A_INITIAL_CAPACITY, JINC_ARG_INITIAL_CAPACITY)) a.initial_capacity = avs_as_int(avs_array_elt(args, A_INITIAL_CAPACITY));
+    if (given(A_INITIAL_FACTOR, JINC_ARG_INITIAL_FACTOR)) a.initial_factor = avs_as_float(avs_array_elt(args, A_INITIAL_FACTOR));
+
+    // cplace not given: the first frame's _ChromaLocation decides (ref :727-742); the ABI applies the rules
+    a.frame0_chroma_location = -1;
+    if (!(a.defined & JINC_ARG_CPLACE) && jvi.is_planar) {
+        // (the reference asks the new filter's clip, whose get_frame is still unset and passes through to the child)
+        if (AVS_VideoFrame* frame0 = avs_get_frame(fi->child, 0)) {
+            const AVS_Map* props = avs_get_frame_props_ro(env, frame0);
+            if (avs_prop_get_type(env, props, "_ChromaLocation") == 'i')
+                a.frame0_chroma_location = static_cast<int>(avs_prop_get_int(env, props, "_ChromaLocation", 0, nullptr));
+            avs_release_video_frame(frame0);
+        }
+    }
+    const int cpu = avs_get_cpu_flags(env);  // ref :748: opt = 1/2/3 are validated against the host CPU as before
+    a.cpu_has_sse41 = (cpu & AVS_CPUF_SSE4_1) != 0;
+    a.cpu_has_avx2 = (cpu & AVS_CPUF_AVX2) != 0;
+    a.cpu_has_avx512f = (cpu & AVS_CPUF_AVX512F) != 0;
+
+    // The message of a failed create must outlive this call (the host reads it from the returned value).
+    static thread_local char err[512];
+    jinc_filter* filter = nullptr;
+    // round-robin over the node's GPUs: AviSynth creates one instance per worker thread (Prefetch(N))
+    if (jinc_filter_create(&jvi, &a, jinc_pick_device(), &filter, err, sizeof err) != JINC_OK) return fail(err);
+
+    Instance* inst = new Instance;
+    inst->filter = filter;
+    inst->chroma_location = jinc_filter_chroma_location(filter);
+    if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(8, std::atoi(e)));
+    if (inst->lookahead > 1) {
+        const char* reg = std::getenv("JINCRESIZE_PIN_FRAMES");
+        if (jinc_filter_set_pipeline(filter, inst->lookahead, reg && std::atoi(reg) != 0) != JINC_OK) inst->lookahead = 1;
+        inst->ring.resize(static_cast<size_t>(inst->lookahead));
+    }
+
+    jinc_video_info out_vi;
+    jinc_filter_output_info(filter, &out_vi);  // ref :791-792
+    vi->width = out_vi.width;
+    vi->height = out_vi.height;
+    fi->user_data = inst;
+    fi->get_frame = jinc_get_frame;              // ref :977
+    fi->set_cache_hints = jinc_set_cache_hints;  // ref :978
+    fi->free_filter = jinc_free;                 // ref :979
+    AVS_Value v = avs_new_value_clip(clip);      // ref :974
+    avs_release_clip(clip);                      // ref :981
+    return v;
+}
+
+// Jinc36Resize / Jinc64Resize / Jinc144Resize / Jinc256Resize: the arguments that are defined travel by name, plus
+// tap = 3 / 4 / 6 / 8, into JincResize (ref :1007-1040).
+AVS_Value AVSC_CC create_alias(AVS_ScriptEnvironment* env, AVS_Value args, void* param) {
+    static const char* const kNames[8] = {"src_left", "src_top", "src_width", "src_height", "quant_x", "quant_y", "cplace", "threads"};
+    AVS_Value values[12];
+    const char* names[12];
+    int n = 0;
+    for (int i = 0; i < 3; ++i) values[n] = avs_array_elt(args, i), names[n++] = nullptr;  // clip, width, height
+    for (int i = 0; i < 8; ++i) {
+        const AVS_Value v = avs_array_elt(args, 3 + i);
+        if (avs_defined(v)) values[n] = v, names[n++] = kNames[i];
+    }
+    values[n] = avs_new_value_int(static_cast<int>(reinterpret_cast<intptr_t>(param)));
+    names[n++] = "tap";
+    return avs_invoke(env, "JincResize", avs_new_value_array(values, n), names);
+}
+
+}  // namespace
+
+extern "C" AVSC_EXPORT const char* AVSC_CC avisynth_c_plugin_init(AVS_ScriptEnvironment* env) {
+    avs_add_function(env, "JincResize",
+                     "cii[src_left]f[src_top]f[src_width]f[src_height]f[quant_x]i[quant_y]i[tap]i[blur]f[cplace]s[threads]i[opt]i"
+                     "[initial_capacity]i[initial_factor]f",
+                     create_jincresize, nullptr);
+    static const char kAliasParams[] = "cii[src_left]f[src_top]f[src_width]f[src_height]f[quant_x]i[quant_y]i[cplace]s[threads]i";
+    static const struct { const char* name; intptr_t taps; } kAliases[] = {
+        {"Jinc36Resize", 3}, {"Jinc64Resize", 4}, {"Jinc144Resize", 6}, {"Jinc256Resize", 8}};
+    for (const auto& al : kAliases) avs_add_function(env, al.name, kAliasParams, create_alias, reinterpret_cast<void*>(al.taps));
+    return "JincResize";
+}

@@ -1,0 +1,341 @@
+// tests/mock_avs/mock_host.cpp -- TEST INFRASTRUCTURE ONLY: a miniature AviSynth-like host that implements the API
+// subset declared in tests/mock_avs/avisynth_c.h, plus a plain C interface (mock_*) through which
+// tests/test_plugin_mock_host.py loads plugin/jincresize_avs.cpp, invokes its script functions with positional and
+// named arguments, pulls frames and reads frame properties.  See the header for what this does and does not prove.
+#include "avisynth_c.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct AVS_Map {
+    std::map<std::string, int64_t> ints;
+};
+
+struct AVS_VideoFrame {
+    int refs = 1;
+    AVS_ScriptEnvironment* counted_by = nullptr;  // frames made by avs_new_video_frame_p are counted while alive
+    int nplanes = 0;
+    int plane_id[4] = {0, 0, 0, 0};
+    int pitch[4] = {0, 0, 0, 0}, row_size[4] = {0, 0, 0, 0}, height[4] = {0, 0, 0, 0};
+    std::vector<unsigned char> data[4];
+    AVS_Map props;
+};
+
+struct Function {
+    std::string name, params;
+    AVS_ApplyFunc apply;
+    void* user_data;
+};
+
+struct AVS_ScriptEnvironment {
+    int interface_version = 10, interface_bugfix = 0;
+    int cpu_flags = AVS_CPUF_SSE4_1 | AVS_CPUF_AVX2;
+    std::vector<Function> functions;
+    std::vector<std::unique_ptr<std::vector<AVS_Value>>> arg_arrays;  // storage of positional arrays built by avs_invoke
+    long live_frames = 0, live_clips = 0;
+};
+
+struct AVS_Clip {
+    int refs = 1;
+    AVS_ScriptEnvironment* env = nullptr;
+    AVS_VideoInfo vi{};
+    // source clip
+    std::vector<std::unique_ptr<AVS_VideoFrame>> frames;
+    int get_frame_calls = 0;
+    // filter clip
+    std::unique_ptr<AVS_FilterInfo> fi;
+};
+
+namespace {
+
+int frame_plane(const AVS_VideoFrame* f, int plane) {
+    for (int i = 0; i < f->nplanes; ++i)
+        if (f->plane_id[i] == plane) return i;
+    return -1;
+}
+
+AVS_VideoFrame* make_frame(const AVS_VideoInfo* vi, int pitch_align) {
+    static const int yuv[4] = {AVS_PLANAR_Y, AVS_PLANAR_U, AVS_PLANAR_V, AVS_PLANAR_A};
+    static const int rgb[4] = {AVS_PLANAR_G, AVS_PLANAR_B, AVS_PLANAR_R, AVS_PLANAR_A};
+    auto* f = new AVS_VideoFrame;
+    f->nplanes = vi->mock_num_components;
+    for (int i = 0; i < f->nplanes; ++i) {
+        const bool chroma = !vi->mock_rgb && (i == 1 || i == 2);
+        const int w = chroma ? vi->width >> vi->mock_sub_w : vi->width;
+        const int h = chroma ? vi->height >> vi->mock_sub_h : vi->height;
+        f->plane_id[i] = (vi->mock_rgb ? rgb : yuv)[i];
+        f->row_size[i] = w * vi->mock_component_size;
+        f->pitch[i] = (f->row_size[i] + pitch_align - 1) / pitch_align * pitch_align;
+        f->height[i] = h;
+        f->data[i].assign(static_cast<size_t>(f->pitch[i]) * h + 64, 0xCD);
+    }
+    return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+AVS_Value avs_new_value_clip(AVS_Clip* clip) {
+    AVS_Value v;
+    v.type = 'c';
+    v.array_size = 0;
+    v.d.clip = clip;
+    ++clip->refs;
+    return v;
+}
+
+int avs_is_planar(const AVS_VideoInfo* vi) { return vi->mock_planar; }
+int avs_is_rgb(const AVS_VideoInfo* vi) { return vi->mock_rgb; }
+int avs_bits_per_component(const AVS_VideoInfo* vi) { return vi->mock_bits; }
+int avs_component_size(const AVS_VideoInfo* vi) { return vi->mock_component_size; }
+int avs_num_components(const AVS_VideoInfo* vi) { return vi->mock_num_components; }
+int avs_get_plane_width_subsampling(const AVS_VideoInfo* vi, int plane) {
+    return (plane == AVS_PLANAR_U || plane == AVS_PLANAR_V) ? vi->mock_sub_w : 0;
+}
+int avs_get_plane_height_subsampling(const AVS_VideoInfo* vi, int plane) {
+    return (plane == AVS_PLANAR_U || plane == AVS_PLANAR_V) ? vi->mock_sub_h : 0;
+}
+
+int avs_check_version(AVS_ScriptEnvironment* env, int version) { return env->interface_version >= version ? 0 : -1; }
+int64_t avs_get_env_property(AVS_ScriptEnvironment* env, int prop) {
+    if (prop == AVS_AEP_INTERFACE_BUGFIX) return env->interface_bugfix;
+    if (prop == AVS_AEP_INTERFACE_VERSION) return env->interface_version;
+    return 0;
+}
+int avs_get_cpu_flags(AVS_ScriptEnvironment* env) { return env->cpu_flags; }
+
+int avs_add_function(AVS_ScriptEnvironment* env, const char* name, const char* params, AVS_ApplyFunc apply, void* user_data) {
+    env->functions.push_back({name, params, apply, user_data});
+    return 0;
+}
+
+// Resolves positional + named arguments against the function's parameter string ("cii[src_left]f...") into the
+// positional array the apply function indexes, with void values for what was not given; type letters are checked.
+AVS_Value avs_invoke(AVS_ScriptEnvironment* env, const char* name, AVS_Value args, const char** arg_names) {
+    const Function* fn = nullptr;
+    for (const Function& f : env->functions)
+        if (f.name == name) fn = &f;
+    if (!fn) return avs_new_value_error("mock host: no such function");
+    struct Param {
+        std::string name;
+        char type;
+    };
+    std::vector<Param> params;
+    for (const char* p = fn->params.c_str(); *p;) {
+        Param q;
+        if (*p == '[') {
+            const char* e = std::strchr(p, ']');
+            q.name.assign(p + 1, e);
+            p = e + 1;
+        }
+        q.type = *p++;
+        params.push_back(q);
+    }
+    auto arr = std::make_unique<std::vector<AVS_Value>>(params.size());
+    for (AVS_Value& v : *arr) v.type = 'v', v.array_size = 0, v.d.clip = nullptr;
+    const int n = args.type == 'a' ? args.array_size : 1;
+    size_t pos = 0;
+    for (int i = 0; i < n; ++i) {
+        const AVS_Value v = avs_array_elt(args, i);
+        size_t slot = params.size();
+        if (arg_names && arg_names[i]) {
+            for (size_t k = 0; k < params.size(); ++k)
+                if (params[k].name == arg_names[i]) slot = k;
+            if (slot == params.size()) return avs_new_value_error("mock host: function does not have a named argument of that name");
+        } else {
+            slot = pos++;
+            if (slot >= params.size()) return avs_new_value_error("mock host: too many arguments");
+        }
+        const char t = params[slot].type;
+        const bool ok = (t == 'c' && v.type == 'c') || (t == 'i' && v.type == 'i') || (t == 'f' && (v.type == 'f' || v.type == 'i')) ||
+                        (t == 's' && v.type == 's') || (t == 'b' && v.type == 'b');
+        if (!ok) return avs_new_value_error("mock host: invalid arguments to function");
+        (*arr)[slot] = v;
+    }
+    for (size_t k = 0; k < params.size(); ++k)
+        if (params[k].name.empty() && (*arr)[k].type == 'v') return avs_new_value_error("mock host: missing positional argument");
+    AVS_Value positional = avs_new_value_array(arr->data(), static_cast<int>(arr->size()));
+    env->arg_arrays.push_back(std::move(arr));
+    return fn->apply(env, positional, fn->user_data);
+}
+
+AVS_Clip* avs_new_c_filter(AVS_ScriptEnvironment* env, AVS_FilterInfo** fi, AVS_Value child, int store_child) {
+    auto* clip = new AVS_Clip;
+    clip->env = env;
+    clip->fi = std::make_unique<AVS_FilterInfo>();
+    std::memset(clip->fi.get(), 0, sizeof(AVS_FilterInfo));
+    AVS_Clip* c = static_cast<AVS_Clip*>(child.d.clip);
+    clip->fi->child = c;
+    if (store_child) ++c->refs;
+    clip->fi->vi = c->vi;
+    clip->fi->env = env;
+    clip->vi = c->vi;
+    *fi = clip->fi.get();
+    ++env->live_clips;
+    return clip;
+}
+
+void avs_release_clip(AVS_Clip* clip) {
+    if (!clip || --clip->refs > 0) return;
+    if (clip->fi) {
+        if (clip->fi->free_filter) clip->fi->free_filter(clip->fi.get());
+        avs_release_clip(clip->fi->child);
+    }
+    --clip->env->live_clips;
+    delete clip;
+}
+
+AVS_VideoFrame* avs_get_frame(AVS_Clip* clip, int n) {
+    if (clip->fi) {
+        clip->vi = clip->fi->vi;
+        // a C filter without a get_frame callback passes the request through to its child
+        return clip->fi->get_frame ? clip->fi->get_frame(clip->fi.get(), n) : avs_get_frame(clip->fi->child, n);
+    }
+    ++clip->get_frame_calls;
+    if (n < 0 || n >= static_cast<int>(clip->frames.size())) return nullptr;
+    ++clip->frames[n]->refs;  // the source keeps its own reference
+    return clip->frames[n].get();
+}
+
+AVS_VideoFrame* avs_new_video_frame_p(AVS_ScriptEnvironment* env, const AVS_VideoInfo* vi, const AVS_VideoFrame* prop_src) {
+    AVS_VideoFrame* f = make_frame(vi, 64);
+    if (prop_src) f->props = prop_src->props;
+    f->counted_by = env;
+    ++env->live_frames;
+    return f;
+}
+
+void avs_release_video_frame(AVS_VideoFrame* frame) {
+    if (!frame) return;
+    if (--frame->refs > 0) return;  // source-owned frames never reach 0 here (the clip holds one reference)
+    if (frame->counted_by) --frame->counted_by->live_frames;
+    delete frame;
+}
+
+int avs_get_pitch_p(const AVS_VideoFrame* f, int plane) { const int i = frame_plane(f, plane); return i < 0 ? 0 : f->pitch[i]; }
+int avs_get_row_size_p(const AVS_VideoFrame* f, int plane) { const int i = frame_plane(f, plane); return i < 0 ? 0 : f->row_size[i]; }
+int avs_get_height_p(const AVS_VideoFrame* f, int plane) { const int i = frame_plane(f, plane); return i < 0 ? 0 : f->height[i]; }
+const unsigned char* avs_get_read_ptr_p(const AVS_VideoFrame* f, int plane) {
+    const int i = frame_plane(f, plane);
+    return i < 0 ? nullptr : f->data[i].data();
+}
+unsigned char* avs_get_write_ptr_p(const AVS_VideoFrame* f, int plane) {
+    const int i = frame_plane(f, plane);
+    return i < 0 ? nullptr : const_cast<unsigned char*>(f->data[i].data());
+}
+
+const AVS_Map* avs_get_frame_props_ro(AVS_ScriptEnvironment*, const AVS_VideoFrame* frame) { return &frame->props; }
+AVS_Map* avs_get_frame_props_rw(AVS_ScriptEnvironment*, AVS_VideoFrame* frame) { return &frame->props; }
+char avs_prop_get_type(AVS_ScriptEnvironment*, const AVS_Map* map, const char* key) { return map->ints.count(key) ? 'i' : 'u'; }
+int64_t avs_prop_get_int(AVS_ScriptEnvironment*, const AVS_Map* map, const char* key, int, int* error) {
+    auto it = map->ints.find(key);
+    if (error) *error = it == map->ints.end();
+    return it == map->ints.end() ? 0 : it->second;
+}
+int avs_prop_set_int(AVS_ScriptEnvironment*, AVS_Map* map, const char* key, int64_t value, int) {
+    map->ints[key] = value;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C interface for the Python tests
+// ---------------------------------------------------------------------------------------------------------------
+const char* avisynth_c_plugin_init(AVS_ScriptEnvironment* env);  // the plugin under test, linked into this library
+
+#define MOCK_API __attribute__((visibility("default")))
+
+MOCK_API AVS_ScriptEnvironment* mock_env_new(int interface_version, int interface_bugfix, int cpu_flags) {
+    auto* env = new AVS_ScriptEnvironment;
+    env->interface_version = interface_version;
+    env->interface_bugfix = interface_bugfix;
+    if (cpu_flags >= 0) env->cpu_flags = cpu_flags;
+    return env;
+}
+MOCK_API void mock_env_free(AVS_ScriptEnvironment* env) { delete env; }
+MOCK_API const char* mock_load_plugin(AVS_ScriptEnvironment* env) { return avisynth_c_plugin_init(env); }
+MOCK_API int mock_function_count(AVS_ScriptEnvironment* env) { return static_cast<int>(env->functions.size()); }
+MOCK_API const char* mock_function_name(AVS_ScriptEnvironment* env, int i) { return env->functions[i].name.c_str(); }
+MOCK_API const char* mock_function_params(AVS_ScriptEnvironment* env, int i) { return env->functions[i].params.c_str(); }
+MOCK_API long mock_live_frames(AVS_ScriptEnvironment* env) { return env->live_frames; }
+MOCK_API long mock_live_clips(AVS_ScriptEnvironment* env) { return env->live_clips; }
+
+// A source clip of `num_frames` frames whose planes the test fills through mock_source_plane.
+// chroma_location >= 0 attaches the int property _ChromaLocation to every frame.
+MOCK_API AVS_Clip* mock_source_new(AVS_ScriptEnvironment* env, int width, int height, int bits, int component_size, int num_components,
+                                   int planar, int rgb, int sub_w, int sub_h, int num_frames, int chroma_location, int pitch_align) {
+    auto* clip = new AVS_Clip;
+    clip->env = env;
+    AVS_VideoInfo& vi = clip->vi;
+    std::memset(&vi, 0, sizeof vi);
+    vi.width = width, vi.height = height, vi.fps_numerator = 24, vi.fps_denominator = 1, vi.num_frames = num_frames;
+    vi.mock_bits = bits, vi.mock_component_size = component_size, vi.mock_num_components = num_components;
+    vi.mock_planar = planar, vi.mock_rgb = rgb, vi.mock_sub_w = sub_w, vi.mock_sub_h = sub_h;
+    for (int n = 0; n < num_frames; ++n) {
+        clip->frames.emplace_back(make_frame(&vi, pitch_align > 0 ? pitch_align : 64));
+        if (chroma_location >= 0) clip->frames.back()->props.ints["_ChromaLocation"] = chroma_location;
+    }
+    ++env->live_clips;
+    return clip;
+}
+MOCK_API unsigned char* mock_frame_plane(AVS_VideoFrame* f, int index, int* pitch, int* row_size, int* height) {
+    if (index < 0 || index >= f->nplanes) return nullptr;
+    *pitch = f->pitch[index], *row_size = f->row_size[index], *height = f->height[index];
+    return f->data[index].data();
+}
+MOCK_API AVS_VideoFrame* mock_source_frame(AVS_Clip* clip, int n) { return clip->frames[n].get(); }
+MOCK_API int mock_source_get_frame_calls(AVS_Clip* clip) { return clip->get_frame_calls; }
+
+// Invokes a script function: positional (clip, width, height) + named arguments.
+// kinds[i]: 'i' -> ivals[i], 'f' -> fvals[i], 's' -> svals[i].  Returns a heap AVS_Value (mock_value_free).
+MOCK_API AVS_Value* mock_invoke(AVS_ScriptEnvironment* env, const char* function, AVS_Clip* clip, int width, int height, int nnamed,
+                                const char** names, const char* kinds, const int* ivals, const double* fvals, const char** svals) {
+    std::vector<AVS_Value> vals;
+    std::vector<const char*> nm;
+    AVS_Value c;
+    c.type = 'c', c.array_size = 0, c.d.clip = clip;
+    vals.push_back(c), nm.push_back(nullptr);
+    vals.push_back(avs_new_value_int(width)), nm.push_back(nullptr);
+    vals.push_back(avs_new_value_int(height)), nm.push_back(nullptr);
+    for (int i = 0; i < nnamed; ++i) {
+        if (kinds[i] == 'i') vals.push_back(avs_new_value_int(ivals[i]));
+        else if (kinds[i] == 'f') vals.push_back(avs_new_value_float(static_cast<float>(fvals[i])));
+        else vals.push_back(avs_new_value_string(svals[i]));
+        nm.push_back(names[i]);
+    }
+    auto* out = new AVS_Value(avs_invoke(env, function, avs_new_value_array(vals.data(), static_cast<int>(vals.size())), nm.data()));
+    return out;
+}
+MOCK_API const char* mock_value_error(const AVS_Value* v) { return v->type == 'e' ? v->d.string : nullptr; }
+MOCK_API AVS_Clip* mock_value_clip(const AVS_Value* v) { return v->type == 'c' ? static_cast<AVS_Clip*>(v->d.clip) : nullptr; }
+MOCK_API void mock_value_free(AVS_Value* v) { delete v; }
+
+MOCK_API void mock_clip_info(AVS_Clip* clip, int* width, int* height, int* num_frames) {
+    const AVS_VideoInfo& vi = clip->fi ? clip->fi->vi : clip->vi;
+    *width = vi.width, *height = vi.height, *num_frames = vi.num_frames;
+}
+MOCK_API AVS_VideoFrame* mock_clip_get_frame(AVS_Clip* clip, int n) { return avs_get_frame(clip, n); }
+MOCK_API const char* mock_clip_error(AVS_Clip* clip) { return clip->fi ? clip->fi->error : nullptr; }
+MOCK_API int mock_clip_mt_mode(AVS_Clip* clip) {
+    return clip->fi && clip->fi->set_cache_hints ? clip->fi->set_cache_hints(clip->fi.get(), AVS_CACHE_GET_MTMODE, 0) : -1;
+}
+MOCK_API void mock_clip_release(AVS_Clip* clip) { avs_release_clip(clip); }
+MOCK_API void mock_source_release(AVS_Clip* clip) {
+    if (--clip->refs > 0) return;
+    --clip->env->live_clips;
+    delete clip;
+}
+MOCK_API int mock_frame_prop_int(AVS_VideoFrame* f, const char* key, long long* value) {
+    auto it = f->props.ints.find(key);
+    if (it == f->props.ints.end()) return 0;
+    *value = it->second;
+    return 1;
+}
+MOCK_API void mock_frame_release(AVS_VideoFrame* f) { avs_release_video_frame(f); }
+
+}  // extern "C"
