@@ -62,6 +62,7 @@ struct DeviceTable {
     jinc::ColStripArgs col_strips;
     jinc::RectList corner_rects;  // ... then only the corners are left for the gather kernel
     jinc::RectList column_rects;  // otherwise: left / right columns, full height, on the gather kernel
+    std::vector<void*> lane_blobs;  // lane-major coefficient copies of the private-set rectangles (RectList::lane_coeffs)
     jinc::RectList whole;         // gather work when it does not
 };
 
@@ -120,8 +121,10 @@ struct jinc_filter {
     ~jinc_filter() {
         if (device >= 0) {
             (void)hipSetDevice(device);
-            for (auto& t : tables)
+            for (auto& t : tables) {
                 if (t.blob) (void)hipFree(t.blob);
+                for (void* b : t.lane_blobs) (void)hipFree(b);
+            }
             for (size_t s = 0; s < slots.size(); ++s) {
                 for (int i = 0; i < 4; ++i) {
                     if (slots[s].src[i]) (void)hipFree(slots[s].src[i]);
@@ -450,7 +453,7 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     qa.n_col_classes = p.n_col_classes;
     qa.n_row_classes = p.n_row_classes;
     qa.px = px, qa.py = py, qa.sx = sx, qa.sy = sy;
-    qa.exact = p.periodic ? 1 : 0;
+    qa.exact = p.periodic ? 1 : 2;  // 1: one set per phase; 2: drifting classes, per-lane coefficient registers
     qa.ix0 = p.ix0, qa.iy0 = p.iy0;
     qa.ni = (p.ix1 - p.ix0) / px;
     qa.nj = (p.iy1 - p.iy0) / py;
@@ -468,7 +471,7 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     }
     qa.min_sx = min_sx, qa.min_sy = min_sy;
     qa.src_w = p.g.src_w, qa.src_h = p.g.src_h, qa.dst_h = p.g.dst_h;
-    if (qa.exact)
+    if (p.periodic)
         for (int q = 0; q < py; ++q)
             for (int r = 0; r < px; ++r)
                 qa.phase_set[q * px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
@@ -572,6 +575,50 @@ uint32_t direct_src_bytes(const void* base, uint64_t plane_bytes) {
     return static_cast<uint32_t>((mis + plane_bytes + 3) & ~3ull);
 }
 
+// Rectangles whose pixels own private coefficient sets (border frame of drifting plans, corners of periodic plans):
+// a lane-major copy of exactly those coefficients, in the gather kernel's item order, turns its per-lane coefficient
+// fetches (64 cache lines per wave and fetch) into contiguous ones.  See RectList::lane_coeffs.
+void attach_lane_coeffs(const jinc::PlanePlan& p, DeviceTable& t, jinc::RectList& rects, hipStream_t stream) {
+    if (!rects.private_sets || rects.n <= 0) return;
+    const int fs = p.fs, fsp = (p.fs + 3) & ~3;
+    const size_t item_floats = static_cast<size_t>(fs) * fsp * 64;
+    long long total = 0;
+    for (int r = 0; r < rects.n; ++r) {
+        int axis, P;
+        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], axis, P);
+        rects.lane_item_base[r] = total;
+        total += jinc::gather_item_count(rects.w[r], rects.h[r], axis, P);
+    }
+    if (total <= 0 || static_cast<unsigned long long>(total) * item_floats * sizeof(float) > (512ull << 20)) return;
+    std::vector<float> buf(static_cast<size_t>(total) * item_floats, 0.f);
+    for (int r = 0; r < rects.n; ++r) {
+        int axis, P;
+        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], axis, P);
+        const int along = axis == 0 ? rects.w[r] : rects.h[r], across = axis == 0 ? rects.h[r] : rects.w[r];
+        const int blocks = (along + 64 * P - 1) / (64 * P);
+        for (int line = 0; line < across; ++line)
+            for (int res = 0; res < P; ++res)
+                for (int ba = 0; ba < blocks; ++ba) {
+                    float* item = buf.data() + static_cast<size_t>(rects.lane_item_base[r] + static_cast<long long>(line * P + res) * blocks + ba) * item_floats;
+                    for (int l = 0; l < 64; ++l) {
+                        const int coord = ba * 64 * P + P * l + res;
+                        if (coord >= along) break;
+                        const int x = rects.x0[r] + (axis == 0 ? coord : line), y = rects.y0[r] + (axis == 0 ? line : coord);
+                        const float* src = p.set_ptr(p.set_of(x, y));
+                        for (int ly = 0; ly < fs; ++ly)
+                            for (int lx = 0; lx < fs; ++lx)
+                                item[((static_cast<size_t>(ly) * (fsp / 4) + lx / 4) * 64 + l) * 4 + lx % 4] = src[ly * fs + lx];
+                    }
+                }
+    }
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, buf.size() * sizeof(float)), "hipMalloc(lane-major coefficients)");
+    t.lane_blobs.push_back(dev);
+    hip_check(hipMemcpyAsync(dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, stream), "lane-major coefficient upload");
+    hip_check(hipStreamSynchronize(stream), "lane-major coefficient upload sync");
+    rects.lane_coeffs = static_cast<const float*>(dev);
+}
+
 void init_device(jinc_filter& f, int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -589,6 +636,8 @@ void init_device(jinc_filter& f, int device) {
         plan_launches(f.plans[i], f.tables[i]);
         plan_quasi(f.plans[i], f.tables[i]);
         plan_direct(f.plans[i], f.tables[i]);
+        attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].border_rects, f.stream);
+        attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].corner_rects, f.stream);
     }
 }
 
@@ -644,10 +693,10 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
     // kernel wherever it applies (also for exactly periodic plans)
     auto wants_quasi = [&](const DeviceTable& t) {
-        return t.use_quasi && (f.kernel_mode == 7 || f.kernel_mode == 8 || (f.kernel_mode != 1 && !t.use_periodic));
+        return t.use_quasi && (f.kernel_mode == 7 || f.kernel_mode == 8 || f.kernel_mode == 10 || (f.kernel_mode != 1 && !t.use_periodic));
     };
     auto wants_periodic = [&](const DeviceTable& t) {
-        return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8;
+        return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8 && f.kernel_mode != 10;
     };
     // Is kernel_direct.hip usable for plane i (interior and border strips)?  See direct_fetch_is_safe().
     auto direct_ok = [&](const DeviceTable& t, int i) {
@@ -747,7 +796,8 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             else if (quasi)
                 timed(f.ev_periodic, stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
                     jinc::QuasiArgs qa = t.quasi;
-                    if (f.kernel_mode == 8) qa.exact = 0;  // A/B: per-row lookup variant on an exactly periodic plan
+                    if (f.kernel_mode == 8) qa.exact = 0;   // A/B: per-row lookup + waterfall over sets in SGPRs
+                    if (f.kernel_mode == 10) qa.exact = 2;  // A/B: per-row lookup + per-lane coefficient registers
                     return jinc::launch_quasi(qa, t.plan.fs, io, s);
                 });
             else
@@ -1109,8 +1159,8 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
     if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return "";
     const DeviceTable& t = f->tables[table];
     const int m = f->kernel_mode;
-    const bool quasi = t.use_quasi && (m == 7 || m == 8 || (m != 1 && !t.use_periodic));
-    const bool periodic = t.use_periodic && m != 1 && m != 7 && m != 8;
+    const bool quasi = t.use_quasi && (m == 7 || m == 8 || m == 10 || (m != 1 && !t.use_periodic));
+    const bool periodic = t.use_periodic && m != 1 && m != 7 && m != 8 && m != 10;
     if (t.use_direct && m != 1 && (m == 9 || (!periodic && !quasi))) return "ewa_direct_kernel";
     if (quasi) return "ewa_quasi_kernel";
     if (periodic) {
@@ -1130,7 +1180,7 @@ int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 9) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 10) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

@@ -54,6 +54,28 @@ __device__ __forceinline__ float chain_runtime(float acc, const float* s_lds, in
     return acc;
 }
 
+// The same chain with the lane's private coefficients read from a lane-major copy: `c` points at the lane's first
+// group of 4 taps, consecutive groups are 256 floats apart (64 lanes x 4), a kernel row has fsp / 4 groups.
+template <typename T, bool STAGED>
+__device__ __forceinline__ float chain_lane_major(float acc, const float* s_lds, int lds_pitch, const char* s_glb, int src_pitch,
+                                                  const float* c, int fs, int fsp) {
+    for (int ly = 0; ly < fs; ++ly) {
+        const T* g = reinterpret_cast<const T*>(s_glb);
+        for (int lx = 0; lx < fs; lx += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(c);
+            const float cf[4] = {v.x, v.y, v.z, v.w};
+            const int n = fs - lx;  // wave-uniform
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (t < n) acc = acc + (STAGED ? s_lds[lx + t] : to_float(g[lx + t])) * cf[t];
+            c += 256;
+        }
+        s_lds += lds_pitch;
+        s_glb += src_pitch;
+    }
+    return acc;
+}
+
 // Any plan.  A block covers 64*P coordinates along the lane axis x 4..32 lines; its source footprint is
 // staged once in LDS as fp32.  Work items = (line, residue): the 64 lanes of an item are P apart, P
 // being the plan's dominant phase period, so that (nearly) all lanes of an item share one coefficient
@@ -113,6 +135,8 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
         const int y = axis == 0 ? by0 + line : by0 + P * lane + res;
         const bool active = x <= bx1 && y <= by1;
         if (!__builtin_amdgcn_readfirstlane(__ballot(active) != 0)) continue;
+        // number of this item in the rectangle's lane-major coefficient copy (see gather_item_count in kernels.h)
+        const long long lane_item = a.rects.lane_item_base[r] + static_cast<long long>((bl * nlines + line) * P + res) * a.blocks_a[r] + ba;
 
         // Inactive lanes (block overhang) look up the block's first pixel so every address stays in range.
         const int qx = active ? x : bx0, qy = active ? y : by0;
@@ -171,20 +195,25 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
                     todo &= ~__ballot(mine);
                 }
                 if (todo) {
+                    // private sets: 16-byte per-lane coefficient loads -- from the lane-major copy when the host
+                    // built one (consecutive lanes, consecutive addresses), else from the lane's own set
+                    const bool lane_major = a.rects.lane_coeffs != nullptr;  // wave-uniform
+                    const float* c = lane_major ? a.rects.lane_coeffs + static_cast<size_t>(lane_item) * (FS * padded_row(FS) * 64) + 4 * lane
+                                                : p.coeffs + static_cast<size_t>(set) * (FS * padded_row(FS));
+                    const int cstep = lane_major ? 256 : 4;  // floats between a lane's consecutive groups of 4 taps
                     if (active && ((todo >> lane) & 1ull)) {
-                        const float* c = p.coeffs + static_cast<size_t>(set) * (FS * padded_row(FS));
                         const float* sr = s;
                         for (int ly = 0; ly < FS; ++ly) {
                             float cr[padded_row(FS)];
 #pragma unroll
-                            for (int k = 0; k < padded_row(FS) / 4; ++k) {  // 16-byte per-lane coefficient loads
-                                const float4 v = *reinterpret_cast<const float4*>(c + 4 * k);
+                            for (int k = 0; k < padded_row(FS) / 4; ++k) {
+                                const float4 v = *reinterpret_cast<const float4*>(c + cstep * k);
                                 cr[4 * k] = v.x, cr[4 * k + 1] = v.y, cr[4 * k + 2] = v.z, cr[4 * k + 3] = v.w;
                             }
 #pragma unroll
                             for (int lx = 0; lx < FS; ++lx) acc = acc + sr[lx] * cr[lx];
                             sr += pitch;
-                            c += padded_row(FS);
+                            c += cstep * (padded_row(FS) / 4);
                         }
                     }
                 }
@@ -211,11 +240,19 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
                 todo &= ~__ballot(mine);
             }
             if (active && ((todo >> lane) & 1ull)) {  // private sets: per-lane coefficient loads
-                const float* c = p.coeffs + static_cast<size_t>(set) * fs * fsp;
-                if (staged)
-                    acc = chain_runtime<T, true>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
-                else
-                    acc = chain_runtime<T, false>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
+                if (a.rects.lane_coeffs != nullptr) {
+                    const float* c = a.rects.lane_coeffs + static_cast<size_t>(lane_item) * (static_cast<size_t>(fs) * fsp * 64) + 4 * lane;
+                    if (staged)
+                        acc = chain_lane_major<T, true>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
+                    else
+                        acc = chain_lane_major<T, false>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
+                } else {
+                    const float* c = p.coeffs + static_cast<size_t>(set) * fs * fsp;
+                    if (staged)
+                        acc = chain_runtime<T, true>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
+                    else
+                        acc = chain_runtime<T, false>(acc, s_lds, pitch, s_glb, a.io.src_pitch, c, fs, fsp);
+                }
             }
         }
         if (active) {
@@ -297,10 +334,8 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
         ga.stride[r] = 1;
         ga.lines[r] = 4;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
-            // Narrow rectangles (border columns, up to ~fs wide) put the lanes along y: a wave is then not mostly
-            // idle, and its lanes share the border column's coefficient sets (along x every lane would own one).
-            const int axis = rects.w[r] < 64 && rects.h[r] > rects.w[r] ? 1 : 0;
-            const int P = axis == 0 ? plan.gather_period_x : plan.gather_period_y;
+            int axis, P;
+            gather_rect_layout(plan, rects.w[r], rects.h[r], axis, P);
             const int along = axis == 0 ? rects.w[r] : rects.h[r];
             const int across = axis == 0 ? rects.h[r] : rects.w[r];
             // More lines per block amortise the block's fixed cost (bounds, staging, barrier) and its halo;

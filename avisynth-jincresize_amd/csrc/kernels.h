@@ -42,7 +42,28 @@ struct RectList {
     // true for the border frame of a plan that is not exactly periodic: there nearly every pixel owns a
     // private coefficient set, so the kernel skips the uniform passes and loads coefficients per lane
     bool private_sets = false;
+    // Optional lane-major copy of the coefficients of these rectangles' pixels (private_sets only): item i of
+    // rectangle r (numbering: gather_item_index) owns fs * padded_row(fs) * 64 floats laid out
+    // [kernel row][group of 4 taps][lane][4], so the 64 lanes of an item fetch their private coefficients with
+    // contiguous 16-byte loads (1 KiB per wave and fetch) instead of touching 64 cache lines.
+    const float* lane_coeffs = nullptr;
+    long long lane_item_base[4] = {0, 0, 0, 0};
 };
+
+// How the gather kernel walks a rectangle: lane axis (0: lanes along x, 1: along y) and lane stride P; shared by
+// launch_gather and by the host code that builds RectList::lane_coeffs.
+inline void gather_rect_layout(const DevicePlan& plan, int w, int h, int& axis, int& P) {
+    // Narrow rectangles (border columns, up to ~fs wide) put the lanes along y: a wave is then not mostly
+    // idle, and its lanes share the border column's coefficient sets (along x every lane would own one).
+    axis = (w < 64 && h > w) ? 1 : 0;
+    P = axis == 0 ? plan.gather_period_x : plan.gather_period_y;
+}
+// Items of a rectangle are numbered (line * P + residue) * blocks_along + block, with line = row (axis 0) or column
+// (axis 1) inside the rectangle and blocks_along = ceil(extent along the lane axis / (64 * P)).
+inline long long gather_item_count(int w, int h, int axis, int P) {
+    const int along = axis == 0 ? w : h, across = axis == 0 ? h : w;
+    return static_cast<long long>(across) * P * ((along + 64 * P - 1) / (64 * P));
+}
 
 // Phase-periodic interior (see plan.h): output pixel (ix0 + px*i + p, iy0 + py*j + q) reads the
 // source window at (start_x[p] + i, start_y[q] + j) with coefficient set set[q*px + p].

@@ -47,6 +47,7 @@ CONFIGS = {
     "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 16),  # 1.5x with Jinc256: fs 17, drifting -> gather kernel
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 64),   # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 32),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables
+    "N15T4": ("Y8", 1280, 720, 1920, 1080, dict(tap=4), 32),  # 1.5x with Jinc64: fs 9, drifting -> quasi-periodic kernel
     "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 32),   # 1/2 down-scale: fs = 13, period 1, source step 2
     "D13": ("Y8", 3840, 2160, 1280, 720, dict(tap=3), 32),    # 1/3 down-scale: fs = 20, period 1, source step 3
     "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 16),    # Jinc144: fs = 13

@@ -220,7 +220,8 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * kernel for every pixel, 2 = periodic fast kernel where the plan allows (same as automatic),
  * 3..6 = A/B variants of the periodic kernels (row-streamed, other tile heights, packed math),
  * 7 = the quasi-periodic kernel wherever it applies (it is the automatic choice only for drifting ratios),
- * 8 = its per-row lookup variant on exactly periodic plans too, 9 = the direct (no-LDS) periodic kernel wherever
+ * 8 = its waterfall variant (coefficient sets in SGPRs, one pass per distinct set of a wave) and 10 = its per-lane
+ * coefficient variant (the default for drifting ratios) on every plan they apply to, 9 = the direct (no-LDS) periodic kernel wherever
  * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */

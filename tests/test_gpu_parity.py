@@ -299,7 +299,7 @@ QUASI_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "gather"])
+@pytest.mark.parametrize("mode", [0, 1, 8, 10], ids=["auto", "gather", "quasi_waterfall", "quasi_lane_coefficients"])
 @pytest.mark.parametrize("case", QUASI_CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
 def test_quasi_periodic_plans(gpu_pkg, O, case, mode):
     """Ratios whose phase classes drift (the reference accumulates positions in float): the plan is not
@@ -536,8 +536,9 @@ def test_device_entry_rejects_bad_layouts(gpu_pkg):
     f.close()
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 7, 8, 9],
-                         ids=["gather", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_lookup", "direct"])
+@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 7, 8, 9, 10],
+                         ids=["gather", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_waterfall", "direct",
+                              "quasi_lane_coefficients"])
 def test_every_kernel_reproduces_the_reference_crc_at_full_size(gpu_pkg, O, mode):
     """C2 at full size through every kernel family: the crc32 of the reference's own opt=0 output."""
     k = next(x for x in KAT["outputs"] if x["name"] == "C2")
