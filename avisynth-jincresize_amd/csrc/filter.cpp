@@ -58,6 +58,7 @@ struct DeviceTable {
     bool use_direct = false;      // exactly periodic, any filter size / source step (kernel_direct.hip)
     jinc::DirectArgs direct;      // interior
     jinc::DirectArgs row_strips;  // border rows of the same plan over the interior's columns (any interior kernel)
+    bool strips_ok = false;       // the border rows / columns really repeat their coefficient sets per phase (plan_direct)
     bool use_colstrip = false;    // border columns over the interior's rows on kernel_colstrip.hip
     jinc::ColStripArgs col_strips;
     jinc::RectList corner_rects;  // ... then only the corners are left for the gather kernel
@@ -552,6 +553,36 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     t.use_colstrip = jinc::colstrip_configure(ca);
     t.col_strips = ca;
 
+    // The strip kernels take ONE coefficient set per (border row, column phase) / (border column, row phase).  That
+    // holds when the border pixels' coefficients repeat with the interior's period (integer ratios, exact down-scales)
+    // -- but a plan can have a periodic interior and still private border sets: for 3/2 on a small frame the
+    // interior classes have not drifted yet, while the reference computes every border pixel's coefficients from its
+    // float-accumulated position, so no two are equal (found by the widened random sweep).  Check, do not assume.
+    bool uniform = true;
+    for (int y = 0; y < H && uniform; ++y) {
+        if (y >= p.iy0 && y < y_end) continue;
+        for (int r = 0; r < p.px && uniform; ++r) {
+            const int s0 = p.set_of(p.ix0 + r, y);
+            for (int i = 1; i < da.ni; ++i)
+                if (p.set_of(p.ix0 + p.px * i + r, y) != s0) {
+                    uniform = false;
+                    break;
+                }
+        }
+    }
+    for (int x = 0; x < W && uniform; ++x) {
+        if (x >= p.ix0 && x < x_end) continue;
+        for (int q = 0; q < p.py && uniform; ++q) {
+            const int s0 = p.set_of(x, p.iy0 + q);
+            for (int j = 1; j < da.nj; ++j)
+                if (p.set_of(x, p.iy0 + p.py * j + q) != s0) {
+                    uniform = false;
+                    break;
+                }
+        }
+    }
+    t.strips_ok = uniform;
+
     for (int q = 0; q < p.py; ++q)
         for (int r = 0; r < p.px; ++r)
             da.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
@@ -559,6 +590,7 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     t.direct = da;
     t.use_direct = true;
     if (!t.use_periodic && !t.use_quasi) t.border_rects = border_frame(p, x_end, y_end);  // fallback border (gather)
+    if (!t.strips_ok) t.border_rects.private_sets = true;  // the gather kernel then fetches coefficients per lane
 }
 
 // kernel_direct.hip fetches whole segments as naturally aligned dwords through a buffer resource that ends with the
@@ -765,7 +797,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         };
         if (direct || periodic || quasi) {
             // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
-            const bool strips = f.border_strips != 0 && direct_ok(t, i);
+            const bool strips = f.border_strips != 0 && t.strips_ok && direct_ok(t, i);
             if (strips) {
                 jinc::DirectArgs rs = t.row_strips;
                 rs.src_bytes = direct_src_bytes(

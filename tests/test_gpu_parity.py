@@ -60,6 +60,9 @@ SMALL_CASES = [
     ("RGBP8", 96, 64, 192, 128, {}),
     ("RGBAP16", 96, 64, 200, 100, {}),
     ("RGBPS", 200, 100, 400, 200, dict(tap=4, blur=0.98)),          # C4 in miniature
+    # 3/2 on a small frame: the interior classes are still exactly periodic (source step 2 -> direct kernel) while every
+    # border pixel owns a coefficient set -- the strip kernels must not be used (found by the widened random sweep)
+    ("YUV420P8", 88, 108, 132, 162, dict(tap=2, quant_x=255, quant_y=67, cplace="mpeg2")),
 ]
 
 
@@ -468,12 +471,65 @@ def _random_case(rng):
     return fmt, sw, sh, tw, th, kw
 
 
-@pytest.mark.parametrize("seed", range(48))
-def test_randomised_arguments(gpu_pkg, O, seed):
+def _random_case_v2(rng):
+    """Second generation of the sweep: larger frames (several tiles), exact down-scales (direct kernel interior),
+    taps up to 16, crops mostly absent so that the plans keep their structure."""
+    fmts = ["Y8", "Y10", "Y16", "Y32", "YUV420P8", "YUV420P16", "YUV422P16", "YUV444P8", "RGBP8", "RGBPS", "YUVA420P8"]
+    fmt = fmts[rng.integers(len(fmts))]
+    kind = rng.integers(6)
+    sw = int(rng.integers(24, 120)) * 4
+    sh = int(rng.integers(20, 70)) * 4
+    kw = dict(tap=int(rng.integers(1, 9)))
+    if kind == 0:      # exact down-scale 1/2, 1/3, 1/4, 2/3, 3/4
+        num, den = [(1, 2), (1, 3), (1, 4), (2, 3), (3, 4)][rng.integers(5)]
+        sw, sh = sw // (4 * den) * 4 * den, sh // (4 * den) * 4 * den
+        tw, th = sw * num // den, sh * num // den
+        kw["tap"] = int(rng.integers(1, 5))
+    elif kind == 1:    # integer up-scale with a large tap
+        r = int(rng.integers(2, 4)); tw, th = sw * r, sh * r
+        kw["tap"] = int(rng.integers(9, 17))
+        sw, sh, tw, th = sw // 2 // 4 * 4, sh // 2 // 4 * 4, sw // 2 // 4 * 4 * r, sh // 2 // 4 * 4 * r
+    elif kind == 2:    # drifting ratios 3/2, 3, 9/4 x 8/3, 5/4
+        num, den = [(3, 2), (3, 1), (5, 4), (5, 2)][rng.integers(4)]
+        sw, sh = sw // (4 * den) * 4 * den, sh // (4 * den) * 4 * den
+        tw, th = sw * num // den, sh * num // den
+        kw["tap"] = int(rng.integers(2, 5))
+    elif kind == 3:    # anisotropic mix of exact ratios
+        rx = [(1, 2), (2, 1), (3, 2), (4, 3), (1, 1)][rng.integers(5)]
+        ry = [(1, 3), (2, 1), (3, 1), (2, 3), (1, 1)][rng.integers(5)]
+        sw, sh = sw // (4 * rx[1]) * 4 * rx[1], sh // (4 * ry[1]) * 4 * ry[1]
+        tw, th = sw * rx[0] // rx[1], sh * ry[0] // ry[1]
+        kw["tap"] = int(rng.integers(1, 6))
+    elif kind == 4:    # arbitrary ratio (no structure)
+        tw = int(sw * rng.uniform(0.6, 2.2)) // 4 * 4; th = int(sh * rng.uniform(0.6, 2.2)) // 4 * 4
+    else:              # 2x with every tap
+        tw, th = sw * 2, sh * 2
+        kw["tap"] = int(rng.integers(1, 17))
+    tw, th = max(16, tw), max(16, th)
+    if rng.random() < 0.3:
+        kw.update(quant_x=int(rng.integers(1, 257)), quant_y=int(rng.integers(1, 257)))
+    if rng.random() < 0.3:
+        kw["blur"] = float(np.round(rng.uniform(0.8, 1.25), 3))
+    if rng.random() < 0.15:
+        kw.update(src_left=float(np.round(rng.uniform(-3, 6), 2)), src_top=float(np.round(rng.uniform(-3, 6), 2)))
+    if "420" in fmt:
+        kw["cplace"] = ["mpeg2", "mpeg1", "topleft"][rng.integers(3)]
+    elif "422" in fmt:
+        kw["cplace"] = ["mpeg2", "mpeg1"][rng.integers(2)]
+    return fmt, sw, sh, tw, th, kw
+
+
+# JINC_SWEEP_SEEDS=N widens both sweeps for soak runs (default: 48 + 48 cases, a few seconds)
+_SWEEP = int(os.environ.get("JINC_SWEEP_SEEDS", "48"))
+
+
+@pytest.mark.parametrize("seed", range(_SWEEP))
+@pytest.mark.parametrize("gen", [1, 2], ids=["small", "structured"])
+def test_randomised_arguments(gpu_pkg, O, seed, gen):
     """Seeded sweep over formats, ratios, taps, quantisation, blur, crops and chroma siting: the HIP path
     (automatic kernel choice) must equal the oracle bit for bit whatever structure the plan has."""
-    rng = np.random.default_rng(1000 + seed)
-    fmt, sw, sh, tw, th, kw = _random_case(rng)
+    rng = np.random.default_rng(1000 * gen + seed)
+    fmt, sw, sh, tw, th, kw = (_random_case if gen == 1 else _random_case_v2)(rng)
     try:
         of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
     except Exception:
@@ -484,9 +540,9 @@ def test_randomised_arguments(gpu_pkg, O, seed):
         assert "smaller than the filter footprint" in str(e)   # the reference reads out of bounds there
         return
     src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=seed)
-    want = of.get_frame(src, threads=2)
+    want = of.get_frame(src, threads=4)
     got = f.get_frame(src)
-    assert_planes_equal(got, want, f.out_dims(), what=f"seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}")
+    assert_planes_equal(got, want, f.out_dims(), what=f"gen {gen} seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}")
     f.close()
 
 
