@@ -88,7 +88,14 @@ template <typename T, int FS>
 __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     __shared__ float tile[kGatherLdsFloats];
     const DevicePlan& p = a.plan;
-    const int b = blockIdx.x;
+    // Block id -> (tile, frame).  A batch of frames shares the plan, and a tile's coefficient sets (up to one per
+    // pixel for plans without phase structure: 196 B per pixel at fs 7) are the dominant traffic of this kernel, so
+    // all frames of a tile run back to back ON THE SAME XCD (workgroups are dealt round-robin over the 8 XCDs by
+    // linear id): the sets are then fetched into that XCD's L2 once per batch instead of once per frame.
+    const unsigned nf = static_cast<unsigned>(a.io.nframes);
+    const unsigned xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
+    const int b = static_cast<int>((slot / nf) * 8u + xcd);
+    if (b >= a.block_begin[4]) return;  // padding ids (tile count not a multiple of 8); whole block, before any barrier
     int r = 0;
     while (r + 1 < a.rects.n && b >= a.block_begin[r + 1]) ++r;
     const int local = b - a.block_begin[r];
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
 
     const int fs = FS ? FS : p.fs;
     const int fsp = FS ? padded_row(FS) : padded_row(p.fs);
-    const size_t frame = blockIdx.y;
+    const size_t frame = slot % nf;
     const char* sframe = static_cast<const char*>(a.io.src) + frame * a.io.src_frame_stride;
     char* dframe = static_cast<char*>(a.io.dst) + frame * a.io.dst_frame_stride;
     const int lane = threadIdx.x & 63;
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
 
 template <typename T, int FS>
 int launch_gather_t(const GatherArgs& ga, int total_blocks, hipStream_t stream) {
-    dim3 grid(total_blocks, ga.io.nframes, 1), block(256, 1, 1);
+    dim3 grid(static_cast<unsigned>((total_blocks + 7) / 8) * 8u * static_cast<unsigned>(ga.io.nframes), 1, 1), block(256, 1, 1);
     hipLaunchKernelGGL((ewa_gather_kernel<T, FS>), grid, block, 0, stream, ga);
     return static_cast<int>(hipGetLastError());
 }
