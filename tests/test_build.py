@@ -48,11 +48,12 @@ def test_no_fused_multiply_add_in_device_code(pkg):
 
 def test_product_does_not_reference_the_oracle():
     pkg_dir = os.path.join(ROOT, "avisynth-jincresize_amd")
-    for base, _, files in os.walk(pkg_dir):
+    product_dirs = [pkg_dir, os.path.join(ROOT, "plugin"), os.path.join(ROOT, "include")]
+    for base, _, files in (entry for d in product_dirs for entry in os.walk(d)):
         if os.path.basename(base) in ("build", "lib", "__pycache__"):
             continue
         for fn in files:
-            if fn.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+            if fn.endswith((".py", ".cpp", ".h", ".hip", ".inc", ".hpp", "Makefile")):
                 text = open(os.path.join(base, fn), errors="ignore").read()
                 assert "oracle" not in text.lower() or fn == "__init__.py" and "oracle" not in text.lower(), \
                     f"{fn} mentions the oracle"

@@ -346,7 +346,7 @@ DIRECT_CASES = [
 @pytest.mark.parametrize("case", DIRECT_CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
 def test_direct_periodic_kernel(gpu_pkg, O, case, mode):
     """Down-scales and large taps whose plans are exactly periodic (any filter size, source step <= 4) run on
-    ewa_periodic_direct_kernel (no LDS, row segments fetched in the source format): bit-exact like the rest."""
+    ewa_direct_kernel (no LDS, row segments fetched in the source format): bit-exact like the rest."""
     fmt, sw, sh, tw, th, kw, want_p = case
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
     src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=1618)
