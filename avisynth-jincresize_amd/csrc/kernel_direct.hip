@@ -102,10 +102,12 @@ __device__ __forceinline__ void mac_rows(float (&acc)[R][K], const uint32_t (&ra
         }
         float seg[NS];
         convert_segment<T, NS, RW>(rw, seg);
+        // tap-major over the K chains of the row: neighbouring instructions belong to different chains, so a
+        // wave does not wait for its own previous add (each chain still sees its taps in lx order)
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[jj][k] = acc[jj][k] + seg[SX * k + t] * cf[t];
+            for (int k = 0; k < K; ++k) acc[jj][k] = acc[jj][k] + seg[SX * k + t] * cf[t];
     }
 }
 
