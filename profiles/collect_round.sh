@@ -13,7 +13,7 @@ for c in C2 C3 C4; do
   python profiles/summarize.py ${tag}_$(echo $c | tr A-Z a-z) gpurun_out/${tag}_stats_$c gpurun_out/${tag}_fetch_$c gpurun_out/${tag}_write_$c > /dev/null 2>&1
   cp profiles/${tag}_$(echo $c | tr A-Z a-z).json gpurun_out/ 2>/dev/null
 done
-for c in C1 C2 C3 C4 N15 N3 U43 N480 D23 D12 D13 T6 T16 N15T8; do
+for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D13 D169 T6 T16 N15T8 A137 A1875; do
   python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$c.json
   python profiles/bench_line.py < gpurun_out/${tag}_bench_$c.json
 done
