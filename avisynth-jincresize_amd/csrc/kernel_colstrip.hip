@@ -44,10 +44,19 @@ __global__ __launch_bounds__(256) void ewa_colstrip_kernel(const ColStripArgs a,
         const int c = threadIdx.x & ((1 << cshift) - 1);
         const int rstep = 256 >> cshift;
         if (c < wsrc) {
-            for (int r = threadIdx.x >> cshift; r < nrows; r += rstep) {
-                const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(row0 + r) * io.src_pitch);
-                const int plane = r % sy, idx = r / sy;
-                cs_tile[(plane * wsrc + c) * kColStripIdxPitch + idx] = to_float(srow[c0 + c]);
+            // four rows per thread and pass, loads in front of the LDS writes
+            for (int r0 = threadIdx.x >> cshift; r0 < nrows; r0 += 4 * rstep) {
+                T v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = r0 + i * rstep < nrows ? r0 + i * rstep : nrows - 1;
+                    v[i] = reinterpret_cast<const T*>(sbase + static_cast<size_t>(row0 + r) * io.src_pitch)[c0 + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = r0 + i * rstep;
+                    if (r < nrows) cs_tile[((r % sy) * wsrc + c) * kColStripIdxPitch + r / sy] = to_float(v[i]);
+                }
             }
         }
     }

@@ -127,9 +127,19 @@ __global__ __launch_bounds__(256) void ewa_gather_kernel(const GatherArgs a) {
     const int pitch = tw | 1;
     const bool staged = pitch * th <= kGatherLdsFloats;  // wave-uniform; huge down-scales read global memory
     if (staged) {
-        for (int rr = wave; rr < th; rr += 4) {
-            const T* srow = reinterpret_cast<const T*>(sframe + static_cast<size_t>(ty0 + rr) * a.io.src_pitch) + tx0;
-            for (int c = lane; c < tw; c += 64) tile[rr * pitch + c] = to_float(srow[c]);
+        // four rows per wave and pass, loads in front of the LDS writes (one memory round trip per pass, not per row)
+        for (int r0 = wave; r0 < th; r0 += 16) {
+            for (int c = lane; c < tw; c += 64) {
+                T v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = r0 + 4 * i < th ? r0 + 4 * i : th - 1;
+                    v[i] = (reinterpret_cast<const T*>(sframe + static_cast<size_t>(ty0 + rr) * a.io.src_pitch) + tx0)[c];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (r0 + 4 * i < th) tile[(r0 + 4 * i) * pitch + c] = to_float(v[i]);
+            }
         }
     }
     __syncthreads();

@@ -39,36 +39,63 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
 
+    // The coefficients of the wave's first phase do not depend on the tile: request them (scalar loads) BEFORE the
+    // staging loads and the barrier, so that their latency overlaps the staging instead of following it.
+    const int nphase = a.px * a.py;
+    float cf[FS * FS];
+    if (wave < nphase) {
+        const JINC_CONSTANT float* cs0 =
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[wave]) * (FS * padded_row(FS)));
+#pragma unroll
+        for (int k = 0; k < FS * FS; ++k) cf[k] = cs0[(k / FS) * padded_row(FS) + (k % FS)];
+    }
+
     // ---- stage the source tile as fp32 (each source sample converted once) ----
     {
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
         const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
-        for (int r = wave; r < Cfg::kLdsRows; r += 4) {
-            int gy = gy0 + r;
+        // Fully unrolled with all loads in front of the LDS writes: one memory latency per tile instead of one per
+        // row (a rolled loop is load -> wait -> write per iteration, 16 round trips during which the block's four
+        // waves compute nothing).
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + 4 * i;
             gy = gy < a.src_h ? gy : a.src_h - 1;
             const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
 #pragma unroll
-            for (int c = lane; c < Cfg::kLdsCols; c += 64) {
-                int gx = gx0 + c;
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
                 gx = gx < a.src_w ? gx : a.src_w - 1;
-                tile[r * Cfg::kLdsPitch + c] = to_float(srow[gx]);
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
             }
         }
     }
     __syncthreads();
 
-    const int nphase = a.px * a.py;
     for (int ph = wave; ph < nphase; ph += 4) {
         const int q = ph / a.px;
         const int p = ph - q * a.px;
 
-        // wave-uniform coefficients -> SGPRs
-        const JINC_CONSTANT float* cs =
-            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
-        float cf[FS * FS];
+        // wave-uniform coefficients -> SGPRs (the first phase's are already on their way)
+        if (ph != wave) {
+            const JINC_CONSTANT float* cs =
+                (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
 #pragma unroll
-        for (int k = 0; k < FS * FS; ++k) cf[k] = cs[(k / FS) * padded_row(FS) + (k % FS)];
+            for (int k = 0; k < FS * FS; ++k) cf[k] = cs[(k / FS) * padded_row(FS) + (k % FS)];
+        }
 
         const float* base = tile + (a.start_y[q] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[p] - a.min_sx) + lane;
 
@@ -344,15 +371,30 @@ __global__ __launch_bounds__(512) void ewa_periodic_rows_kernel(const PeriodicAr
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
         const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
-        for (int r = wave; r < Cfg::kRows; r += Cfg::kWaves) {
-            int gy = gy0 + r;
+        // all loads in front of the LDS writes: one memory latency per tile instead of one per row (see ewa_periodic_kernel)
+        constexpr int kRowsPerWave = (Cfg::kRows + Cfg::kWaves - 1) / Cfg::kWaves;
+        constexpr int kColsPerLane = (Cfg::kCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + Cfg::kWaves * i;
             gy = gy < a.src_h ? gy : a.src_h - 1;
             const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
 #pragma unroll
-            for (int c = lane; c < Cfg::kCols; c += 64) {
-                int gx = gx0 + c;
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
                 gx = gx < a.src_w ? gx : a.src_w - 1;
-                tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = to_float(srow[gx]);
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + Cfg::kWaves * i;
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kRows && c < Cfg::kCols)
+                    tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = to_float(staged[i][k]);
             }
         }
     }
