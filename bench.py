@@ -219,6 +219,14 @@ def main():
     info = flt.plan_info(0)
     sb = fmt.sample_bytes
 
+    # Untimed device spin-up before the W warm-up steps: a C2 step is ~1 ms, so a handful of warm-up steps ends before the
+    # shader clock and the caches have settled (measured: 482 vs 541 Gpix/s for --steps 5 --warmup 2 without / with it).
+    # JINC_BENCH_SPINUP_MS=0 switches it off.
+    spin_ms = float(os.environ.get("JINC_BENCH_SPINUP_MS", "300"))
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -274,7 +282,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {sw}x{sh}->{dw}x{dh} {fmt_name} tap={kw['tap']}"
                                    + (f" blur={kw['blur']}" if 'blur' in kw else ""),
-                       "sample_type": {1: "u8", 2: "u16", 4: "f32"}[sb], "frames_per_step_per_gpu": B, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "sample_type": {1: "u8", 2: "u16", 4: "f32"}[sb], "frames_per_step_per_gpu": B,
+                       "untimed_spinup_ms_before_warmup": spin_ms, "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "kernel": dom_name, "filter_size": fs, "plan_sets": info.num_sets,
                        "plan_bytes": int(info.plan_bytes)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
