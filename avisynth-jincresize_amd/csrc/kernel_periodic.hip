@@ -16,8 +16,10 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int kTileCols = 64;  // source-aligned columns per tile = lanes of a wave
 
-// RG: row groups of FS rows per tile.  A/B on MI355X (C2): 8 groups 2.3 % faster than 4, 16 groups 10 % slower.
-template <int FS, int RG = (FS <= 7 ? 8 : 6)>
+// RG: row groups of FS rows per tile.  A/B on MI355X: fs 7 (C2) 8 groups = 4 groups (was +2.3 % before the staging loads
+// were issued together), 16 groups 10 % slower; fs 9 (C4, 88 VGPRs = 5 waves/SIMD) 9 groups +3.9 % over 6 -- 27 KB of
+// LDS per block still allows the 5 blocks per CU the registers allow.
+template <int FS, int RG = (FS <= 7 ? 8 : 9)>
 struct PeriodicCfg {
     static constexpr int kRowGroups = RG;
     static constexpr int kTileRows = FS * kRowGroups;     // period-rows per tile (multiple of FS)
@@ -464,7 +466,7 @@ int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStr
     if (variant == 3 && fs == 7) return launch_periodic_pk_t<T, 7, 4>(pa, io, stream);
     if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
     if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);
-    if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 9>(pa, io, stream);
+    if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 6>(pa, io, stream);
     if (variant == 1) {
         if (fs == 7) return launch_rows_t<T, 7>(pa, io, stream);
         if (fs == 9) return launch_rows_t<T, 9>(pa, io, stream);
