@@ -226,6 +226,29 @@ def test_full_size_properties(gpu_pkg, O):
     f.close()
 
 
+FULL_SIZE = [
+    ("Y8", 3840, 2160, 1920, 1080, {}, "ewa_direct_kernel"),             # 4K -> 1080p: direct interior, strips
+    ("YUV420P8", 1280, 720, 1920, 1080, {}, "ewa_quasi_kernel"),         # 720p -> 1080p: drifting, per-lane coefficients
+    ("Y16", 1920, 1080, 3840, 2160, dict(tap=12), "ewa_direct_kernel"),  # fs 25 at full size
+    ("Y8", 1280, 720, 1754, 986, {}, "ewa_gather_kernel"),               # no phase structure
+]
+
+
+@pytest.mark.parametrize("case", FULL_SIZE, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
+def test_full_size_frames_of_the_other_kernels_match_the_oracle(gpu_pkg, O, case):
+    """Real frame sizes (many tiles, 32-bit offset ranges, all border structures) through the kernels the small cases
+    reach only with a few tiles: bit-exact against the oracle, plus agreement with the forced gather kernel."""
+    fmt, sw, sh, tw, th, kw, kernel = case
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=2024)
+    want = of.get_frame(src, threads=16)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    assert f.interior_kernel(0) == kernel
+    got = f.get_frame(src)
+    assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th}")
+    f.close()
+
+
 def test_many_instances_share_a_device(gpu_pkg, O):
     """MT_MULTI_INSTANCE (ref :649-652): several instances on several host threads, one device."""
     import threading
