@@ -542,17 +542,42 @@ def _random_case_v2(rng):
     return fmt, sw, sh, tw, th, kw
 
 
-# JINC_SWEEP_SEEDS=N widens both sweeps for soak runs (default: 48 + 48 cases, a few seconds)
+def _random_case_v3(rng):
+    """Third generation: extreme geometry -- tiny frames, thin strips, 8x ratios, big taps on small sources (many are
+    rejected like the reference's out-of-bounds cases), odd chroma sizes."""
+    fmts = ["Y8", "Y16", "Y32", "YUV420P8", "YUV444P16", "RGBPS"]
+    fmt = fmts[rng.integers(len(fmts))]
+    even = 2 if "420" in fmt else 1
+    sw = int(rng.integers(8, 72)) // even * even
+    sh = int(rng.integers(8, 72)) // even * even
+    shape = rng.integers(4)
+    if shape == 0:      # thin strip
+        sh = [8, 10, 12, 16][rng.integers(4)]
+    elif shape == 1:    # tall strip
+        sw = [8, 10, 12, 16][rng.integers(4)]
+    tw = max(4, int(sw * [0.25, 0.5, 1.0, 2.0, 4.0, 8.0, rng.uniform(0.3, 6.0)][rng.integers(7)])) // even * even
+    th = max(4, int(sh * [0.25, 0.5, 1.0, 2.0, 4.0, 8.0, rng.uniform(0.3, 6.0)][rng.integers(7)])) // even * even
+    kw = dict(tap=int([1, 2, 3, 3, 4, 8, 16][rng.integers(7)]))
+    if rng.random() < 0.3:
+        kw.update(quant_x=int([1, 2, 16, 256][rng.integers(4)]), quant_y=int([1, 3, 64, 256][rng.integers(4)]))
+    if rng.random() < 0.2:
+        kw["blur"] = float(np.round(rng.uniform(0.6, 1.6), 3))
+    if "420" in fmt:
+        kw["cplace"] = ["mpeg2", "mpeg1", "topleft"][rng.integers(3)]
+    return fmt, sw, sh, tw, th, kw
+
+
+# JINC_SWEEP_SEEDS=N widens the sweeps for soak runs (default: 3 x 48 cases, a few seconds)
 _SWEEP = int(os.environ.get("JINC_SWEEP_SEEDS", "48"))
 
 
 @pytest.mark.parametrize("seed", range(_SWEEP))
-@pytest.mark.parametrize("gen", [1, 2], ids=["small", "structured"])
+@pytest.mark.parametrize("gen", [1, 2, 3], ids=["small", "structured", "extreme"])
 def test_randomised_arguments(gpu_pkg, O, seed, gen):
     """Seeded sweep over formats, ratios, taps, quantisation, blur, crops and chroma siting: the HIP path
     (automatic kernel choice) must equal the oracle bit for bit whatever structure the plan has."""
     rng = np.random.default_rng(1000 * gen + seed)
-    fmt, sw, sh, tw, th, kw = (_random_case if gen == 1 else _random_case_v2)(rng)
+    fmt, sw, sh, tw, th, kw = {1: _random_case, 2: _random_case_v2, 3: _random_case_v3}[gen](rng)
     try:
         of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
     except Exception:
