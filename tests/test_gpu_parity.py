@@ -436,29 +436,35 @@ def test_border_strips_and_gather_border_agree_with_oracle(gpu_pkg, O, case, str
     f.close()
 
 
-def test_plane_ending_on_a_page_boundary(gpu_pkg, O):
+@pytest.mark.parametrize("fmt,slacks", [("Y8", (0, 1, 2, 3, 4, 2048)), ("Y16", (0, 2, 4, 6, 2050))], ids=["u8", "u16"])
+def test_plane_ending_on_a_page_boundary(gpu_pkg, O, fmt, slacks):
     """ewa_direct_kernel fetches naturally aligned dwords only, bounded by the dword that holds the plane's last
-    sample: planes that end on (or within 3 bytes of) a 4 KiB page boundary, at every base misalignment, are served
-    without touching the next page and without losing the last samples."""
+    sample: planes that end on (or within 3 bytes of) a 4 KiB page boundary, at every base misalignment the sample
+    size allows, are served without touching the next page and without losing the last samples."""
     torch = pytest.importorskip("torch")
-    fmt, sw, sh, tw, th = "Y8", 200, 120, 100, 60
-    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
-    frame = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=4096)
+    sw, sh, tw, th = 200, 120, 100, 60
+    ofmt = O.FORMATS[fmt]
+    sb = ofmt.sample_bytes
+    of = O.OracleFilter(ofmt, sw, sh, tw, th)
+    frame = O.lcg_frame(ofmt, sw, sh, seed=4096)
     want = of.get_frame(frame, threads=4)[0][:th, :tw]
     plane = np.ascontiguousarray(frame[0][:sh, :sw])
+    nbytes = sw * sh * sb
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
-    pool = torch.zeros(4 * 4096 + sw * sh, dtype=torch.uint8, device="cuda")
-    dst = torch.zeros((th, tw), dtype=torch.uint8, device="cuda")
+    assert f.interior_kernel(0) == "ewa_direct_kernel"
+    pool = torch.zeros(4 * 4096 + nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.zeros((th, tw * sb), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
-    for slack in (0, 1, 2, 3, 4, 2048):   # bytes between the plane's end and the next page boundary
-        off = (-(pool.data_ptr() + sw * sh + slack)) % 4096
-        view = pool[off:off + sw * sh]
-        assert (view.data_ptr() + sw * sh + slack) % 4096 == 0
-        view.copy_(torch.from_numpy(plane.reshape(-1)))
+    for slack in slacks:   # bytes between the plane's end and the next page boundary
+        off = (-(pool.data_ptr() + nbytes + slack)) % 4096
+        view = pool[off:off + nbytes]
+        assert (view.data_ptr() + nbytes + slack) % 4096 == 0 and view.data_ptr() % sb == 0
+        view.copy_(torch.from_numpy(plane.view(np.uint8).reshape(-1)))
         dst.zero_()
-        f.process_device([view.data_ptr()], [sw], [0], [dst.data_ptr()], [tw], [0], 1, stream=stream.cuda_stream)
+        f.process_device([view.data_ptr()], [sw * sb], [0], [dst.data_ptr()], [tw * sb], [0], 1, stream=stream.cuda_stream)
         stream.synchronize()
-        assert np.array_equal(dst.cpu().numpy(), want), f"slack {slack}"
+        got = dst.cpu().numpy().view(ofmt.dtype)
+        assert np.array_equal(got, want), f"slack {slack} (base % 4 = {view.data_ptr() % 4})"
     f.close()
 
 
