@@ -127,6 +127,31 @@ struct MacSelect<T, SX, 0, R, K, RW, NC> {
     static __device__ __forceinline__ void run(int, float (&)[R][K], const uint32_t (&)[R][RW], const float (&)[NC]) {}
 };
 
+// Interior form (one step at a time): every variant fetches exactly the dwords ITS tap count needs -- the tail of a
+// kernel row, or a kernel row shorter than a full step (fs 13 with 16-tap steps), would otherwise fetch a full
+// step's segment: one buffer_load more per row than necessary.
+template <typename T, int SX, int NT, int R, int K, int NC>
+struct FetchMacSelect {
+    static __device__ __forceinline__ void run(int remaining, float (&acc)[R][K], BufferRsrc rsrc, const uint32_t (&voff)[R],
+                                               const uint32_t (&shift)[R], uint32_t srow, uint32_t srow_step, const float (&cf)[NC]) {
+        if (remaining >= NT) {
+            constexpr int RWN = ((NT + SX * (K - 1)) * static_cast<int>(sizeof(T)) + 3) / 4;
+            uint32_t raw[R][RWN];
+#pragma unroll
+            for (int jj = 0; jj < R; ++jj)
+                load_raw<RWN, (sizeof(T) < 4)>(rsrc, voff[jj], shift[jj], srow + static_cast<uint32_t>(jj) * srow_step, raw[jj]);
+            mac_rows<T, SX, NT, R, K, RWN, NC>(acc, raw, cf);
+        } else {
+            FetchMacSelect<T, SX, NT - 1, R, K, NC>::run(remaining, acc, rsrc, voff, shift, srow, srow_step, cf);
+        }
+    }
+};
+template <typename T, int SX, int R, int K, int NC>
+struct FetchMacSelect<T, SX, 0, R, K, NC> {
+    static __device__ __forceinline__ void run(int, float (&)[R][K], BufferRsrc, const uint32_t (&)[R], const uint32_t (&)[R], uint32_t,
+                                               uint32_t, const float (&)[NC]) {}
+};
+
 __device__ __forceinline__ int plan_int(const int32_t* base, size_t index) {  // wave-uniform table lookup -> s_load
     return ((const JINC_CONSTANT int32_t*)base)[index];
 }
@@ -238,6 +263,17 @@ __global__ __launch_bounds__(256) void ewa_direct_kernel(const DirectArgs a, con
     int ly = 0, lxi = 0;  // coordinates of the next step to fetch
 #pragma unroll 1
     for (int s0 = 0; s0 < nsteps; s0 += D) {
+        if constexpr (D == 1) {
+            const int lx = lxi * B;
+            const uint32_t srow = soff0 + static_cast<uint32_t>(ly) * pitch + static_cast<uint32_t>(lx) * SB;
+            const JINC_CONSTANT float* c = cs + static_cast<size_t>(ly) * a.coeff_row + lx;
+            float cf1[B];
+#pragma unroll
+            for (int t = 0; t < B; ++t) cf1[t] = c[t];  // wave-uniform -> SGPRs (the allocation has slack past the last row)
+            FetchMacSelect<T, SX, B, R, K, B>::run(fs - lx, acc, srsrc, voff, shift, srow, srow_step, cf1);
+            if (++lxi == nsx) lxi = 0, ++ly;
+            continue;
+        }
         uint32_t raw[D][R][RW];
         float cf[D][B];
         int rem[D];
