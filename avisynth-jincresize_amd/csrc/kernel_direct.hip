@@ -5,8 +5,8 @@
 //                    and up-scales with taps 9..16 (fs 19..33);
 //   kDirectRowStrip  the top/bottom border rows of EVERY exactly periodic plan (interior column range): a border row
 //                    is an interior row with its own window origin and its own coefficient set per column phase.
-// The left/right border columns (full height, corners included) stay with the gather kernel: lanes would have to run
-// along y there, one cache line per lane and fetch -- measured 3x slower than the gather kernel's LDS staging.
+// The left/right border columns are kernel_colstrip.hip's (lanes have to run along y there -- without LDS staging that
+// is one cache line per lane and fetch, measured 3x slower); the four corners stay with the gather kernel.
 // See device_common.hpp for the parity rules.
 //
 // Why no LDS tile: a down-scale by s reads s*s source samples per output sample, so an fp32 LDS tile for the
