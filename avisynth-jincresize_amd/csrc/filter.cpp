@@ -617,7 +617,7 @@ void attach_lane_coeffs(const jinc::PlanePlan& p, DeviceTable& t, jinc::RectList
     long long total = 0;
     for (int r = 0; r < rects.n; ++r) {
         int axis, P;
-        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], axis, P);
+        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], rects.private_sets, axis, P);
         rects.lane_item_base[r] = total;
         total += jinc::gather_item_count(rects.w[r], rects.h[r], axis, P);
     }
@@ -625,7 +625,7 @@ void attach_lane_coeffs(const jinc::PlanePlan& p, DeviceTable& t, jinc::RectList
     std::vector<float> buf(static_cast<size_t>(total) * item_floats, 0.f);
     for (int r = 0; r < rects.n; ++r) {
         int axis, P;
-        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], axis, P);
+        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], rects.private_sets, axis, P);
         const int along = axis == 0 ? rects.w[r] : rects.h[r], across = axis == 0 ? rects.h[r] : rects.w[r];
         const int blocks = (along + 64 * P - 1) / (64 * P);
         for (int line = 0; line < across; ++line)
@@ -659,7 +659,12 @@ void init_device(jinc_filter& f, int device) {
     hip_check(hipSetDevice(device), "hipSetDevice");
     f.device = device;
     hip_check(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking), "hipStreamCreate");
-    hip_check(hipStreamCreateWithFlags(&f.aux_stream, hipStreamNonBlocking), "hipStreamCreate");
+    {   // The side stream carries the small border kernels: at the highest priority its workgroups are dispatched as
+        // soon as slots free up instead of queueing behind the interior kernel, which can hold every wave slot.
+        int least = 0, greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        hip_check(hipStreamCreateWithPriority(&f.aux_stream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    }
     hip_check(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming), "hipEventCreate");
     f.tables.resize(f.plans.size());
@@ -802,14 +807,17 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 jinc::DirectArgs rs = t.row_strips;
                 rs.src_bytes = direct_src_bytes(
                     src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                const bool colstrip = t.use_colstrip && f.border_strips != 2;
+                // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
+                // last it would start when the interior kernel already holds every wave slot
+                if (colstrip && t.corner_rects.n > 0)
+                    timed(f.ev_gather, border_stream, "corner kernel launch",
+                          [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
                 timed(f.ev_gather, border_stream, "border row kernel launch",
                       [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
-                if (t.use_colstrip && f.border_strips != 2) {
+                if (colstrip) {
                     timed(f.ev_gather, border_stream, "border column kernel launch",
                           [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
-                    if (t.corner_rects.n > 0)
-                        timed(f.ev_gather, border_stream, "corner kernel launch",
-                              [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
                 } else if (t.column_rects.n > 0) {
                     timed(f.ev_gather, border_stream, "border column kernel launch",
                           [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });

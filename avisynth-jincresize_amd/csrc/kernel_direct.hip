@@ -35,58 +35,59 @@ template <typename T, int MODE>
 struct DirectShape {
     static constexpr int K = 4;
     static constexpr int R = MODE == kDirectInterior ? 4 : 1;
-    static constexpr int B = (MODE == kDirectInterior && sizeof(T) == 1) ? 16 : 8;
+    static constexpr int B = (MODE == kDirectInterior && sizeof(T) <= 2) ? 16 : 8;
     static constexpr int D = MODE == kDirectInterior ? 1 : 4;
 };
 
-// Row segment of a lane in the source format: RW dwords starting at byte offset voffset + shift (+ soffset), where
-// voffset and soffset are multiples of 4 and shift = 0..3 is the lane's misalignment.  Only naturally aligned
-// dwords are fetched (16/8/4-byte pieces) and funnel-shifted into place (v_alignbyte_b32), so nothing outside the
-// aligned dwords that hold the plane's samples is ever touched: the buffer resource bounds the rest.
-template <int RW, bool SHIFT>
-__device__ __forceinline__ void load_raw(BufferRsrc rsrc, uint32_t voffset, uint32_t shift, uint32_t soffset, uint32_t (&raw)[RW]) {
+// Row segment of a lane in the source format: RW naturally aligned dwords from byte offset voffset (+ soffset), both
+// multiples of 4, fetched as 16/8/4-byte pieces.  The lane's first sample sits SH = 0..3 bytes into the first dword;
+// SH is the same for every lane of a wave (the lane stride SX*4 samples is a multiple of 4 bytes) and a template
+// parameter of everything below, so the samples are picked out of the aligned dwords by the conversion itself
+// (v_cvt_f32_ubyteN / SDWA word select) -- no funnel shifts.  Nothing outside the aligned dwords that hold the
+// plane's samples is ever touched: the buffer resource bounds the rest.
+template <int RW>
+__device__ __forceinline__ void load_raw(BufferRsrc rsrc, uint32_t voffset, uint32_t soffset, uint32_t (&raw)[RW]) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    constexpr int NW = SHIFT ? RW + 1 : RW;
-    uint32_t ld[NW];
     int w = 0;
 #pragma unroll
-    for (; w + 4 <= NW; w += 4) {
+    for (; w + 4 <= RW; w += 4) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voffset + 4 * w, soffset, 0);
-        ld[w] = v.x, ld[w + 1] = v.y, ld[w + 2] = v.z, ld[w + 3] = v.w;
+        raw[w] = v.x, raw[w + 1] = v.y, raw[w + 2] = v.z, raw[w + 3] = v.w;
     }
-    if constexpr (NW % 4 >= 2) {
+    if constexpr (RW % 4 >= 2) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voffset + 4 * w, soffset, 0);
-        ld[w] = v.x, ld[w + 1] = v.y;
+        raw[w] = v.x, raw[w + 1] = v.y;
         w += 2;
     }
-    if constexpr (NW % 2 == 1) ld[w] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset + 4 * w, soffset, 0);
-#pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        if constexpr (SHIFT)
-            raw[i] = __builtin_amdgcn_alignbyte(ld[i + 1], ld[i], shift);
-        else
-            raw[i] = ld[i];
-    }
+    if constexpr (RW % 2 == 1) raw[w] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voffset + 4 * w, soffset, 0);
 }
 
-template <typename T, int NS, int RW>
+// dwords that hold NS samples starting SH bytes into the first one
+template <typename T>
+__host__ __device__ constexpr int segment_words(int ns, int sh) {
+    return (ns * static_cast<int>(sizeof(T)) + sh + 3) / 4;
+}
+
+template <typename T, int NS, int RW, int SH>
 __device__ __forceinline__ void convert_segment(const uint32_t (&raw)[RW], float (&seg)[NS]) {
-    static_assert(NS * static_cast<int>(sizeof(T)) <= 4 * RW, "segment larger than its raw words");
+    static_assert(NS * static_cast<int>(sizeof(T)) + SH <= 4 * RW, "segment larger than its raw words");
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
+        constexpr int SB = static_cast<int>(sizeof(T));
+        const int b = i * SB + SH;  // byte position of sample i in the raw words (compile-time after unrolling)
         if constexpr (sizeof(T) == 1)
-            seg[i] = static_cast<float>((raw[i / 4] >> (8 * (i % 4))) & 0xffu);  // v_cvt_f32_ubyteN
+            seg[i] = static_cast<float>((raw[b / 4] >> (8 * (b % 4))) & 0xffu);  // v_cvt_f32_ubyteN
         else if constexpr (sizeof(T) == 2)
-            seg[i] = static_cast<float>((raw[i / 2] >> (16 * (i % 2))) & 0xffffu);
+            seg[i] = static_cast<float>((raw[b / 4] >> (8 * (b % 4))) & 0xffffu);  // SDWA word select
         else
-            seg[i] = __builtin_bit_cast(float, raw[i]);
+            seg[i] = __builtin_bit_cast(float, raw[b / 4]);
     }
 }
 
 // NT taps (lx = lx0 .. lx0+NT-1) of kernel row ly for all R x K chains of the lane, from segments already in
 // registers.  Every chain still meets its taps in (ly, lx) raster order: steps run in lx order inside ly order.
-template <typename T, int SX, int NT, int R, int K, int RW, int NC>
+template <typename T, int SX, int NT, int R, int K, int RW, int NC, int SH>
 __device__ __forceinline__ void mac_rows(float (&acc)[R][K], const uint32_t (&raw)[R][RW], const float (&cf)[NC]) {
     constexpr int NS = NT + SX * (K - 1);
 #pragma unroll
@@ -101,7 +102,7 @@ __device__ __forceinline__ void mac_rows(float (&acc)[R][K], const uint32_t (&ra
             asm volatile("" : "+v"(rw[w]));
         }
         float seg[NS];
-        convert_segment<T, NS, RW>(rw, seg);
+        convert_segment<T, NS, RW, SH>(rw, seg);
         // tap-major over the K chains of the row: neighbouring instructions belong to different chains, so a
         // wave does not wait for its own previous add (each chain still sees its taps in lx order)
 #pragma unroll
@@ -112,45 +113,94 @@ __device__ __forceinline__ void mac_rows(float (&acc)[R][K], const uint32_t (&ra
 }
 
 // remaining >= B: a full step; otherwise the tail of the kernel row with a compile-time tap count
-template <typename T, int SX, int NT, int R, int K, int RW, int NC>
+template <typename T, int SX, int NT, int R, int K, int RW, int NC, int SH>
 struct MacSelect {
     static __device__ __forceinline__ void run(int remaining, float (&acc)[R][K], const uint32_t (&raw)[R][RW],
                                                const float (&cf)[NC]) {
         if (remaining >= NT)
-            mac_rows<T, SX, NT, R, K, RW, NC>(acc, raw, cf);
+            mac_rows<T, SX, NT, R, K, RW, NC, SH>(acc, raw, cf);
         else
-            MacSelect<T, SX, NT - 1, R, K, RW, NC>::run(remaining, acc, raw, cf);
+            MacSelect<T, SX, NT - 1, R, K, RW, NC, SH>::run(remaining, acc, raw, cf);
     }
 };
-template <typename T, int SX, int R, int K, int RW, int NC>
-struct MacSelect<T, SX, 0, R, K, RW, NC> {
+template <typename T, int SX, int R, int K, int RW, int NC, int SH>
+struct MacSelect<T, SX, 0, R, K, RW, NC, SH> {
     static __device__ __forceinline__ void run(int, float (&)[R][K], const uint32_t (&)[R][RW], const float (&)[NC]) {}
 };
 
 // Interior form (one step at a time): every variant fetches exactly the dwords ITS tap count needs -- the tail of a
 // kernel row, or a kernel row shorter than a full step (fs 13 with 16-tap steps), would otherwise fetch a full
 // step's segment: one buffer_load more per row than necessary.
-template <typename T, int SX, int NT, int R, int K, int NC>
+template <typename T, int SX, int NT, int R, int K, int NC, int SH>
 struct FetchMacSelect {
     static __device__ __forceinline__ void run(int remaining, float (&acc)[R][K], BufferRsrc rsrc, const uint32_t (&voff)[R],
-                                               const uint32_t (&shift)[R], uint32_t srow, uint32_t srow_step, const float (&cf)[NC]) {
+                                               uint32_t srow, uint32_t srow_step, const float (&cf)[NC]) {
         if (remaining >= NT) {
-            constexpr int RWN = ((NT + SX * (K - 1)) * static_cast<int>(sizeof(T)) + 3) / 4;
+            constexpr int RWN = segment_words<T>(NT + SX * (K - 1), SH);
             uint32_t raw[R][RWN];
 #pragma unroll
-            for (int jj = 0; jj < R; ++jj)
-                load_raw<RWN, (sizeof(T) < 4)>(rsrc, voff[jj], shift[jj], srow + static_cast<uint32_t>(jj) * srow_step, raw[jj]);
-            mac_rows<T, SX, NT, R, K, RWN, NC>(acc, raw, cf);
+            for (int jj = 0; jj < R; ++jj) load_raw<RWN>(rsrc, voff[jj], srow + static_cast<uint32_t>(jj) * srow_step, raw[jj]);
+            mac_rows<T, SX, NT, R, K, RWN, NC, SH>(acc, raw, cf);
         } else {
-            FetchMacSelect<T, SX, NT - 1, R, K, NC>::run(remaining, acc, rsrc, voff, shift, srow, srow_step, cf);
+            FetchMacSelect<T, SX, NT - 1, R, K, NC, SH>::run(remaining, acc, rsrc, voff, srow, srow_step, cf);
         }
     }
 };
-template <typename T, int SX, int R, int K, int NC>
-struct FetchMacSelect<T, SX, 0, R, K, NC> {
-    static __device__ __forceinline__ void run(int, float (&)[R][K], BufferRsrc, const uint32_t (&)[R], const uint32_t (&)[R], uint32_t,
-                                               uint32_t, const float (&)[NC]) {}
+template <typename T, int SX, int R, int K, int NC, int SH>
+struct FetchMacSelect<T, SX, 0, R, K, NC, SH> {
+    static __device__ __forceinline__ void run(int, float (&)[R][K], BufferRsrc, const uint32_t (&)[R], uint32_t, uint32_t,
+                                               const float (&)[NC]) {}
 };
+
+// The whole tap loop of an item for one value of SH: steps in (ly, lx) raster order, step s covers kernel row
+// s / nsx, taps (s % nsx) * B ...
+template <typename T, int SX, int MODE, int SH, int R, int K>
+__device__ __forceinline__ void direct_steps(float (&acc)[R][K], BufferRsrc srsrc, const uint32_t (&voff)[R], uint32_t soff0,
+                                             uint32_t srow_step, uint32_t pitch, const JINC_CONSTANT float* cs, int coeff_row,
+                                             int fs) {
+    using Shape = DirectShape<T, MODE>;
+    static_assert(R == Shape::R && K == Shape::K, "chain shape of the mode");
+    constexpr int B = Shape::B, D = Shape::D;
+    constexpr int RW = segment_words<T>(B + SX * (K - 1), SH);  // dwords of a full step's segment
+    constexpr uint32_t SB = static_cast<uint32_t>(sizeof(T));
+    const int nsx = (fs + B - 1) / B;
+    const int nsteps = fs * nsx;
+    int ly = 0, lxi = 0;  // coordinates of the next step to fetch
+#pragma unroll 1
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+        if constexpr (D == 1) {
+            const int lx = lxi * B;
+            const uint32_t srow = soff0 + static_cast<uint32_t>(ly) * pitch + static_cast<uint32_t>(lx) * SB;
+            const JINC_CONSTANT float* c = cs + static_cast<size_t>(ly) * coeff_row + lx;
+            float cf1[B];
+#pragma unroll
+            for (int t = 0; t < B; ++t) cf1[t] = c[t];  // wave-uniform -> SGPRs (the allocation has slack past the last row)
+            FetchMacSelect<T, SX, B, R, K, B, SH>::run(fs - lx, acc, srsrc, voff, srow, srow_step, cf1);
+            if (++lxi == nsx) lxi = 0, ++ly;
+        } else {
+            uint32_t raw[D][R][RW];
+            float cf[D][B];
+            int rem[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (s0 + d < nsteps) {  // wave-uniform
+                    const int lx = lxi * B;
+                    const uint32_t srow = soff0 + static_cast<uint32_t>(ly) * pitch + static_cast<uint32_t>(lx) * SB;
+#pragma unroll
+                    for (int jj = 0; jj < R; ++jj) load_raw<RW>(srsrc, voff[jj], srow + static_cast<uint32_t>(jj) * srow_step, raw[d][jj]);
+                    const JINC_CONSTANT float* c = cs + static_cast<size_t>(ly) * coeff_row + lx;
+#pragma unroll
+                    for (int t = 0; t < B; ++t) cf[d][t] = c[t];  // wave-uniform -> SGPRs
+                    rem[d] = fs - lx;
+                    if (++lxi == nsx) lxi = 0, ++ly;
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                if (s0 + d < nsteps) MacSelect<T, SX, B, R, K, RW, B, SH>::run(rem[d], acc, raw[d], cf[d]);
+        }
+    }
+}
 
 __device__ __forceinline__ int plan_int(const int32_t* base, size_t index) {  // wave-uniform table lookup -> s_load
     return ((const JINC_CONSTANT int32_t*)base)[index];
@@ -164,10 +214,7 @@ __device__ __forceinline__ int plan_int(const int32_t* base, size_t index) {  //
 template <typename T, int SX, int MODE>
 __global__ __launch_bounds__(256) void ewa_direct_kernel(const DirectArgs a, const PlaneIO io) {
     using Shape = DirectShape<T, MODE>;
-    constexpr int B = Shape::B, D = Shape::D;
     constexpr int K = Shape::K, R = Shape::R;
-    constexpr int NSB = B + SX * (K - 1);                                 // samples of a full step's segment
-    constexpr int RW = (NSB * static_cast<int>(sizeof(T)) + 3) / 4;       // ... in dwords
     constexpr uint32_t SB = static_cast<uint32_t>(sizeof(T));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -233,19 +280,16 @@ __global__ __launch_bounds__(256) void ewa_direct_kernel(const DirectArgs a, con
         dst_xstep = static_cast<uint32_t>(a.px) * SB;
     }
 
-    // Split every segment address into an aligned part and the lane's byte shift.  The host guarantees that the
-    // pitch and the frame stride are multiples of 4; the plane's own misalignment (base & 3) joins the lane offset.
-    constexpr bool kShift = sizeof(T) < 4;
+    // Split every segment address into an aligned part and the byte shift SH of its first sample.  The host guarantees
+    // that the pitch and the frame stride are multiples of 4; the plane's own misalignment (base & 3) joins the lane
+    // offset.  The lane stride (SX * 4 samples) is a multiple of 4 bytes, so SH is the same for all lanes: one
+    // wave-uniform switch selects the instantiation of the tap loop that has SH as a compile-time constant.
     const uintptr_t plane = reinterpret_cast<uintptr_t>(io.src) + frame * io.src_frame_stride;
     const uint32_t mis = static_cast<uint32_t>(plane & 3u) + (soff0 & 3u);
     soff0 &= ~3u;
-    uint32_t shift[R];
+    const uint32_t sh = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((voff[0] + mis) & 3u)));
 #pragma unroll
-    for (int jj = 0; jj < R; ++jj) {
-        const uint32_t v = voff[jj] + mis;
-        shift[jj] = v & 3u;
-        voff[jj] = v & ~3u;
-    }
+    for (int jj = 0; jj < R; ++jj) voff[jj] = (voff[jj] + mis) & ~3u;
     const BufferRsrc srsrc = make_rsrc(reinterpret_cast<char*>(plane & ~static_cast<uintptr_t>(3)), a.src_bytes);
     if (!lane_ok) return;
     const JINC_CONSTANT float* cs =
@@ -257,44 +301,20 @@ __global__ __launch_bounds__(256) void ewa_direct_kernel(const DirectArgs a, con
 #pragma unroll
         for (int k = 0; k < K; ++k) acc[jj][k] = 0.f;
 
-    // steps in (ly, lx) raster order: step s covers kernel row s / nsx, taps (s % nsx) * B ...
-    const int nsx = (fs + B - 1) / B;
-    const int nsteps = fs * nsx;
-    int ly = 0, lxi = 0;  // coordinates of the next step to fetch
-#pragma unroll 1
-    for (int s0 = 0; s0 < nsteps; s0 += D) {
-        if constexpr (D == 1) {
-            const int lx = lxi * B;
-            const uint32_t srow = soff0 + static_cast<uint32_t>(ly) * pitch + static_cast<uint32_t>(lx) * SB;
-            const JINC_CONSTANT float* c = cs + static_cast<size_t>(ly) * a.coeff_row + lx;
-            float cf1[B];
-#pragma unroll
-            for (int t = 0; t < B; ++t) cf1[t] = c[t];  // wave-uniform -> SGPRs (the allocation has slack past the last row)
-            FetchMacSelect<T, SX, B, R, K, B>::run(fs - lx, acc, srsrc, voff, shift, srow, srow_step, cf1);
-            if (++lxi == nsx) lxi = 0, ++ly;
-            continue;
+    if constexpr (sizeof(T) == 4) {
+        direct_steps<T, SX, MODE, 0>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs);
+    } else if constexpr (sizeof(T) == 2) {
+        if (sh == 0)
+            direct_steps<T, SX, MODE, 0>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs);
+        else
+            direct_steps<T, SX, MODE, 2>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs);
+    } else {
+        switch (sh) {
+            case 0: direct_steps<T, SX, MODE, 0>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs); break;
+            case 1: direct_steps<T, SX, MODE, 1>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs); break;
+            case 2: direct_steps<T, SX, MODE, 2>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs); break;
+            default: direct_steps<T, SX, MODE, 3>(acc, srsrc, voff, soff0, srow_step, pitch, cs, a.coeff_row, fs); break;
         }
-        uint32_t raw[D][R][RW];
-        float cf[D][B];
-        int rem[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (D == 1 || s0 + d < nsteps) {  // wave-uniform
-                const int lx = lxi * B;
-                const uint32_t srow = soff0 + static_cast<uint32_t>(ly) * pitch + static_cast<uint32_t>(lx) * SB;
-#pragma unroll
-                for (int jj = 0; jj < R; ++jj)
-                    load_raw<RW, kShift>(srsrc, voff[jj], shift[jj], srow + static_cast<uint32_t>(jj) * srow_step, raw[d][jj]);
-                const JINC_CONSTANT float* c = cs + static_cast<size_t>(ly) * a.coeff_row + lx;
-#pragma unroll
-                for (int t = 0; t < B; ++t) cf[d][t] = c[t];  // wave-uniform -> SGPRs (the allocation has slack past the last row)
-                rem[d] = fs - lx;
-                if (++lxi == nsx) lxi = 0, ++ly;
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (D == 1 || s0 + d < nsteps) MacSelect<T, SX, B, R, K, RW, B>::run(rem[d], acc, raw[d], cf[d]);
     }
 
     const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,

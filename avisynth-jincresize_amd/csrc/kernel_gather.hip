@@ -352,7 +352,7 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
         ga.lines[r] = 4;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
             int axis, P;
-            gather_rect_layout(plan, rects.w[r], rects.h[r], axis, P);
+            gather_rect_layout(plan, rects.w[r], rects.h[r], rects.private_sets, axis, P);
             const int along = axis == 0 ? rects.w[r] : rects.h[r];
             const int across = axis == 0 ? rects.h[r] : rects.w[r];
             // More lines per block amortise the block's fixed cost (bounds, staging, barrier) and its halo;

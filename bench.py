@@ -52,6 +52,8 @@ CONFIGS = {
     "A1875": ("Y8", 1024, 576, 1920, 1080, dict(tap=3), 32),   # PAL -> 1080p, 15/8: period 15, source step 8
     "D169": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 32),    # 5/6 down-scale: drifting, period 5, source step 6, fs 8
     "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 32),   # 1/2 down-scale: fs = 13, period 1, source step 2
+    "D12H": ("YUV420P16", 3840, 2160, 1920, 1080, dict(tap=3), 16),  # 4K 16-bit 4:2:0 -> 1080p
+    "D12F": ("RGBPS", 3840, 2160, 1920, 1080, dict(tap=3), 8),       # 4K float RGB -> 1080p
     "D13": ("Y8", 3840, 2160, 1280, 720, dict(tap=3), 32),    # 1/3 down-scale: fs = 20, period 1, source step 3
     "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 16),    # Jinc144: fs = 13
     "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 4),   # tap 16: fs = 33 (1089 taps)
