@@ -35,7 +35,7 @@ template <typename T, int MODE>
 struct DirectShape {
     static constexpr int K = 4;
     static constexpr int R = MODE == kDirectInterior ? 4 : 1;
-    static constexpr int B = (MODE == kDirectInterior && sizeof(T) <= 2) ? 16 : 8;
+    static constexpr int B = MODE == kDirectInterior ? 16 : 8;
     static constexpr int D = MODE == kDirectInterior ? 1 : 4;
 };
 
