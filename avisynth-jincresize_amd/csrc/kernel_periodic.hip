@@ -204,18 +204,34 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
         const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
-        for (int r = wave; r < Cfg::kLdsRows; r += 4) {
-            int gy = gy0 + r;
+        // all loads in front of the LDS writes (see ewa_periodic_kernel)
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kColsPerLane = (Cfg::kSrcCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + 4 * i;
             gy = gy < a.src_h ? gy : a.src_h - 1;
             const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + 4 * i;
             float* trow = tile + r * Cfg::kLdsPitch;
 #pragma unroll
-            for (int c = lane; c < Cfg::kSrcCols; c += 64) {
-                int gx = gx0 + c;
-                gx = gx < a.src_w ? gx : a.src_w - 1;
-                const float v = to_float(srow[gx]);
-                if (c < Cfg::kPairsPerRow) trow[2 * c] = v;        // first element of pair c
-                if (c >= 64) trow[2 * (c - 64) + 1] = v;           // second element of pair c - 64
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kLdsRows && c < Cfg::kSrcCols) {
+                    const float v = to_float(staged[i][k]);
+                    if (c < Cfg::kPairsPerRow) trow[2 * c] = v;        // first element of pair c
+                    if (c >= 64) trow[2 * (c - 64) + 1] = v;           // second element of pair c - 64
+                }
             }
         }
     }
