@@ -343,6 +343,7 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
     ga.io = io;
     ga.rects = rects;
     ga.max_passes = rects.private_sets ? 0 : 4;
+    if (const char* e = std::getenv("JINC_GATHER_PASSES")) ga.max_passes = std::atoi(e);  // A/B knob
     int total = 0;
     for (int r = 0; r < 4; ++r) {
         ga.block_begin[r] = total;
@@ -352,7 +353,7 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
         ga.lines[r] = 4;
         if (r < rects.n && rects.w[r] > 0 && rects.h[r] > 0) {
             int axis, P;
-            gather_rect_layout(plan, rects.w[r], rects.h[r], rects.private_sets, axis, P);
+            gather_rect_layout(plan, rects.w[r], rects.h[r], rects.unit_stride, axis, P);
             const int along = axis == 0 ? rects.w[r] : rects.h[r];
             const int across = axis == 0 ? rects.h[r] : rects.w[r];
             // More lines per block amortise the block's fixed cost (bounds, staging, barrier) and its halo;

@@ -42,6 +42,9 @@ struct RectList {
     // true for the border frame of a plan that is not exactly periodic: there nearly every pixel owns a
     // private coefficient set, so the kernel skips the uniform passes and loads coefficients per lane
     bool private_sets = false;
+    // lane stride 1 instead of the plan's dominant period: for rectangles in which even pixels of one phase never
+    // share a set (corners, border frame of drifting plans) the period stride only thins out the lanes
+    bool unit_stride = false;
     // Optional lane-major copy of the coefficients of these rectangles' pixels (private_sets only): item i of
     // rectangle r (numbering: gather_item_index) owns fs * padded_row(fs) * 64 floats laid out
     // [kernel row][group of 4 taps][lane][4], so the 64 lanes of an item fetch their private coefficients with
@@ -52,13 +55,13 @@ struct RectList {
 
 // How the gather kernel walks a rectangle: lane axis (0: lanes along x, 1: along y) and lane stride P; shared by
 // launch_gather and by the host code that builds RectList::lane_coeffs.
-inline void gather_rect_layout(const DevicePlan& plan, int w, int h, bool private_sets, int& axis, int& P) {
+inline void gather_rect_layout(const DevicePlan& plan, int w, int h, bool unit_stride, int& axis, int& P) {
     // Narrow rectangles (border columns, up to ~fs wide) put the lanes along y: a wave is then not mostly
     // idle, and its lanes share the border column's coefficient sets (along x every lane would own one).
     axis = (w < 64 && h > w) ? 1 : 0;
     // The lane stride exists to give the lanes of an item one coefficient set; where every pixel owns its set it only
     // thins out the lanes of narrow rectangles (a 33-pixel corner: 17 of 64 lanes at stride 2).
-    P = private_sets ? 1 : (axis == 0 ? plan.gather_period_x : plan.gather_period_y);
+    P = unit_stride ? 1 : (axis == 0 ? plan.gather_period_x : plan.gather_period_y);
 }
 // Items of a rectangle are numbered (line * P + residue) * blocks_along + block, with line = row (axis 0) or column
 // (axis 1) inside the rectangle and blocks_along = ceil(extent along the lane axis / (64 * P)).
