@@ -25,7 +25,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JINC_LIB") or os.path.join(_HERE, "lib", "libjincresize_hip.so")  # JINC_LIB: A/B runs against another build
-ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_periodic", "kernel_direct", "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
+ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_periodic", "kernel_direct", "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
                        "kernel_quasi_exact_fs9", "kernel_quasi_lane_fs7", "kernel_quasi_lane_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
 
@@ -77,7 +77,7 @@ ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_hei
 EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
-           "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel",
+           "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_filter_set_pipeline",
            "jinc_filter_submit", "jinc_filter_wait"]
 
@@ -122,6 +122,8 @@ def lib():
         L.jinc_filter_set_border_strips.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_interior_kernel.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_interior_kernel.restype = C.c_char_p
+        L.jinc_filter_last_kernel.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_last_kernel.restype = C.c_char_p
         L.jinc_debug_convert.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]
         L.jinc_filter_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
@@ -320,6 +322,10 @@ class Filter:
 
     def interior_kernel(self, table: int = 0) -> str:
         return lib().jinc_filter_interior_kernel(self._h, int(table)).decode()
+
+    def last_kernel(self, table: int = 0) -> str:
+        """Interior kernel of the most recent frame call (depends on the batch size)."""
+        return lib().jinc_filter_last_kernel(self._h, int(table)).decode()
 
     def set_border_strips(self, mode) -> None:
         """Border frame of exactly periodic plans: True/1 strip kernels (default), 2 rows only, False/0 gather kernel."""

@@ -65,6 +65,9 @@ struct DeviceTable {
     jinc::RectList column_rects;  // otherwise: left / right columns, full height, on the gather kernel
     std::vector<void*> lane_blobs;  // lane-major coefficient copies of the private-set rectangles (RectList::lane_coeffs)
     jinc::RectList whole;         // gather work when it does not
+    bool use_framelane = false;   // frame-lane kernel configured for the whole plane (batches of frames, any plan)
+    jinc::FrameLaneArgs fl_whole;
+    const char* last_kernel = "";  // interior kernel of the most recent call (reports)
 };
 
 struct EventPair {
@@ -292,6 +295,10 @@ void configure(jinc_filter& f, const jinc_video_info& vi, const jinc_args& a) {
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Smallest batch the frame-lane kernel takes over from the gather kernel: its lanes are the frames of the batch, so a
+// batch of n < 64 frames fills n of 64 lanes.
+constexpr int kFrameLaneMinFrames = 16;
 
 // Smallest stride P <= 8 such that at least 90 % of the interior coordinates keep their class when
 // stepping by P (1 if there is none).  Exact for periodic plans; for drifting ratios (1.5x, 3x) it is
@@ -681,6 +688,9 @@ void init_device(jinc_filter& f, int device) {
         plan_direct(f.plans[i], f.tables[i]);
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].border_rects, f.stream);
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].corner_rects, f.stream);
+        f.tables[i].use_framelane =
+            jinc::framelane_configure(f.plans[i], f.tables[i].whole, f.vi_in.component_size, 64, f.tables[i].fl_whole);
+        f.tables[i].fl_whole.plan = f.tables[i].plan;
     }
 }
 
@@ -753,10 +763,19 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         if (!direct_ok(t, i)) return false;
         return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
     };
+    // Frame-lane kernel (lanes = frames): the choice for batches whose plan has no phase structure for the other
+    // interior kernels (they would run on the gather kernel with per-lane coefficient traffic); kernel_mode 11 forces
+    // it for every plan and batch size.
+    auto wants_framelane = [&](const DeviceTable& t, int i) {
+        if (!t.use_framelane || f.kernel_mode == 1) return false;
+        if (f.kernel_mode == 11) return true;
+        if (f.kernel_mode != 0) return false;
+        return nframes >= kFrameLaneMinFrames && !wants_periodic(t) && !wants_quasi(t) && !wants_direct(t, i);
+    };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        any_periodic |= wants_periodic(t) || wants_quasi(t) || wants_direct(t, i);
+        any_periodic |= !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i));
     }
     // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
     // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
@@ -790,9 +809,6 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         io.nframes = nframes;
         io.sample_bytes = sb;
         io.peak = f.peak;
-        const bool direct = wants_direct(t, i);
-        const bool quasi = !direct && wants_quasi(t);
-        const bool periodic = !direct && !quasi && wants_periodic(t);
         auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
             EventPair ev;
             if (f.profiling) {
@@ -806,6 +822,20 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 sink.push_back(ev);
             }
         };
+        if (wants_framelane(t, i)) {
+            jinc::FrameLaneArgs fa = t.fl_whole;
+            fa.io = io;
+            const uintptr_t vec = static_cast<uintptr_t>(4 * sb);
+            fa.vec_store_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
+                              (nframes <= 1 || io.dst_frame_stride % vec == 0);
+            t.last_kernel = "ewa_framelane_kernel";
+            timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            continue;
+        }
+        const bool direct = wants_direct(t, i);
+        const bool quasi = !direct && wants_quasi(t);
+        const bool periodic = !direct && !quasi && wants_periodic(t);
+        t.last_kernel = direct ? "ewa_direct_kernel" : quasi ? "ewa_quasi_kernel" : periodic ? "ewa_periodic_kernel" : "ewa_gather_kernel";
         if (direct || periodic || quasi) {
             // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
             const bool strips = f.border_strips != 0 && t.strips_ok && direct_ok(t, i);
@@ -1218,6 +1248,11 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
     return "ewa_gather_kernel";
 }
 
+const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {
+    if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return "";
+    return f->tables[table].last_kernel;
+}
+
 int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
     f->border_strips = enable < 0 ? 1 : enable > 2 ? 1 : enable;  // 2: rows as strips, columns on the gather kernel
@@ -1226,7 +1261,7 @@ int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 10) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 11) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->kernel_mode = mode;
     return JINC_OK;
 }

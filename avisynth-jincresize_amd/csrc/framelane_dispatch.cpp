@@ -1,0 +1,81 @@
+// framelane_dispatch.cpp -- host side of the frame-lane kernel (kernel_framelane.hip): tile configuration.
+#include <algorithm>
+#include <cstddef>
+#include <cstdlib>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace jinc {
+
+namespace {
+// Largest source extent (window origins are non-decreasing) of a run of `t` consecutive outputs inside [i0, i1).
+int max_extent(const std::vector<int32_t>& start, int i0, int i1, int t, int fs) {
+    int best = 0;
+    for (int a = i0; a < i1; a += t) {
+        const int b = std::min(a + t, i1) - 1;
+        best = std::max(best, start[b] + fs - start[a]);
+    }
+    return best;
+}
+}  // namespace
+
+bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out) {
+    const int ps = kFrameLanePosBytes(static_cast<size_t>(sample_bytes));
+    const int table_bytes = (2 * kFrameLaneMaxTile + kFrameLaneMaxTile * kFrameLaneMaxTile) * 4;
+    // LDS per workgroup: a larger tile has less halo (fewer staged samples per output pixel), a smaller one lets more
+    // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
+    size_t budget = 48 * 1024;
+    if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
+    budget = std::min<size_t>(budget, 64 * 1024);
+    const int groups = std::max(1, (nframes_hint + 63) / 64);
+
+    bool found = false, found_enough = false;
+    double best_cost = 0.0;
+    for (int tys = 5; tys >= 2; --tys)
+        for (int txs = 5; txs >= 2; --txs) {
+            const int tx = 1 << txs, ty = 1 << tys;
+            int max_tw = 0, max_th = 0;
+            long long tiles = 0;
+            for (int r = 0; r < rects.n; ++r) {
+                if (rects.w[r] <= 0 || rects.h[r] <= 0) continue;
+                max_tw = std::max(max_tw, max_extent(p.col_start, rects.x0[r], rects.x0[r] + rects.w[r], tx, p.fs));
+                max_th = std::max(max_th, max_extent(p.row_start, rects.y0[r], rects.y0[r] + rects.h[r], ty, p.fs));
+                tiles += static_cast<long long>((rects.w[r] + tx - 1) / tx) * ((rects.h[r] + ty - 1) / ty);
+            }
+            if (tiles <= 0 || tiles > (1ll << 30) || max_tw > 64) continue;
+            const size_t bytes = table_bytes + (static_cast<size_t>(max_tw) * max_th + 8) * ps;
+            if (bytes > budget) continue;
+            const double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty);
+            const bool enough = tiles * groups >= 1024;  // >= 2 workgroups in flight per CU, twice over
+            if (found && ((found_enough && !enough) || (enough == found_enough && cost >= best_cost))) continue;
+            found = true;
+            found_enough = enough;
+            best_cost = cost;
+            out.tx_shift = txs;
+            out.ty_shift = tys;
+            out.lds_bytes = static_cast<int>(bytes);
+        }
+    if (!found) return false;
+    const int tx = 1 << out.tx_shift, ty = 1 << out.ty_shift;
+    int total = 0;
+    out.rects = RectList{};
+    out.rects.n = rects.n;
+    for (int r = 0; r < 4; ++r) {
+        out.block_begin[r] = total;
+        out.tiles_x[r] = 1;
+        if (r < rects.n) {
+            out.rects.x0[r] = rects.x0[r], out.rects.y0[r] = rects.y0[r], out.rects.w[r] = rects.w[r], out.rects.h[r] = rects.h[r];
+            if (rects.w[r] > 0 && rects.h[r] > 0) {
+                out.tiles_x[r] = (rects.w[r] + tx - 1) / tx;
+                total += out.tiles_x[r] * ((rects.h[r] + ty - 1) / ty);
+            }
+        }
+    }
+    out.block_begin[4] = total;
+    const int units = (tx / 4) * (ty / 4);
+    out.threads = 64 * std::min(8, std::max(1, units));
+    return total > 0;
+}
+
+}  // namespace jinc

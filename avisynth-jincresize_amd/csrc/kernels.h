@@ -159,6 +159,27 @@ struct ColStripArgs {
 bool colstrip_configure(ColStripArgs& args);
 int launch_colstrip(const ColStripArgs& args, const PlaneIO& io, void* stream);
 
+// Frame-lane kernel (kernel_framelane.hip): batches of frames, any plan.  The 64 lanes of a wave are the same output
+// pixel of 64 different frames, so coefficients are wave-uniform (SGPRs) whatever the plan's structure.
+constexpr int kFrameLaneMaxTile = 32;  // output tile edge limit
+constexpr int kFrameLanePosBytes(size_t sample_bytes) { return static_cast<int>(64 * sample_bytes + 4); }  // LDS bytes per source position
+struct FrameLaneArgs {
+    DevicePlan plan;
+    PlaneIO io;
+    RectList rects;           // rectangles of the output plane to compute (x0/y0/w/h only)
+    int block_begin[5] = {0, 0, 0, 0, 0};  // first tile of each rectangle; [4] = number of tiles
+    int tiles_x[4] = {1, 1, 1, 1};
+    int tx_shift = 5, ty_shift = 5;        // tile = (1 << tx_shift) x (1 << ty_shift) output pixels, tx >= 4, ty >= 4
+    int threads = 512;
+    int lds_bytes = 0;
+    int vec_store_ok = 0;     // destination base, pitch and frame stride are multiples of 4 samples
+};
+// Chooses the tile size for the rectangles `rects` of plane plan `p` (host arrays) so that every tile's source
+// footprint fits the LDS budget and is at most 64 columns wide; false if no tile size fits (huge filter footprints).
+struct PlanePlan;
+bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out);
+int launch_framelane(const FrameLaneArgs& args, void* stream);
+
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);
 

@@ -44,13 +44,13 @@ CONFIGS = {
     "N15": ("Y8", 1280, 720, 1920, 1080, dict(tap=3), 64),
     "D23": ("Y8", 1920, 1080, 1280, 720, dict(tap=3), 64),   # 2/3 down-scale: fs = 10, period 2, source step 3
     "N3": ("Y8", 1280, 720, 3840, 2160, dict(tap=3), 64),     # 3x: drifting phases, quasi-periodic kernel
-    "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 16),  # 1.5x with Jinc256: fs 17, drifting -> gather kernel
+    "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 64),  # 1.5x with Jinc256: fs 17, drifting -> gather kernel
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 64),   # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 32),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables
     "N15T4": ("Y8", 1280, 720, 1920, 1080, dict(tap=4), 32),  # 1.5x with Jinc64: fs 9, drifting -> quasi-periodic kernel
-    "A137": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 32),     # 1.37x: no phase structure at all -> gather kernel everywhere
-    "A1875": ("Y8", 1024, 576, 1920, 1080, dict(tap=3), 32),   # PAL -> 1080p, 15/8: period 15, source step 8
-    "D169": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 32),    # 5/6 down-scale: drifting, period 5, source step 6, fs 8
+    "A137": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 64),     # 1.37x: no phase structure at all -> gather kernel everywhere
+    "A1875": ("Y8", 1024, 576, 1920, 1080, dict(tap=3), 64),   # PAL -> 1080p, 15/8: period 15, source step 8
+    "D169": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 64),    # 5/6 down-scale: drifting, period 5, source step 6, fs 8
     "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 32),   # 1/2 down-scale: fs = 13, period 1, source step 2
     "D12H": ("YUV420P16", 3840, 2160, 1920, 1080, dict(tap=3), 16),  # 4K 16-bit 4:2:0 -> 1080p
     "D12F": ("RGBPS", 3840, 2160, 1920, 1080, dict(tap=3), 8),       # 4K float RGB -> 1080p
@@ -258,7 +258,7 @@ def main():
         src_bytes_frame = sum(w * h for (w, h) in fmt.plane_dims(sw, sh)) * sb
         n_planes = fmt.planes
         if per_n > 0:
-            dom_name, dom_ms, dom_n = flt.interior_kernel(0), per_ms, per_n
+            dom_name, dom_ms, dom_n = flt.last_kernel(0), per_ms, per_n
         else:
             dom_name, dom_ms, dom_n = "ewa_gather_kernel", gat_ms, gat_n
         # one launch per plane per step; algorithmic bytes of a launch = the batch's bytes for that plane,

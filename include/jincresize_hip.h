@@ -222,10 +222,15 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * 7 = the quasi-periodic kernel wherever it applies (it is the automatic choice only for drifting ratios),
  * 8 = its waterfall variant (coefficient sets in SGPRs, one pass per distinct set of a wave) and 10 = its per-lane
  * coefficient variant (the default for drifting ratios) on every plan they apply to, 9 = the direct (no-LDS) periodic kernel wherever
- * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8). */
+ * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8), 11 = the frame-lane kernel
+ * (lanes of a wave = frames of the batch; the automatic choice for batches of >= 16 frames whose plan has no phase
+ * structure) for every plan and batch size. */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
 JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);
+/* Name of the kernel that computed the interior of `table` in the most recent frame call (the choice depends on the
+ * batch size: the frame-lane kernel needs a batch). "" before the first call. */
+JINC_API const char *jinc_filter_last_kernel(const jinc_filter *f, int table);
 /* Border frame of exactly periodic plans: 1 (default) = rows and columns on the strip kernels, corners on the
  * gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel; 0 = everything on the
  * gather kernel (A/B measurements, tests). */

@@ -1,0 +1,106 @@
+"""GPU parity tests of the frame-lane kernel (kernel_framelane.hip: the 64 lanes of a wave are one output pixel of
+64 different frames).  Through the C ABI, bit-exact against the CPU oracle: every small geometry case as a single frame
+(kernel mode 11 = forced), and device-resident batches of distinct frames in every lane-fill state (1, partial wave,
+64, 64 + partial, 2 x 64 + partial)."""
+import numpy as np
+import pytest
+
+from conftest import assert_planes_equal, oracle_kwargs
+from test_gpu_parity import SMALL_CASES, _id
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", SMALL_CASES, ids=_id)
+def test_single_frame_through_the_framelane_kernel(gpu_pkg, O, case):
+    fmt, sw, sh, tw, th, kw = case
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=4242)
+    want = of.get_frame(src, threads=4)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    f.set_kernel_mode(11)
+    got = f.get_frame(src)
+    if f.last_kernel(0) != "ewa_framelane_kernel":  # footprints beyond the 64 KB LDS tile fall back to the other kernels
+        fs, sb = of.tables[0].filter_size, np.dtype(O.FORMATS[fmt].dtype).itemsize
+        assert (fs + 3) ** 2 * (64 * sb + 4) > 48 * 1024, f"frame-lane kernel not used for fs {fs}, {sb}-byte samples"
+    assert_planes_equal(got, want, f.out_dims(), what=_id(case))
+    f.close()
+
+
+BATCH_CASES = [
+    # (format, src, dst, args, batch sizes)
+    ("Y8", 160, 90, 219, 123, {}, (1, 3, 16, 64, 70, 130)),                  # 1.37x: no phase structure, fs 7
+    ("Y16", 160, 90, 219, 123, {}, (17, 65)),
+    ("Y32", 160, 90, 219, 123, {}, (17, 64)),
+    ("Y8", 192, 108, 160, 90, {}, (33, 64)),                                 # 5/6 down-scale: fs 8
+    ("Y8", 128, 72, 192, 108, dict(tap=8), (20, 64)),                        # 1.5x with tap 8: fs 17, drifting
+    ("Y8", 128, 72, 240, 135, dict(tap=4), (40,)),                           # 15/8 with tap 4: fs 9
+    ("Y8", 150, 100, 330, 190, dict(tap=6), (24,)),                          # fs 13: run-time filter size path
+    ("Y10", 160, 90, 219, 123, dict(tap=2), (19,)),                          # fs 5 (run-time path), peak 1023
+    ("YUV420P8", 160, 96, 222, 130, dict(cplace="topleft"), (18,)),          # luma + chroma tables
+    ("RGBPS", 96, 64, 131, 90, dict(tap=4, blur=0.98), (16,)),
+    ("Y8", 64, 48, 397, 301, dict(src_left=1.5, src_top=-2.25, src_width=50.5, src_height=40.125), (16,)),  # 7.9x, crop
+]
+
+
+@pytest.mark.parametrize("case", BATCH_CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
+def test_batches_of_frames(gpu_pkg, O, case):
+    """jinc_filter_process_device on distinct frames: every frame of the batch against the oracle, for batch sizes that
+    leave lanes idle, fill a wave exactly and spill into further frame groups.  Batches of >= 16 frames of plans
+    without phase structure take the frame-lane kernel by themselves; smaller ones are forced (kernel mode 11)."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th, kw, sizes = case
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    of = O.OracleFilter(ofmt, sw, sh, tw, th, **oracle_kwargs(kw))
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, **kw)
+    ddims = f.out_dims()
+    nmax = max(sizes)
+    frames = [O.lcg_frame(ofmt, sw, sh, seed=900 + i) for i in range(nmax)]
+    wants = [of.get_frame(fr, threads=8) for fr in frames]
+    np_dtype = frames[0][0].dtype
+    tdtype = {np.dtype(np.uint8): torch.uint8, np.dtype(np.uint16): torch.int16, np.dtype(np.float32): torch.float32}[np.dtype(np_dtype)]
+    sb = np.dtype(np_dtype).itemsize
+
+    def to_t(a):
+        a = np.ascontiguousarray(a)
+        return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
+
+    for n in sizes:
+        src_t = [torch.stack([to_t(fr[i]) for fr in frames[:n]]).cuda() for i in range(gfmt.planes)]
+        dst_t = [torch.zeros((n, h, (w * sb + 63) // 64 * 64 // sb), dtype=tdtype, device="cuda") for (w, h) in ddims]
+        f.set_kernel_mode(0 if n >= 16 else 11)
+        stream = torch.cuda.current_stream()
+        f.process_device([t.data_ptr() for t in src_t], [t.stride(1) * sb for t in src_t], [t.stride(0) * sb for t in src_t],
+                         [t.data_ptr() for t in dst_t], [t.stride(1) * sb for t in dst_t], [t.stride(0) * sb for t in dst_t],
+                         n, stream=stream.cuda_stream)
+        stream.synchronize()
+        assert f.last_kernel(0) == "ewa_framelane_kernel", f.last_kernel(0)
+        for k in range(n):
+            got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
+            assert_planes_equal(got, wants[k], ddims, what=f"batch {n} frame {k}")
+    f.close()
+
+
+def test_unaligned_destination_takes_the_sample_stores(gpu_pkg, O):
+    """A destination whose base / pitch is not a multiple of 4 samples cannot take the packed 4-sample stores."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th, n = "Y8", 100, 60, 137, 83, 20
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=50 + i) for i in range(n)]
+    src_t = torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]).cuda()
+    for pitch, offset in ((139, 0), (140, 1), (141, 3)):
+        buf = torch.full((n * th * pitch + 8,), 0xAB, dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.current_stream()
+        f.process_device([src_t.data_ptr()], [src_t.stride(1)], [src_t.stride(0)], [buf.data_ptr() + offset], [pitch],
+                         [th * pitch], n, stream=stream.cuda_stream)
+        stream.synchronize()
+        assert f.last_kernel(0) == "ewa_framelane_kernel"
+        out = buf.cpu().numpy()
+        body = out[offset:offset + n * th * pitch].reshape(n, th, pitch)
+        for k in range(n):
+            want = of.get_frame(frames[k], threads=4)[0][:th, :tw]
+            assert np.array_equal(body[k, :, :tw], want), f"pitch {pitch} offset {offset} frame {k}"
+        assert (body[:, :, tw:] == 0xAB).all(), "padding between rows was written"
+        assert (out[:offset] == 0xAB).all() and (out[offset + n * th * pitch:] == 0xAB).all()
+    f.close()
