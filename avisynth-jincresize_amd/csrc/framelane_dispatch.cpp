@@ -25,7 +25,7 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     const int table_bytes = (2 * kFrameLaneMaxTile + kFrameLaneMaxTile * kFrameLaneMaxTile) * 4;
     // LDS per workgroup: a larger tile has less halo (fewer staged samples per output pixel), a smaller one lets more
     // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
-    size_t budget = 48 * 1024;
+    size_t budget = 64 * 1024;  // A/B (64 frames): 1.37x fs 7 48 KB = 64 KB; 5/6 down-scale fs 8 +28 % over 48 KB
     if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
     budget = std::min<size_t>(budget, 64 * 1024);
     const int groups = std::max(1, (nframes_hint + 63) / 64);
@@ -44,7 +44,8 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
                 tiles += static_cast<long long>((rects.w[r] + tx - 1) / tx) * ((rects.h[r] + ty - 1) / ty);
             }
             if (tiles <= 0 || tiles > (1ll << 30) || max_tw > 64) continue;
-            const size_t bytes = table_bytes + (static_cast<size_t>(max_tw) * max_th + 8) * ps;
+            // (+ 1 row: the sliding-window form pads the column pitch of its column-major tile to an odd number)
+            const size_t bytes = table_bytes + (static_cast<size_t>(max_tw) * (max_th + 1) + 8) * ps;
             if (bytes > budget) continue;
             const double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty);
             const bool enough = tiles * groups >= 1024;  // >= 2 workgroups in flight per CU, twice over
@@ -75,6 +76,9 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     out.block_begin[4] = total;
     const int units = (tx / 4) * (ty / 4);
     out.threads = 64 * std::min(8, std::max(1, units));
+    if (const char* e = std::getenv("JINC_FL_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
+    out.variant = 0;
+    if (const char* e = std::getenv("JINC_FL_VARIANT")) out.variant = std::atoi(e);  // A/B knob: 1 = row-segment form always
     return total > 0;
 }
 

@@ -67,11 +67,11 @@ __device__ __forceinline__ typename FlPack<T>::type fl_pack(const float (&r)[4],
     }
 }
 
-// One chunk of N <= 8 taps of one source row for the K chains of an output column: samples from the LDS tile (converted
-// once), K coefficient rows through scalar loads, then the chains whose window holds this source row.
-template <typename T, int K, int N>
-__device__ __forceinline__ void fl_chunk(float (&acc)[K], const char* lds, const JINC_CONSTANT float* const (&cp)[K],
-                                         const bool (&on)[K]) {
+// One chunk of N <= 8 taps of one source row for the chains KLO..KHI of an output column (all of them hold this source
+// row): samples from the LDS tile (read and converted once), one coefficient row per chain through scalar loads.
+template <typename T, int K, int N, int KLO, int KHI>
+__device__ __forceinline__ void fl_chunk(float (&acc)[K], const char* lds, const JINC_CONSTANT char* cbase, const uint32_t (&co)[K],
+                                         uint32_t cofs) {
     constexpr int PS = kFrameLanePosBytes(sizeof(T));
     constexpr int NL = (N + 3) & ~3;  // coefficient rows are padded to multiples of 4 floats
     float seg[N];
@@ -79,24 +79,342 @@ __device__ __forceinline__ void fl_chunk(float (&acc)[K], const char* lds, const
     for (int j = 0; j < N; ++j) seg[j] = to_float(*reinterpret_cast<const T*>(lds + j * PS));
     float c[K][NL];
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int k = KLO; k <= KHI; ++k) {
+        // one base pointer + a 32-bit byte offset per chain: s_load_dwordxN sdst, sbase, soffset (no 64-bit scalar
+        // address arithmetic per row and chain)
+        const JINC_CONSTANT float* cp = reinterpret_cast<const JINC_CONSTANT float*>(cbase + (co[k] + cofs));
 #pragma unroll
-        for (int j = 0; j < NL; ++j) c[k][j] = cp[k][j];
-    // All K coefficient rows are requested together, in front of the wave-uniform branches (left alone the compiler sinks
-    // each row's scalar loads into its branch: load -> wait -> 14 VALU, K times per source row).
+        for (int j = 0; j < NL; ++j) c[k][j] = cp[j];
+    }
+    // every coefficient row of the chunk is requested before the first multiply (one wait per chunk)
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int k = KLO; k <= KHI; ++k)
 #pragma unroll
         for (int j = 0; j < NL; ++j) asm volatile("" : "+s"(c[k][j]));
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (on[k]) {
+    for (int k = KLO; k <= KHI; ++k)
 #pragma unroll
-            for (int j = 0; j < N; ++j) acc[k] = acc[k] + seg[j] * c[k][j];
+        for (int j = 0; j < N; ++j) acc[k] = acc[k] + seg[j] * c[k][j];
+}
+
+// `nrows` consecutive source rows, starting with row `rr`, of one output column, for the chains KLO..KHI -- exactly the
+// chains whose windows hold all of these rows, so the loop has no per-row conditions: the scalar unit (one per CU,
+// shared by the four SIMDs) only advances KHI-KLO+1 offsets and the counter per row.
+template <typename T, int FS, int K, int KLO, int KHI>
+__device__ __forceinline__ void fl_rows(float (&acc)[K], const char* lrow, int lrow_step, int rr, int nrows, const int (&sy)[K],
+                                        const uint32_t (&cb)[K], const JINC_CONSTANT char* cbase, uint32_t row_bytes, int fs) {
+    constexpr int PS = kFrameLanePosBytes(sizeof(T));
+    uint32_t co[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) co[k] = cb[k] + static_cast<uint32_t>(rr - sy[k]) * row_bytes;  // (used for KLO..KHI only)
+    for (int i = 0; i < nrows; ++i) {
+        if constexpr (FS != 0) {
+#pragma unroll
+            for (int c0 = 0; c0 < FS; c0 += 8) {
+                if (FS - c0 >= 8)
+                    fl_chunk<T, K, 8, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4);
+                else
+                    fl_chunk<T, K, (FS % 8 ? FS % 8 : 8), KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4);
+            }
+        } else {
+            for (int c0 = 0; c0 < fs; c0 += 8) {
+                const int n = fs - c0;  // wave-uniform
+                if (n >= 8) {
+                    fl_chunk<T, K, 8, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4);
+                } else {
+                    switch (n) {
+                        case 1: fl_chunk<T, K, 1, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                        case 2: fl_chunk<T, K, 2, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                        case 3: fl_chunk<T, K, 3, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                        case 4: fl_chunk<T, K, 4, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                        case 5: fl_chunk<T, K, 5, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                        case 6: fl_chunk<T, K, 6, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                        default: fl_chunk<T, K, 7, KLO, KHI>(acc, lrow + c0 * PS, cbase, co, c0 * 4); break;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = KLO; k <= KHI; ++k) co[k] += row_bytes;
+        lrow += lrow_step;
+    }
+}
+
+template <typename T, int FS, int K>
+__device__ __forceinline__ void fl_rows_dispatch(int klo, int khi, float (&acc)[K], const char* lrow, int lrow_step, int rr, int nrows,
+                                                 const int (&sy)[K], const uint32_t (&cb)[K], const JINC_CONSTANT char* cbase,
+                                                 uint32_t row_bytes, int fs) {
+    static_assert(K == 4, "the dispatch below lists the chain ranges of K = 4");
+#define JINC_FL_ROWS(LO, HI) \
+    case LO * 4 + HI: fl_rows<T, FS, K, LO, HI>(acc, lrow, lrow_step, rr, nrows, sy, cb, cbase, row_bytes, fs); break;
+    switch (klo * 4 + khi) {
+        JINC_FL_ROWS(0, 0) JINC_FL_ROWS(0, 1) JINC_FL_ROWS(0, 2) JINC_FL_ROWS(0, 3) JINC_FL_ROWS(1, 1) JINC_FL_ROWS(1, 2)
+        JINC_FL_ROWS(1, 3) JINC_FL_ROWS(2, 2) JINC_FL_ROWS(2, 3) JINC_FL_ROWS(3, 3)
+        default: break;
+    }
+#undef JINC_FL_ROWS
+}
+
+// Tile of a workgroup and its source footprint (all wave-uniform).
+struct FlTile {
+    int bx0, by0, bx1, by1;  // output pixels, inclusive
+    int tx0, ty0, tw, th;    // source footprint: origin and extent
+    int f0, nfg;             // first frame of the group, frames in it (<= 64)
+};
+
+// block -> tile.  Workgroups are dealt round-robin over the 8 XCDs by linear id; XCD k walks the contiguous run of
+// tiles [k*q + min(k, rem), ...) so that the halos shared by neighbouring tiles stay in one L2.  False: padding block.
+__device__ __forceinline__ bool fl_locate(const FrameLaneArgs& a, int fs, FlTile& t) {
+    const DevicePlan& p = a.plan;
+    const int ntiles = a.block_begin[4];
+    const int q = ntiles / 8, rem = ntiles % 8;
+    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    if (idx >= q + (xcd < rem ? 1 : 0)) return false;
+    const int tid = xcd * q + (xcd < rem ? xcd : rem) + idx;
+    int r = 0;
+    while (r + 1 < a.rects.n && tid >= a.block_begin[r + 1]) ++r;
+    const int local = tid - a.block_begin[r];
+    const int tcx = local % a.tiles_x[r], tcy = local / a.tiles_x[r];
+    const int rx1 = a.rects.x0[r] + a.rects.w[r], ry1 = a.rects.y0[r] + a.rects.h[r];
+    t.bx0 = a.rects.x0[r] + (tcx << a.tx_shift), t.by0 = a.rects.y0[r] + (tcy << a.ty_shift);
+    t.bx1 = min(t.bx0 + (1 << a.tx_shift), rx1) - 1, t.by1 = min(t.by0 + (1 << a.ty_shift), ry1) - 1;
+    t.tx0 = p.col_start[t.bx0], t.ty0 = p.row_start[t.by0];
+    t.tw = p.col_start[t.bx1] + fs - t.tx0;  // <= 64 (host: framelane_configure)
+    t.th = p.row_start[t.by1] + fs - t.ty0;
+    t.f0 = blockIdx.y * 64;
+    t.nfg = min(64, a.io.nframes - t.f0);
+    return true;
+}
+
+// Per-tile tables in LDS: window origins and the coefficient set of every pixel (looked up once per pixel for 64 frames).
+__device__ __forceinline__ void fl_tables(const FrameLaneArgs& a, const FlTile& t, int* cs, int* rs, int* sets) {
+    const DevicePlan& p = a.plan;
+    for (int i = threadIdx.x; i < (1 << a.tx_shift); i += blockDim.x) cs[i] = p.col_start[min(t.bx0 + i, t.bx1)];
+    for (int i = threadIdx.x; i < (1 << a.ty_shift); i += blockDim.x) rs[i] = p.row_start[min(t.by0 + i, t.by1)];
+    for (int i = threadIdx.x; i < (1 << (a.tx_shift + a.ty_shift)); i += blockDim.x) {
+        const int ix = i & ((1 << a.tx_shift) - 1), iy = i >> a.tx_shift;
+        const int qx = min(t.bx0 + ix, t.bx1), qy = min(t.by0 + iy, t.by1);
+        const int rc = p.row_class[qy], cc = p.col_class[qx];
+        int set;
+        if (rc < 0)
+            set = p.brow_set[static_cast<size_t>(~rc) * p.dst_w + qx];
+        else if (cc < 0)
+            set = p.bcol_set[static_cast<size_t>(~cc) * p.dst_h + qy];
+        else
+            set = p.interior_set[rc * p.n_col_classes + cc];
+        sets[iy * kFrameLaneMaxTile + ix] = set;
+    }
+}
+
+// Stages the source footprint of the group's frames in LDS in the source format, one position per source sample of the
+// tile and 64 frames per position: position (row, col) = row * row_pos + col * col_pos.  Global loads run along the
+// columns of one frame (coalesced), 16 in flight per lane.
+template <typename T>
+__device__ __forceinline__ void fl_stage(const FrameLaneArgs& a, const FlTile& t, char* tile, int row_pos, int col_pos, int lane,
+                                         int wave, int nwaves) {
+    constexpr int PS = kFrameLanePosBytes(sizeof(T));
+    constexpr int SB = static_cast<int>(sizeof(T));
+    const int tw = t.tw, th = t.th;
+    const int sh = tw <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned>(tw - 1));  // lanes per row = 1 << sh >= tw
+    const int lc = lane & ((1 << sh) - 1), lr = lane >> sh, rps = 64 >> sh;
+    const int nsteps = (th + rps - 1) >> (6 - sh);
+    const int colc = min(lc, tw - 1);
+    constexpr int U = 16;
+    for (int fi = wave; fi < t.nfg; fi += nwaves) {
+        const char* sframe = static_cast<const char*>(a.io.src) + static_cast<size_t>(t.f0 + fi) * a.io.src_frame_stride +
+                             static_cast<size_t>(t.ty0) * a.io.src_pitch + static_cast<size_t>(t.tx0 + colc) * SB;
+        char* lds_f = tile + fi * SB + lc * col_pos * PS;
+        for (int s0 = 0; s0 < nsteps; s0 += U) {
+            T v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int row = min((s0 + j) * rps + lr, th - 1);
+                v[j] = *reinterpret_cast<const T*>(sframe + static_cast<size_t>(row) * a.io.src_pitch);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int row = (s0 + j) * rps + lr;
+                if (row < th && lc < tw) *reinterpret_cast<T*>(lds_f + row * row_pos * PS) = v[j];
+            }
         }
     }
 }
 
+// Stores up to four horizontally adjacent results of a lane's frame: one packed store where the address allows it.
+template <typename T>
+__device__ __forceinline__ void fl_store4(char* d, const float (&res)[4], int nvx, bool vec, float peak) {
+    if (vec) {
+        *reinterpret_cast<typename FlPack<T>::type*>(d) = fl_pack<T>(res, peak);
+    } else {
+#pragma unroll
+        for (int xx = 0; xx < 4; ++xx)
+            if (xx < nvx) store_sample<T>(reinterpret_cast<T*>(d) + xx, res[xx], peak);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sliding-window form, filter sizes up to 9: a wave walks along an output row; the fs x fs window of its 64 frames stays
+// in registers as a ring over source columns (compile-time ring phase: FS code variants), so a pixel costs the new
+// window columns (source step, 0.5 .. 2 per pixel) x fs LDS reads and conversions, fs scalar coefficient-row loads and
+// the 2 * fs * fs multiply / add with static register indices -- no per-row conditions, about 25 scalar instructions.
+// LDS positions are column-major here ((col, row) -> col * (th | 1) + row): a window column is fs consecutive positions.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int FS, int PH>
+__device__ __forceinline__ float fl_win_mac(const float (&w)[FS][FS], const JINC_CONSTANT char* cset) {
+    constexpr int FSP = padded_row(FS);
+    constexpr int G = 56 / FSP >= FS ? FS : (56 / FSP);  // coefficient rows per batch of scalar loads (<= 56 SGPRs)
+    float acc = 0.f;
+#pragma unroll
+    for (int g0 = 0; g0 < FS; g0 += G) {
+        float c[G][FSP];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g0 + g < FS) {
+                const JINC_CONSTANT float* cp = reinterpret_cast<const JINC_CONSTANT float*>(cset + (g0 + g) * FSP * 4);
+#pragma unroll
+                for (int lx = 0; lx < FSP; ++lx) c[g][lx] = cp[lx];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g0 + g < FS) {
+#pragma unroll
+                for (int lx = 0; lx < FSP; ++lx) asm volatile("" : "+s"(c[g][lx]));
+            }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (g0 + g < FS) {
+#pragma unroll
+                for (int lx = 0; lx < FS; ++lx) acc = acc + w[(PH + lx) % FS][g0 + g] * c[g][lx];
+            }
+    }
+    return acc;
+}
+
+template <typename T, int FS>
+__device__ __forceinline__ void fl_win_load_col(float (&col)[FS], const char* p) {
+    constexpr int PS = kFrameLanePosBytes(sizeof(T));
+#pragma unroll
+    for (int ly = 0; ly < FS; ++ly) col[ly] = to_float(*reinterpret_cast<const T*>(p + ly * PS));
+}
+
+// One window origin `s` of a strip at ring phase I: the column completing its window, then every pixel with this origin.
+// False: past the strip's last origin.
+template <typename T, int FS, int I>
+__device__ __forceinline__ bool fl_win_step(float (&w)[FS][FS], const char*& pc, int pc_step, int s, int s_last, int& j, int npix, int csv,
+                                            int setv, const JINC_CONSTANT char* cbase, float (&res)[4], char* drow, bool lane_on,
+                                            bool vec_ok, float peak) {
+    constexpr int SB = static_cast<int>(sizeof(T));
+    constexpr uint32_t kSetBytes = FS * padded_row(FS) * 4;
+    if (s > s_last) return false;  // wave-uniform
+    fl_win_load_col<T, FS>(w[(I + FS - 1) % FS], pc);  // column s + FS - 1
+    pc += pc_step;
+    while (j < npix && __builtin_amdgcn_readlane(csv, j) == s) {
+        const uint32_t soff = static_cast<uint32_t>(__builtin_amdgcn_readlane(setv, j)) * kSetBytes;
+        const float acc = fl_win_mac<T, FS, I>(w, cbase + soff);
+        switch (j & 3) {
+            case 0: res[0] = acc; break;
+            case 1: res[1] = acc; break;
+            case 2: res[2] = acc; break;
+            default: res[3] = acc; break;
+        }
+        if ((j & 3) == 3 || j == npix - 1) {
+            const int nvx = (j & 3) + 1;
+            if (lane_on) fl_store4<T>(drow + static_cast<size_t>(j & ~3) * SB, res, nvx, vec_ok && nvx == 4, peak);
+        }
+        ++j;
+    }
+    return true;
+}
+
+template <typename T, int FS>
+__global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fl_smem[];
+    int* cs = reinterpret_cast<int*>(fl_smem);
+    int* rs = cs + kFrameLaneMaxTile;
+    int* sets = rs + kFrameLaneMaxTile;
+    char* tile = fl_smem + kFlTableInts * 4;
+    constexpr int PS = kFrameLanePosBytes(sizeof(T));
+    constexpr int SB = static_cast<int>(sizeof(T));
+    constexpr uint32_t kSetBytes = FS * padded_row(FS) * 4;
+    const DevicePlan& p = a.plan;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    FlTile t;
+    if (!fl_locate(a, FS, t)) return;  // whole block, before any barrier
+    fl_tables(a, t, cs, rs, sets);
+    __syncthreads();
+
+    // Coefficient sets of a strip (one output row of the tile, <= 32 pixels), requested one strip ahead with VECTOR
+    // loads, one cache line per lane: see ewa_framelane_kernel.
+    const int nstrips = t.by1 - t.by0 + 1, npix = t.bx1 - t.bx0 + 1;
+    auto prefetch_strip = [&](int st) -> uint32_t {
+        uint32_t keep = 0;
+        if (st < nstrips) {
+            const int set = sets[st * kFrameLaneMaxTile + min(lane & 31, npix - 1)];  // (entries past the tile's width are not filled)
+            const char* sp = reinterpret_cast<const char*>(p.coeffs) + static_cast<size_t>(static_cast<uint32_t>(set) * kSetBytes);
+            for (uint32_t off = static_cast<uint32_t>(lane >> 5) * 64u; off < kSetBytes + 60u; off += 128u)
+                keep |= *reinterpret_cast<const uint32_t*>(sp + (off < kSetBytes - 4u ? off : kSetBytes - 4u));
+        }
+        return keep;
+    };
+    uint32_t pf_keep = prefetch_strip(wave);
+
+    const int thp = t.th | 1;  // odd column pitch: the staging writes of neighbouring columns fall on different banks
+    fl_stage<T>(a, t, tile, 1, thp, lane, wave, nwaves);
+    __syncthreads();
+    asm volatile("" ::"v"(pf_keep));
+    // Lanes without a frame (last group of the batch) stay active: the strip tables below live one pixel per LANE and are
+    // read with v_readlane, so every lane has to load its entry.  Such lanes compute on unwritten LDS and store nothing.
+    const bool lane_on = lane < t.nfg;
+
+    char* dframe = static_cast<char*>(a.io.dst) + static_cast<size_t>(t.f0 + (lane_on ? lane : 0)) * a.io.dst_frame_stride;
+    const char* lds_lane = tile + lane * SB;
+    const JINC_CONSTANT char* cbase = (const JINC_CONSTANT char*)(p.coeffs);
+    const bool vec_ok = a.vec_store_ok && ((t.bx0 & 3) == 0);
+    for (int st = wave; st < nstrips; st += nwaves) {
+        asm volatile("" ::"v"(pf_keep));
+        pf_keep = prefetch_strip(st + nwaves);
+        const int sy = __builtin_amdgcn_readfirstlane(rs[st]);
+        const int pj = min(lane & 31, npix - 1);
+        const int csv = cs[pj];                              // lane j: window origin of the strip's pixel j
+        const int setv = sets[st * kFrameLaneMaxTile + pj];  // ... and its coefficient set
+        const char* lrow = lds_lane + (sy - t.ty0) * PS;            // column c of the window rows: + (c - tx0) * thp * PS
+        char* drow = dframe + static_cast<size_t>(t.by0 + st) * a.io.dst_pitch + static_cast<size_t>(t.bx0) * SB;
+        // The strip is walked by WINDOW ORIGIN (source column), not by pixel: consecutive origins advance the ring by
+        // exactly one column, so with the origin loop unrolled FS times the ring phase -- and with it every register index
+        // of the tap loop -- is a compile-time constant (a switch on a run-time phase makes the compiler copy the whole
+        // window between the cases).  An origin serves 0, 1 or 2 pixels (source step 0.5 .. 2).
+        float w[FS][FS];  // w[slot][ly]; source column c of the strip lives in slot (c - s_first) % FS
+        const int s_first = __builtin_amdgcn_readlane(csv, 0), s_last = __builtin_amdgcn_readlane(csv, npix - 1);
+        const char* pc = lrow + (s_first - t.tx0) * thp * PS;  // next column to load
+#pragma unroll
+        for (int i = 0; i < FS - 1; ++i) {
+            fl_win_load_col<T, FS>(w[i], pc);
+            pc += thp * PS;
+        }
+        int j = 0;
+        float res[4] = {0.f, 0.f, 0.f, 0.f};
+        static_assert(FS <= 9, "the step list below has nine entries");
+        for (int s0 = s_first; s0 <= s_last; s0 += FS) {
+#define JINC_FL_STEP(I)                                                                                                           \
+    if constexpr (I < FS) {                                                                                                        \
+        if (!fl_win_step<T, FS, (I < FS ? I : 0)>(w, pc, thp * PS, s0 + I, s_last, j, npix, csv, setv, cbase, res, drow, lane_on, \
+                                                  vec_ok, a.io.peak))                                                             \
+            break;                                                                                                                 \
+    }
+            JINC_FL_STEP(0) JINC_FL_STEP(1) JINC_FL_STEP(2) JINC_FL_STEP(3) JINC_FL_STEP(4) JINC_FL_STEP(5) JINC_FL_STEP(6)
+            JINC_FL_STEP(7) JINC_FL_STEP(8)
+#undef JINC_FL_STEP
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-segment form, any filter size: units of 4 x K output pixels, K chains below each other share each source row
+// segment read from LDS.
+// ------------------------------------------------------------------------------------------------
 template <typename T, int FS, int K>
 __global__ __launch_bounds__(512) void ewa_framelane_kernel(const FrameLaneArgs a) {
     extern __shared__ __attribute__((aligned(16))) char fl_smem[];
@@ -111,87 +429,49 @@ __global__ __launch_bounds__(512) void ewa_framelane_kernel(const FrameLaneArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-
-    // ---- block -> tile.  Workgroups are dealt round-robin over the 8 XCDs by linear id; XCD k walks the contiguous
-    // run of tiles [k*q + min(k, rem), ...) so that the halos shared by neighbouring tiles stay in one L2.
-    const int ntiles = a.block_begin[4];
-    int tid;
-    {
-        const int q = ntiles / 8, rem = ntiles % 8;
-        const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-        if (idx >= q + (xcd < rem ? 1 : 0)) return;  // padding ids; whole block, before any barrier
-        tid = xcd * q + (xcd < rem ? xcd : rem) + idx;
-    }
-    int r = 0;
-    while (r + 1 < a.rects.n && tid >= a.block_begin[r + 1]) ++r;
-    const int local = tid - a.block_begin[r];
-    const int tcx = local % a.tiles_x[r], tcy = local / a.tiles_x[r];
-    const int rx1 = a.rects.x0[r] + a.rects.w[r], ry1 = a.rects.y0[r] + a.rects.h[r];
-    const int bx0 = a.rects.x0[r] + (tcx << a.tx_shift), by0 = a.rects.y0[r] + (tcy << a.ty_shift);
-    const int bx1 = min(bx0 + (1 << a.tx_shift), rx1) - 1, by1 = min(by0 + (1 << a.ty_shift), ry1) - 1;  // inclusive
-
     const int fs = FS ? FS : p.fs;
     const int fsp = padded_row(fs);
-    const int f0 = blockIdx.y * 64;
-    const int nfg = min(64, a.io.nframes - f0);  // frames of this group
-
-    // ---- per-tile tables: window origins and set ids (looked up once per pixel for 64 frames) ----
-    for (int t = threadIdx.x; t < (1 << a.tx_shift); t += blockDim.x) cs[t] = p.col_start[min(bx0 + t, bx1)];
-    for (int t = threadIdx.x; t < (1 << a.ty_shift); t += blockDim.x) rs[t] = p.row_start[min(by0 + t, by1)];
-    for (int i = threadIdx.x; i < (1 << (a.tx_shift + a.ty_shift)); i += blockDim.x) {
-        const int ix = i & ((1 << a.tx_shift) - 1), iy = i >> a.tx_shift;
-        const int qx = min(bx0 + ix, bx1), qy = min(by0 + iy, by1);
-        const int rc = p.row_class[qy], cc = p.col_class[qx];
-        int set;
-        if (rc < 0)
-            set = p.brow_set[static_cast<size_t>(~rc) * p.dst_w + qx];
-        else if (cc < 0)
-            set = p.bcol_set[static_cast<size_t>(~cc) * p.dst_h + qy];
-        else
-            set = p.interior_set[rc * p.n_col_classes + cc];
-        sets[iy * kFrameLaneMaxTile + ix] = set;
-    }
-
-    // ---- stage the source footprint of the group's frames: [row][column][frame], source format ----
-    const int tx0 = p.col_start[bx0], ty0 = p.row_start[by0];
-    const int tw = p.col_start[bx1] + fs - tx0;  // <= 64 (host: framelane_configure)
-    const int th = p.row_start[by1] + fs - ty0;
-    {
-        const int sh = tw <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned>(tw - 1));  // lanes per row = 1 << sh >= tw
-        const int lc = lane & ((1 << sh) - 1), lr = lane >> sh, rps = 64 >> sh;
-        const int nsteps = (th + rps - 1) >> (6 - sh);
-        const int colc = min(lc, tw - 1);
-        constexpr int U = 16;  // loads in flight per lane
-        for (int fi = wave; fi < nfg; fi += nwaves) {
-            const char* sframe = static_cast<const char*>(a.io.src) + static_cast<size_t>(f0 + fi) * a.io.src_frame_stride +
-                                 static_cast<size_t>(ty0) * a.io.src_pitch + static_cast<size_t>(tx0 + colc) * SB;
-            char* lds_f = tile + fi * SB + lc * PS;
-            for (int s0 = 0; s0 < nsteps; s0 += U) {
-                T v[U];
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const int row = min((s0 + j) * rps + lr, th - 1);
-                    v[j] = *reinterpret_cast<const T*>(sframe + static_cast<size_t>(row) * a.io.src_pitch);
-                }
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const int row = (s0 + j) * rps + lr;
-                    if (row < th && lc < tw) *reinterpret_cast<T*>(lds_f + row * tw * PS) = v[j];
-                }
-            }
-        }
-    }
+    FlTile t;
+    if (!fl_locate(a, fs, t)) return;  // padding ids; whole block, before any barrier
+    const int bx0 = t.bx0, by0 = t.by0, bx1 = t.bx1, by1 = t.by1, tx0 = t.tx0, ty0 = t.ty0, tw = t.tw, f0 = t.f0, nfg = t.nfg;
+    fl_tables(a, t, cs, rs, sets);
     __syncthreads();
+
+    // Coefficient sets of a unit (4 x K pixels), requested with VECTOR loads one unit ahead, one cache line per lane:
+    // for a plan without phase structure the sets of a tile are 4 x K x fs x fs coefficients scattered over a table of
+    // tens of MB (far beyond the XCD's 4 MB L2), and the scalar loads of the tap loop would each wait for the
+    // Infinity Cache; the prefetch turns that into an L2 hit.  The loaded words are only kept alive, never used.
+    const uint32_t row_bytes = static_cast<uint32_t>(fsp) * 4u, set_bytes = static_cast<uint32_t>(fs) * row_bytes;
+    const int ux_shift = a.tx_shift - 2;
+    constexpr int KS = K == 4 ? 2 : (K == 2 ? 1 : 0);
+    const int nunits = 1 << (ux_shift + a.ty_shift - KS);
+    auto prefetch_unit = [&](int u2) -> uint32_t {
+        uint32_t keep = 0;
+        if (u2 < nunits) {
+            const int ux2 = u2 & ((1 << ux_shift) - 1), uy2 = u2 >> ux_shift;
+            const int s = lane & (4 * K - 1);  // pixel of the unit: column s / K, row s % K
+            const int set = sets[(K * uy2 + (s % K)) * kFrameLaneMaxTile + 4 * ux2 + s / K];
+            const char* sp = reinterpret_cast<const char*>(p.coeffs) + static_cast<size_t>(static_cast<uint32_t>(set) * set_bytes);
+            constexpr int kGroups = 64 / (4 * K);  // lanes per pixel = cache lines requested per load instruction and set
+            for (uint32_t off = static_cast<uint32_t>(lane / (4 * K)) * 64u; off < set_bytes + 60u; off += 64u * kGroups)
+                keep |= *reinterpret_cast<const uint32_t*>(sp + (off < set_bytes - 4u ? off : set_bytes - 4u));
+        }
+        return keep;
+    };
+    uint32_t pf_keep = prefetch_unit(wave);  // the wave's first unit: in flight during the staging below
+
+    fl_stage<T>(a, t, tile, tw, 1, lane, wave, nwaves);  // row-major positions: a row segment is fs consecutive positions
+    __syncthreads();
+    asm volatile("" ::"v"(pf_keep));
     if (lane >= nfg) return;  // lanes without a frame (last group of the batch); no barrier below
 
     // ---- compute: units of 4 x K output pixels; lane = frame ----
     char* dframe = static_cast<char*>(a.io.dst) + static_cast<size_t>(f0 + lane) * a.io.dst_frame_stride;
     const char* lds_lane = tile + lane * SB;
-    const size_t set_floats = static_cast<size_t>(fs) * fsp;
-    const int ux_shift = a.tx_shift - 2;
-    constexpr int KS = K == 4 ? 2 : (K == 2 ? 1 : 0);
-    const int nunits = 1 << (ux_shift + a.ty_shift - KS);
+    const JINC_CONSTANT char* cbase = (const JINC_CONSTANT char*)(p.coeffs);
     for (int u = wave; u < nunits; u += nwaves) {
+        asm volatile("" ::"v"(pf_keep));           // (keeps the previous prefetch's loads alive; they completed long ago)
+        pf_keep = prefetch_unit(u + nwaves);
         const int ux = u & ((1 << ux_shift) - 1), uy = u >> ux_shift;
         const int x0 = bx0 + 4 * ux, y0 = by0 + K * uy;
         if (x0 > bx1 || y0 > by1) continue;
@@ -204,84 +484,68 @@ __global__ __launch_bounds__(512) void ewa_framelane_kernel(const FrameLaneArgs 
 
         float res[K][4];
 #pragma unroll
-        for (int xx = 0; xx < 4; ++xx) {
+        for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int k = 0; k < K; ++k) res[k][xx] = 0.f;
-            if (xx < nvx) {
-                const int sx = __builtin_amdgcn_readfirstlane(cs[4 * ux + xx]);
-                const JINC_CONSTANT float* cb[K];
+            for (int xx = 0; xx < 4; ++xx) res[k][xx] = 0.f;
+#pragma nounroll
+        for (int xx = 0; xx < nvx; ++xx) {
+            const int sx = __builtin_amdgcn_readfirstlane(cs[4 * ux + xx]);
+            uint32_t cb[K];  // byte offset of each chain's coefficient set (host: table < 4 GiB)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int set = __builtin_amdgcn_readfirstlane(sets[(K * uy + k) * kFrameLaneMaxTile + 4 * ux + xx]);
+                cb[k] = static_cast<uint32_t>(set) * set_bytes;
+            }
+            float acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = 0.f;
+            const char* lcol = lds_lane + (sx - tx0) * PS;
+            // Source rows rr0 .. rr1-1 in segments over which the set of chains holding the row is constant: chain k
+            // holds rows sy[k] .. sy[k]+fs-1 and sy is ascending, so that set is a range klo..khi.
+            int rr = rr0;
+            while (rr < rr1) {
+                int klo = 0, khi = 0, next = rr1;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const int set = __builtin_amdgcn_readfirstlane(sets[(K * uy + k) * kFrameLaneMaxTile + 4 * ux + xx]);
-                    cb[k] = (const JINC_CONSTANT float*)(p.coeffs + static_cast<size_t>(set) * set_floats);
-                }
-                float acc[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc[k] = 0.f;
-                const char* lrow = lds_lane + ((rr0 - ty0) * tw + (sx - tx0)) * PS;
-                for (int rr = rr0; rr < rr1; ++rr) {
-                    bool on[K];
-                    const JINC_CONSTANT float* cp[K];
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const int ly = rr - sy[k];
-                        on[k] = static_cast<unsigned>(ly) < static_cast<unsigned>(fs) && k < kvalid;
-                        cp[k] = cb[k] + min(max(ly, 0), fs - 1) * fsp;
+                    if (k < kvalid) {
+                        const int e = sy[k] + fs;
+                        if (e <= rr) klo = k + 1;
+                        if (sy[k] <= rr) khi = k;
+                        if (e > rr) next = min(next, e);
+                        if (sy[k] > rr) next = min(next, sy[k]);
                     }
-                    if constexpr (FS != 0) {
-#pragma unroll
-                        for (int c0 = 0; c0 < FS; c0 += 8) {
-                            constexpr int kFull = 8;
-                            if (FS - c0 >= kFull) {
-                                fl_chunk<T, K, 8>(acc, lrow + c0 * PS, cp, on);
-                            } else {
-                                fl_chunk<T, K, (FS % 8 ? FS % 8 : 8)>(acc, lrow + c0 * PS, cp, on);
-                            }
-#pragma unroll
-                            for (int k = 0; k < K; ++k) cp[k] += 8;
-                        }
-                    } else {
-                        for (int c0 = 0; c0 < fs; c0 += 8) {
-                            const int n = fs - c0;  // wave-uniform
-                            if (n >= 8) {
-                                fl_chunk<T, K, 8>(acc, lrow + c0 * PS, cp, on);
-                            } else {
-                                switch (n) {
-                                    case 1: fl_chunk<T, K, 1>(acc, lrow + c0 * PS, cp, on); break;
-                                    case 2: fl_chunk<T, K, 2>(acc, lrow + c0 * PS, cp, on); break;
-                                    case 3: fl_chunk<T, K, 3>(acc, lrow + c0 * PS, cp, on); break;
-                                    case 4: fl_chunk<T, K, 4>(acc, lrow + c0 * PS, cp, on); break;
-                                    case 5: fl_chunk<T, K, 5>(acc, lrow + c0 * PS, cp, on); break;
-                                    case 6: fl_chunk<T, K, 6>(acc, lrow + c0 * PS, cp, on); break;
-                                    default: fl_chunk<T, K, 7>(acc, lrow + c0 * PS, cp, on); break;
-                                }
-                            }
-#pragma unroll
-                            for (int k = 0; k < K; ++k) cp[k] += 8;
-                        }
-                    }
-                    lrow += tw * PS;
                 }
+                if (klo <= khi)  // (no chain holds rr only if the windows of consecutive output rows do not overlap)
+                    fl_rows_dispatch<T, FS, K>(klo, khi, acc, lcol + (rr - ty0) * tw * PS, tw * PS, rr, next - rr, sy, cb, cbase,
+                                               row_bytes, fs);
+                rr = next;
+            }
+            switch (xx) {  // wave-uniform; keeps the register indices of res[][] static without unrolling the column loop
+                case 0:
 #pragma unroll
-                for (int k = 0; k < K; ++k) res[k][xx] = acc[k];
+                    for (int k = 0; k < K; ++k) res[k][0] = acc[k];
+                    break;
+                case 1:
+#pragma unroll
+                    for (int k = 0; k < K; ++k) res[k][1] = acc[k];
+                    break;
+                case 2:
+#pragma unroll
+                    for (int k = 0; k < K; ++k) res[k][2] = acc[k];
+                    break;
+                default:
+#pragma unroll
+                    for (int k = 0; k < K; ++k) res[k][3] = acc[k];
+                    break;
             }
         }
 
         // ---- store: one 4-sample store per row where the address allows it ----
         const bool vec = nvx == 4 && a.vec_store_ok && ((x0 & 3) == 0);  // wave-uniform
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (k < kvalid) {
-                char* d = dframe + static_cast<size_t>(y0 + k) * a.io.dst_pitch + static_cast<size_t>(x0) * SB;
-                if (vec) {
-                    *reinterpret_cast<typename FlPack<T>::type*>(d) = fl_pack<T>(res[k], a.io.peak);
-                } else {
-#pragma unroll
-                    for (int xx = 0; xx < 4; ++xx)
-                        if (xx < nvx) store_sample<T>(reinterpret_cast<T*>(d) + xx, res[k][xx], a.io.peak);
-                }
-            }
-        }
+        for (int k = 0; k < K; ++k)
+            if (k < kvalid)
+                fl_store4<T>(dframe + static_cast<size_t>(y0 + k) * a.io.dst_pitch + static_cast<size_t>(x0) * SB, res[k], nvx, vec, a.io.peak);
     }
 }
 
@@ -294,12 +558,28 @@ int launch_fl_t(const FrameLaneArgs& a, hipStream_t stream) {
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int FS>
+int launch_fl_win(const FrameLaneArgs& a, hipStream_t stream) {
+    const int ntiles = a.block_begin[4];
+    dim3 grid(static_cast<unsigned>((ntiles + 7) / 8) * 8u, static_cast<unsigned>((a.io.nframes + 63) / 64), 1);
+    dim3 block(static_cast<unsigned>(a.threads), 1, 1);
+    hipLaunchKernelGGL((ewa_framelane_win_kernel<T, FS>), grid, block, static_cast<size_t>(a.lds_bytes), stream, a);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T>
 int launch_fl_fs(const FrameLaneArgs& a, hipStream_t stream) {
+    if (a.variant != 1) {  // sliding-window form for the small filter sizes (variant 1: A/B, the row-segment form)
+        switch (a.plan.fs) {
+            case 5: return launch_fl_win<T, 5>(a, stream);
+            case 7: return launch_fl_win<T, 7>(a, stream);
+            case 8: return launch_fl_win<T, 8>(a, stream);
+            case 9: return launch_fl_win<T, 9>(a, stream);
+            default: break;
+        }
+    }
     switch (a.plan.fs) {
         case 7: return launch_fl_t<T, 7, 4>(a, stream);
-        case 8: return launch_fl_t<T, 8, 4>(a, stream);
-        case 9: return launch_fl_t<T, 9, 4>(a, stream);
         case 17: return launch_fl_t<T, 17, 4>(a, stream);
         default: return launch_fl_t<T, 0, 4>(a, stream);
     }

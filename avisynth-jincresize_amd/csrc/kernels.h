@@ -173,6 +173,7 @@ struct FrameLaneArgs {
     int threads = 512;
     int lds_bytes = 0;
     int vec_store_ok = 0;     // destination base, pitch and frame stride are multiples of 4 samples
+    int variant = 0;          // 0: automatic (sliding-window form for filter sizes 5, 7, 8, 9), 1: row-segment form always
 };
 // Chooses the tile size for the rectangles `rects` of plane plan `p` (host arrays) so that every tile's source
 // footprint fits the LDS budget and is at most 64 columns wide; false if no tile size fits (huge filter footprints).

@@ -1,11 +1,19 @@
-import csv,glob,sys,collections
-for d in sys.argv[1:]:
-    for f in glob.glob(d+"/**/*_counter_collection.csv", recursive=True):
-        agg=collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k,v in agg.items():
-            if "ewa_" not in k: continue
-            print(k)
-            for c,vals in sorted(v.items()):
-                print("   %-28s n=%d mean=%.4g" % (c,len(vals),sum(vals)/len(vals)))
+#!/usr/bin/env python3
+"""Averages rocprofv3 counter_collection CSVs per (kernel, counter): usage pmc_summary.py <dir>."""
+import collections, csv, glob, json, os, re, sys
+
+def short(name):
+    m = re.search(r"(ewa_\w+)", name)
+    return m.group(1) if m else None
+
+agg = collections.defaultdict(list)
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*_counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k:
+            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+out = collections.defaultdict(dict)
+for (k, c), v in agg.items():
+    out[k][c] = sum(v) / len(v)
+    out[k]["launches"] = len(v)
+print(json.dumps(out, indent=1))
