@@ -79,7 +79,8 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_filter_set_pipeline",
-           "jinc_filter_submit", "jinc_filter_wait"]
+           "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
+           "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -128,6 +129,15 @@ def lib():
         L.jinc_filter_set_profiling.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                                C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.jinc_shard_device.argtypes = [C.c_int, C.c_int]
+        L.jinc_batch_create.argtypes = [C.POINTER(VideoInfo), C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                        C.c_char_p, C.c_size_t]
+        L.jinc_batch_devices.argtypes = [C.c_void_p]
+        L.jinc_batch_device_of_frame.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_batch_process.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I4, C.c_void_p, _I4]
+        L.jinc_batch_free.restype = None
+        L.jinc_batch_free.argtypes = [C.c_void_p]
+        L.jinc_batch_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -215,6 +225,95 @@ class Clip:
         return self.source(n)
 
 
+def _build_args(fmt, width, height, target_width, target_height, frame0_chroma_location, planar, cpu_flags, alias_taps, kw):
+    """jinc_video_info + jinc_args of a JincResize() call (keyword names = the script arguments)."""
+    vi = fmt.video_info(width, height)
+    vi.is_planar = int(planar)
+    a = Args()
+    a.target_width, a.target_height = int(target_width), int(target_height)
+    a.frame0_chroma_location = int(frame0_chroma_location)
+    a.cpu_has_sse41, a.cpu_has_avx2, a.cpu_has_avx512f = (int(bool(x)) for x in cpu_flags)
+    keep = []
+    for k, v in kw.items():
+        if k not in ARG_BITS:
+            raise TypeError(f"JincResize: unknown argument {k!r}")
+        if v is None:
+            continue
+        a.defined |= ARG_BITS[k]
+        if k == "cplace":
+            b = str(v).encode()
+            keep.append(b)
+            a.cplace = b
+        else:
+            setattr(a, k, v)
+    if alias_taps is not None:
+        b = Args()
+        rc = lib().jinc_alias_args(int(alias_taps), C.byref(a), C.byref(b))
+        if rc != 0:
+            raise JincError(rc, lib().jinc_last_error().decode())
+        a = b
+    return vi, a, keep
+
+
+class Batch:
+    """Frames of one clip sharded over the node's HIP devices (jinc_batch_*: frame n -> device n mod G, a plan replica
+    and `streams` frames in flight per device, no exchange between devices)."""
+
+    def __init__(self, fmt: Format, width: int, height: int, target_width: int, target_height: int, *, ndevices: int = 0,
+                 streams: int = 2, register_host_buffers: bool = False, **kw):
+        self.fmt = fmt
+        vi, a, self._keep = _build_args(fmt, width, height, target_width, target_height, -1, True, (True, True, True), None, kw)
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = lib().jinc_batch_create(C.byref(vi), C.byref(a), int(ndevices), int(streams), int(register_host_buffers),
+                                     C.byref(self._h), err, len(err))
+        if rc != 0:
+            raise JincError(rc, err.value.decode())
+        self.dst_w, self.dst_h = int(target_width), int(target_height)
+
+    @property
+    def devices(self) -> int:
+        return int(lib().jinc_batch_devices(self._h))
+
+    def device_of_frame(self, n: int) -> int:
+        return int(lib().jinc_batch_device_of_frame(self._h, int(n)))
+
+    def out_dims(self) -> List[Tuple[int, int]]:
+        return self.fmt.plane_dims(self.dst_w, self.dst_h)
+
+    def process(self, frames: Sequence[Sequence[np.ndarray]], outs: Optional[Sequence[Sequence[np.ndarray]]] = None):
+        """frames[n] = the planes of frame n (all with the same pitches); returns outs[n] = its output planes."""
+        n, np_ = len(frames), self.fmt.planes
+        if outs is None:
+            outs = [[alloc_plane(w, h, self.fmt.dtype) for (w, h) in self.out_dims()] for _ in range(n)]
+        sp, dp = (C.c_void_p * (4 * n))(), (C.c_void_p * (4 * n))()
+        spitch, dpitch = _I4(), _I4()
+        for k in range(n):
+            for i in range(np_):
+                sp[4 * k + i], dp[4 * k + i] = frames[k][i].ctypes.data, outs[k][i].ctypes.data
+                if frames[k][i].strides[0] != frames[0][i].strides[0] or outs[k][i].strides[0] != outs[0][i].strides[0]:
+                    raise ValueError("all frames of a batch must share their pitches")
+        for i in range(np_):
+            if n:
+                spitch[i], dpitch[i] = frames[0][i].strides[0], outs[0][i].strides[0]
+        rc = lib().jinc_batch_process(self._h, n, sp, spitch, dp, dpitch)
+        if rc != 0:
+            raise JincError(rc, lib().jinc_batch_last_error().decode())
+        return outs
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().jinc_batch_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def shard_device(frame: int, ndevices: int) -> int:
+    """Device of frame `frame` in a shard over `ndevices` devices (jinc_shard_device; needs no GPU)."""
+    return int(lib().jinc_shard_device(int(frame), int(ndevices)))
+
+
 class Filter:
     """One filter instance (= one `JincResize` object of the reference)."""
 
@@ -222,31 +321,8 @@ class Filter:
                  device: int = 0, frame0_chroma_location: int = -1, planar: bool = True,
                  cpu_flags: Tuple[bool, bool, bool] = (True, True, True), alias_taps: Optional[int] = None, **kw):
         self.fmt = fmt
-        vi = fmt.video_info(width, height)
-        vi.is_planar = int(planar)
-        a = Args()
-        a.target_width, a.target_height = int(target_width), int(target_height)
-        a.frame0_chroma_location = int(frame0_chroma_location)
-        a.cpu_has_sse41, a.cpu_has_avx2, a.cpu_has_avx512f = (int(bool(x)) for x in cpu_flags)
-        self._keep = []
-        for k, v in kw.items():
-            if k not in ARG_BITS:
-                raise TypeError(f"JincResize: unknown argument {k!r}")
-            if v is None:
-                continue
-            a.defined |= ARG_BITS[k]
-            if k == "cplace":
-                b = str(v).encode()
-                self._keep.append(b)
-                a.cplace = b
-            else:
-                setattr(a, k, v)
-        if alias_taps is not None:
-            b = Args()
-            rc = lib().jinc_alias_args(int(alias_taps), C.byref(a), C.byref(b))
-            if rc != 0:
-                raise JincError(rc, lib().jinc_last_error().decode())
-            a = b
+        vi, a, self._keep = _build_args(fmt, width, height, target_width, target_height, frame0_chroma_location, planar,
+                                        cpu_flags, alias_taps, kw)
         self._h = C.c_void_p()
         err = C.create_string_buffer(512)
         rc = lib().jinc_filter_create(C.byref(vi), C.byref(a), int(device), C.byref(self._h), err, len(err))

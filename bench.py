@@ -36,7 +36,12 @@ VALU_UNFUSED_PEAK = 78.6e12  # 256 CU x 128 lanes/clk x 2.4 GHz, one IEEE op per
 
 CONFIGS = {
     # name: (format, src_w, src_h, dst_w, dst_h, script args, default frames per step)
-    "C2": ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 64),
+    # C2 default: 1024 frames per step = twice the 512-frame clip of BASELINE.json configs[4], 10.6 GB resident in HBM;
+    # one step is then ~14 ms of kernel time, so that --steps 20 times ~0.28 s instead of 17 ms
+    "C2": ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 1024),
+    # BASELINE.json configs[4]: ONE clip of 512 frames sharded over the ranks (strong scaling: the per-rank batch shrinks
+    # with N); the default C2 run is the weak-scaling form of the same workload
+    "C5": ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 512),
     "C3": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=8, cplace="mpeg2"), 16),
     "C4": ("RGBPS", 3840, 2160, 7680, 4320, dict(tap=4, blur=0.98), 8),
     # not a BASELINE.json config: a non-periodic ratio (1.5x, float drift => gather kernel for every pixel)
@@ -96,9 +101,21 @@ def algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh):
     return b
 
 
-def cpu_baseline(cfg_name, budget_s=12.0):
-    """Times the CPU oracle (port of resize_plane_c) on this host: all cores (row-parallel, the
-    reference's thr==0 design) and one core, on a bounded number of frames of the same workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo", encoding="utf-8", errors="replace"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
+    """Times the CPU oracle (port of resize_plane_c, opt=0) on this host on a bounded sample of the same workload:
+    row-parallel over OpenMP threads (the reference's thr==0 design) and on one core.  The thread count is chosen from
+    >= scan_s seconds per candidate (a shorter probe picked counts that did not hold up), and `value` is a
+    second, longer run at that count, so scan and value can be compared."""
     O = entry.load_oracle()
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[cfg_name]
     fmt = O.FORMATS[fmt_name]
@@ -109,30 +126,31 @@ def cpu_baseline(cfg_name, budget_s=12.0):
     except AttributeError:
         avail = os.cpu_count() or 1
 
-    def run(threads, budget, max_frames=64):
+    def run(threads, budget):
         n, t0 = 0, time.perf_counter()
         while True:
             flt.get_frame(src, threads=threads)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget or n >= max_frames:
+            if el >= budget:
                 return dw * dh * n / el / 1e6, n, el
 
-    # the row fan-out does not scale to every core count (memory-bound table walk, container CPU
-    # quotas): probe a few thread counts briefly and keep the fastest for the timed sample
-    run(1, 0.0, 1)  # touch tables once
-    cands = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, avail) if t <= avail})
-    probe = {t: run(t, 0.4, 4)[0] for t in cands}
-    best = max(probe, key=probe.get)
-    run(best, 0.5, 1 << 30)  # settle the thread pool at this size
-    v, n, el = run(best, budget_s * 0.6, 1 << 30)
-    v1, n1, el1 = run(1, budget_s * 0.3, 1 << 30)
+    run(1, 0.0)  # touch tables once
+    cands = sorted({t for t in (8, 16, 32, 64, 128, avail) if t <= avail} or {avail})
+    scan = {}
+    for t in cands:
+        run(t, 0.2)  # settle the thread pool at this size, untimed
+        scan[t] = run(t, scan_s)[0]
+    best = max(scan, key=scan.get)
+    run(best, 0.2)
+    v, n, el = run(best, sample_s)
+    v1, n1, el1 = run(1, 3.0)
     return {"value": round(v, 2), "unit": "Mpix/s", "cores": best, "kind": "port",
-            "sample": f"{n} frames of {cfg_name} in {el:.1f}s; oracle (opt=0 port) rows over {best} OpenMP "
-                      f"threads (fastest of {cands} on a host with {avail} usable cores)",
-            "single_core_value": round(v1, 2),
-            "single_core_sample": f"{n1} frames in {el1:.1f}s",
-            "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in probe.items()}}
+            "sample": f"{n} frames of {cfg_name} in {el:.1f}s; oracle (opt=0 port) rows over {best} OpenMP threads, the fastest "
+                      f"of {cands} at {scan_s:.0f}s each, on a host with {avail} usable cores ({cpu_model()})",
+            "cpu_model": cpu_model(), "host_cores": avail,
+            "single_core_value": round(v1, 2), "single_core_sample": f"{n1} frames in {el1:.1f}s",
+            "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in scan.items()}}
 
 
 def make_workload(pkg, torch, config, frames, device, seed):
@@ -154,13 +172,15 @@ def make_workload(pkg, torch, config, frames, device, seed):
     src_t, dst_t = [], []
     for (w, h) in sdims:
         shape = (frames, h, pitch_elems(w))
-        if sb == 4:
-            t = torch.rand(shape, device="cuda", generator=gen, dtype=torch.float32)
-        else:
-            t = torch.randint(0, 1 << fmt.bits, shape, device="cuda", generator=gen, dtype=torch.int32).to(
-                torch.uint8 if sb == 1 else torch.int16)
-            if sb == 2:
-                t = t.view(torch.uint16)
+        t = torch.empty(shape, device="cuda", dtype=torch.float32 if sb == 4 else (torch.uint8 if sb == 1 else torch.int16))
+        for f0 in range(0, frames, 64):  # in chunks: randint produces int32 first
+            part = (min(64, frames - f0), h, pitch_elems(w))
+            if sb == 4:
+                t[f0:f0 + part[0]] = torch.rand(part, device="cuda", generator=gen, dtype=torch.float32)
+            else:
+                t[f0:f0 + part[0]] = torch.randint(0, 1 << fmt.bits, part, device="cuda", generator=gen, dtype=torch.int32).to(t.dtype)
+        if sb == 2:
+            t = t.view(torch.uint16)
         src_t.append(t)
     for (w, h) in ddims:
         dst_t.append(torch.zeros((frames, h, pitch_elems(w)), device="cuda", dtype=tdtype))
@@ -214,6 +234,11 @@ def main():
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, default_frames = CONFIGS[args.config]
     B = args.frames or default_frames
+    strong = args.config == "C5"
+    if strong:  # the clip's frames are the sharding unit: rank r owns a contiguous run of them
+        B = shard_frames(B, rank, world)[1]
+        if B < 1:
+            raise SystemExit("C5: more ranks than frames")
     flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, local_rank, 12345 + rank * B)
     flt.set_kernel_mode(args.kernel_mode)
     if args.border_overlap >= 0:
@@ -267,29 +292,34 @@ def main():
         kernel_ms_per_step = dom_ms / args.steps
         achieved_gbs = bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9
         valu_ops = 2.0 * fs * fs * samples_frame * B / (kernel_ms_per_step * 1e-3)
-        traffic = None
+        traffic = traffic_raw = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath)).get(args.config, {})
-                if "hbm_bytes_per_launch" in rec:  # PMC figure, scaled to this run's frames per launch
-                    traffic = int(rec["hbm_bytes_per_launch"] * B / rec.get("frames_per_launch", B))
+                if "hbm_bytes_per_launch" in rec:  # PMC figure (2 x FETCH_SIZE + WRITE_SIZE), scaled to this run's frames per launch
+                    scale = B / (rec.get("frames_per_launch") or B)
+                    traffic = int(rec["hbm_bytes_per_launch"] * scale)
+                    traffic_raw = int(rec.get("hbm_bytes_per_launch_raw", 0) * scale) or None
             except Exception:  # noqa: BLE001
-                traffic = None
+                traffic = traffic_raw = None
         line = {
             "metric": baseline_metric() if args.config == "C2" else f"Mpix/s ({args.config})",
             "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32",  # arithmetic type of the path (un-fused fp32 accumulate over u8/u16/f32 samples)
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {sw}x{sh}->{dw}x{dh} {fmt_name} tap={kw['tap']}"
                                    + (f" blur={kw['blur']}" if 'blur' in kw else ""),
                        "sample_type": {1: "u8", 2: "u16", 4: "f32"}[sb], "frames_per_step_per_gpu": B,
+                       "timed_region_s": round(elapsed_max, 4), "resident_bytes_per_gpu": (bytes_frame * B),
                        "untimed_spinup_ms_before_warmup": spin_ms, "parallelism": f"frames sharded over {world} GPU(s), no collective",
                        "kernel": dom_name, "filter_size": fs, "plan_sets": info.num_sets,
                        "plan_bytes": int(info.plan_bytes)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE from profiles/traffic.json (gfx950 FETCH correction); raw sum in traffic_raw",
+                         "traffic_raw": traffic_raw,
                          "kernel": dom_name, "kernel_ms_per_launch": round(dom_ms / max(1, dom_n), 4),
                          "launches": dom_n, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": bytes_frame * B // max(1, launches_per_step),

@@ -181,6 +181,26 @@ JINC_API int jinc_filter_process_device(jinc_filter *f, const void *const src[4]
  * Work given to jinc_filter_process_device is synchronised by the caller through its stream. */
 JINC_API int jinc_filter_sync(jinc_filter *f);
 
+/* ---- Frames of a clip sharded over the HIP devices of the node (BASELINE.json configs[4]) --------
+ * Frames are independent units (JincResize_GetFrame touches frame n only, ref :603-630) and the plan is read-only, so
+ * the shard needs no exchange between devices: frame n is computed on device jinc_shard_device(n, G) = n mod G, every
+ * device holds a replica of the plan (one filter instance) and keeps `streams_per_device` frames in flight (per-frame
+ * device buffers and hipStreams, H2D -> kernels -> D2H), driven by one host thread per device.  No collective.
+ * ndevices <= 0: all visible devices.  register_host_buffers: as for jinc_filter_set_pipeline.
+ * jinc_batch_process: src_planes / dst_planes hold 4 pointers per frame ([frame][plane], planes in the reference's
+ * processing order, unused planes NULL), HOST buffers with the given pitches (bytes); returns when every frame is
+ * complete.  Errors: first failure's status, message from jinc_batch_last_error(). */
+typedef struct jinc_batch jinc_batch;
+JINC_API int jinc_shard_device(int frame, int ndevices);
+JINC_API int jinc_batch_create(const jinc_video_info *vi, const jinc_args *args, int ndevices, int streams_per_device,
+                               int register_host_buffers, jinc_batch **out, char *err, size_t err_len);
+JINC_API int jinc_batch_devices(const jinc_batch *b);
+JINC_API int jinc_batch_device_of_frame(const jinc_batch *b, int frame);
+JINC_API int jinc_batch_process(jinc_batch *b, int nframes, const void *const *src_planes, const int src_pitch[4],
+                                void *const *dst_planes, const int dst_pitch[4]);
+JINC_API void jinc_batch_free(jinc_batch *b);
+JINC_API const char *jinc_batch_last_error(void);
+
 /* ---- Jinc36Resize / Jinc64Resize / Jinc144Resize / Jinc256Resize (ref :986-1040, :1061-1108) ----
  * Builds the argument set the alias forwards through avs_invoke("JincResize", ...): the three
  * positional arguments plus, when defined, src_left/top/width/height, quant_x/y, cplace, threads

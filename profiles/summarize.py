@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 CSV output (gpurun_out/...) into the small summaries kept under profiles/.
 
-usage: summarize.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>]
+usage: summarize.py <round-tag> <stats_dir> [<fetch_dir> <write_dir>]      (env JINC_FRAMES_PER_LAUNCH: recorded in the summary;
+                                                                          env JINC_PROFILE_DIR: output directory under profiles/)
   stats_dir : output of  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python bench.py ...
   fetch_dir : output of  rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python bench.py ...
   write_dir : output of  rocprofv3 --pmc WRITE_SIZE ...   (separate pass: TCC has 4 slots, FETCH_SIZE takes 3)
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB (MI355X_MICROARCH.md, HBM section: bytes =
-counter * 1024).  The guide's x2 correction of FETCH_SIZE applies to 16-B-per-lane streaming reads; this
-kernel stages its source tile with 1-byte-per-lane loads, which is an uncalibrated width, so the raw value
-is reported and the corrected one is given as an upper bound.
+counter * 1024).  Both the raw sum and the sum with the guide's x2 correction of FETCH_SIZE are written;
+profiles/make_traffic.py publishes the corrected one (the raw FETCH figure is below the compulsory source bytes).
 """
 import collections
 import csv
@@ -26,8 +26,11 @@ def short(name):
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
-    out_dir = os.path.dirname(os.path.abspath(__file__))
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get("JINC_PROFILE_DIR", ""))
+    os.makedirs(out_dir, exist_ok=True)
     out = {"tag": tag, "kernels": {}}
+    if os.environ.get("JINC_FRAMES_PER_LAUNCH"):
+        out["frames_per_launch"] = int(os.environ["JINC_FRAMES_PER_LAUNCH"])
     for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Name"])
@@ -54,7 +57,10 @@ def main():
     for k, e in out["kernels"].items():
         if "FETCH_SIZE_bytes_mean" in e and "WRITE_SIZE_bytes_mean" in e:
             e["hbm_bytes_per_launch_raw"] = e["FETCH_SIZE_bytes_mean"] + e["WRITE_SIZE_bytes_mean"]
-            e["hbm_bytes_per_launch_fetch_x2_upper_bound"] = 2 * e["FETCH_SIZE_bytes_mean"] + e["WRITE_SIZE_bytes_mean"]
+            e["hbm_bytes_per_launch_fetch_x2"] = 2 * e["FETCH_SIZE_bytes_mean"] + e["WRITE_SIZE_bytes_mean"]
+    for f in glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True):
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as o:
+            o.write(open(f).read())
     path = os.path.join(out_dir, f"{tag}.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))

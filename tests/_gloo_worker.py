@@ -28,6 +28,14 @@ def main():
     dist.all_reduce(owned)
     assert bool((owned == 1).all()), "frames must be partitioned exactly once"
 
+    # the library's own shard (jinc_batch_*: frame n -> device n mod G, here rank = device): also an exact partition,
+    # balanced to within one frame
+    pkg = entry.load_package()
+    mine = torch.tensor([1 if pkg.shard_device(n, world) == rank else 0 for n in range(total)], dtype=torch.int32)
+    assert abs(int(mine.sum()) - total / world) < 1.0
+    dist.all_reduce(mine)
+    assert bool((mine == 1).all()), "round-robin shard must own every frame exactly once"
+
     # MAX over ranks of the time, SUM of the units -- the only cross-rank traffic of the bench
     elapsed = 1.0 + 0.25 * rank
     t, units = bench.aggregate(elapsed, float(count), dist)
@@ -35,7 +43,6 @@ def main():
     assert units == float(total)
 
     # each rank builds its own replica of the plan; replicas must be identical (no exchange needed)
-    pkg = entry.load_package()
     f = pkg.Filter(pkg.FORMATS["YUV420P8"], 320, 180, 640, 360, device=-1, tap=3)
     h = hashlib.sha256()
     for tbl in range(f.num_tables):

@@ -22,6 +22,16 @@ def test_shard_frames_partitions(total, world):
     assert seen == list(range(total))
 
 
+@pytest.mark.parametrize("total,ndev", [(512, 1), (512, 8), (515, 4), (3, 8)])
+def test_library_shard_is_round_robin(pkg, total, ndev):
+    """jinc_shard_device: the frame -> device map of jinc_batch_process (no GPU needed to evaluate it)."""
+    owners = [pkg.shard_device(n, ndev) for n in range(total)]
+    assert owners == [n % ndev for n in range(total)]
+    counts = [owners.count(d) for d in range(ndev)]
+    assert max(counts) - min(counts) <= 1
+    assert pkg.shard_device(-1, ndev) == -1 and pkg.shard_device(0, 0) == -1
+
+
 def test_algorithmic_bytes_match_survey(pkg):
     """C2 10 368 000 B, C3 31 104 000 B, C4 497 664 000 B per frame."""
     want = {"C2": 10_368_000, "C3": 31_104_000, "C4": 497_664_000}
