@@ -106,6 +106,8 @@ struct jinc_filter {
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
     int border_strips = 1;  // border rows/columns of exactly periodic plans on kernel_direct.hip (0: gather kernel)
+    bool direct_premise = false;  // buffer_range_check_covers_soffset(device) == 1
+    int simd_order = 0;  // 0: opt=0 results (default); 1 / 2 / 3: summation order of the reference's SSE4.1 / AVX2 / AVX-512 path
     int overlap_border = -1;  // -1: automatic (side stream when the border frame is heavy: fs > 9), 0: off, 1: on
 
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
@@ -607,6 +609,37 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     if (!t.strips_ok) t.border_rects.private_sets = t.border_rects.unit_stride = true;  // coefficients per lane
 }
 
+// kernel_direct.hip passes the row offset of its segment fetches as the buffer instructions' scalar offset and relies
+// on the hardware range check covering it (measured on gfx950; LLVM's intrinsic documentation says otherwise).  Checked
+// once per device on the device itself; 1 = covered, 0 = not (the direct kernel is then not used), < 0 = HIP error.
+int buffer_range_check_covers_soffset(int device) {
+    static std::atomic<int> cache[64];  // 0: unknown, 1: not covered, 2: covered
+    if (device < 0 || device >= 64) return 0;
+    const int c = cache[device].load();
+    if (c != 0) return c - 1;
+    constexpr uint32_t N = 4096;
+    std::vector<uint32_t> h(2 * N / 4), r(128, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < h.size(); ++i) h[i] = i;
+    uint32_t *d = nullptr, *o = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, 2 * N) != hipSuccess) return -1;
+    if (hipMalloc(&o, 128 * 4) != hipSuccess) {
+        (void)hipFree(d);
+        return -1;
+    }
+    bool ok = hipMemcpy(d, h.data(), 2 * N, hipMemcpyHostToDevice) == hipSuccess &&
+              jinc::launch_soffset_probe(d, N, o, nullptr) == 0 && hipMemcpy(r.data(), o, 128 * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    (void)hipFree(o);
+    if (!ok) return -1;
+    bool covered = true;
+    for (uint32_t l = 0; l < 64; ++l) {
+        covered = covered && r[l] == (l < 32 ? (N - 128) / 4 + l : 0u);  // in range up to the descriptor's end, zero past it
+        covered = covered && r[64 + l] == 0u;                            // scalar offset alone past the end
+    }
+    cache[device].store(covered ? 2 : 1);
+    return covered ? 1 : 0;
+}
+
 // kernel_direct.hip fetches whole segments as naturally aligned dwords through a buffer resource that ends with the
 // aligned dword holding the plane's last sample, so it cannot touch memory outside the plane's own dwords.  It needs
 // 4-byte multiples for pitch and frame stride (the plane base may be anywhere) and 32-bit offsets.
@@ -681,6 +714,7 @@ void init_device(jinc_filter& f, int device) {
     }
     hip_check(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming), "hipEventCreate");
+    f.direct_premise = buffer_range_check_covers_soffset(device) == 1;
     f.tables.resize(f.plans.size());
     for (size_t i = 0; i < f.plans.size(); ++i) {
         upload_table(f.plans[i], f.tables[i], f.stream);
@@ -769,7 +803,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     };
     // Is kernel_direct.hip usable for plane i (interior and border strips)?  See direct_fetch_is_safe().
     auto direct_ok = [&](const DeviceTable& t, int i) {
-        if (!t.use_direct || f.kernel_mode == 1) return false;
+        if (!t.use_direct || f.kernel_mode == 1 || !f.direct_premise) return false;
         const uint64_t plane_bytes = static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb;
         return direct_fetch_is_safe(src_fs ? src_fs[i] : 0, nframes, plane_bytes, src_pitch[i], t.plan.fs);
     };
@@ -796,7 +830,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        any_periodic |= !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i));
+        any_periodic |= f.simd_order == 0 && !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i));
     }
     // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
     // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
@@ -843,6 +877,13 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                 sink.push_back(ev);
             }
         };
+        if (f.simd_order != 0) {  // compatibility modes (private switch): whole plane on kernel_simdorder.hip
+            const float min_val = (i != 0 && !f.vi_in.is_rgb) ? -0.5f : 0.f;  // ref resize_plane_sse41.cpp:20
+            t.last_kernel = "ewa_simd_order_kernel";
+            timed(f.ev_gather, stream, "SIMD-order kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_simd_order(t.plan, io, f.simd_order, min_val, s); });
+            continue;
+        }
         if (wants_framelane(t, i)) {
             jinc::FrameLaneArgs fa = t.fl_whole;
             fa.io = io;
@@ -1267,6 +1308,18 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
         return "ewa_periodic_kernel";
     }
     return "ewa_gather_kernel";
+}
+
+int jinc_filter_set_simd_order(jinc_filter* f, int order) {
+    if (!f || order < 0 || order > 3) return fail(JINC_ERR_INVALID_ARG, "JincResize: SIMD order must be 0..3.");
+    f->simd_order = order;
+    return JINC_OK;
+}
+
+int jinc_debug_buffer_range_check(int device) {
+    const int r = buffer_range_check_covers_soffset(device);
+    if (r < 0) return fail(JINC_ERR_HIP, "JincResize: the buffer range-check probe could not run.");
+    return r;
 }
 
 const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {

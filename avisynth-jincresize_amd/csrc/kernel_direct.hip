@@ -45,6 +45,13 @@ struct DirectShape {
 // parameter of everything below, so the samples are picked out of the aligned dwords by the conversion itself
 // (v_cvt_f32_ubyteN / SDWA word select) -- no funnel shifts.  Nothing outside the aligned dwords that hold the
 // plane's samples is ever touched: the buffer resource bounds the rest.
+// The wave-uniform row offset travels in the instruction's soffset.  LLVM documents soffset of raw.buffer.load as
+// "excluded from bounds checking"; on gfx950 the hardware does include it -- a fetch is out of range when
+// voffset + imm + soffset reaches num_records, also for soffset alone beyond num_records (measured:
+// profiles/probes/soffset_probe.hip, profiles/round2/soffset_probe.log).  Because everything here rests on that, the same
+// probe runs on the device when a filter is created (buffer_range_check_covers_soffset) and the direct kernel is not
+// used where it fails; tests/test_gpu_parity.py::test_buffer_range_check_premise pins it too.  (Moving the row offset
+// into a per-row descriptor instead costs 20 % of this issue-bound kernel's speed: D12 60 -> 48 % of the VALU peak.)
 template <int RW>
 __device__ __forceinline__ void load_raw(BufferRsrc rsrc, uint32_t voffset, uint32_t soffset, uint32_t (&raw)[RW]) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -369,6 +376,22 @@ int launch_direct_mode(const DirectArgs& args, const PlaneIO& io, void* stream) 
 }
 
 }  // namespace
+
+namespace {
+// See load_raw: lane l reads dword l of a 2N-byte buffer through a descriptor of N bytes with soffset = N - 128 and with
+// soffset = N + 256; the range check must zero lanes 32.. of the first read and all of the second.
+__global__ void soffset_probe_kernel(const uint32_t* buf, uint32_t nbytes, uint32_t* out) {
+    const BufferRsrc r = make_rsrc(const_cast<uint32_t*>(buf), nbytes);
+    const uint32_t l = threadIdx.x;
+    out[l] = __builtin_amdgcn_raw_buffer_load_b32(r, 4 * l, nbytes - 128, 0);
+    out[64 + l] = __builtin_amdgcn_raw_buffer_load_b32(r, 4 * l, nbytes + 256, 0);
+}
+}  // namespace
+
+int launch_soffset_probe(const uint32_t* buf, uint32_t nbytes, uint32_t* out, void* stream) {
+    hipLaunchKernelGGL(soffset_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), buf, nbytes, out);
+    return static_cast<int>(hipGetLastError());
+}
 
 bool direct_supported(int fs, int px, int py, int sx, int sy) {
     if (fs < 1 || sx < 1 || sx > 4 || sy < 1 || sy > 4) return false;

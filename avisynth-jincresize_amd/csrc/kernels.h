@@ -139,6 +139,9 @@ struct DirectArgs {
     int dst_h = 0;
 };
 bool direct_supported(int fs, int px, int py, int sx, int sy);
+// Probe of the hardware premise of kernel_direct.hip (the buffer range check covers the scalar offset): `buf` holds
+// 2 * nbytes bytes with dword i = i, `out` 128 dwords.  See load_raw in kernel_direct.hip.
+int launch_soffset_probe(const uint32_t* buf, uint32_t nbytes, uint32_t* out, void* stream);
 int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream);
 int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream);
 
@@ -188,6 +191,10 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 bool periodic_supported(int fs, int px, int py, int sx, int sy);
 // variant: 0 = default choice per filter size, 1 = always the row-streamed kernel (A/B measurements)
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
+
+// Compatibility modes: the summation order of the reference's SIMD paths (kernel_simdorder.hip).  order 1 = SSE4.1,
+// 2 = AVX2, 3 = AVX-512; min_val = lower clamp of float source samples of this plane.
+int launch_simd_order(const DevicePlan& plan, const PlaneIO& io, int order, float min_val, void* stream);
 
 // Test hook: applies the kernels' float -> sample conversion (clamp, round-half-even, store) to n sums.
 int launch_debug_convert(const float* in, void* out, int n, int sample_bytes, float peak, void* stream);

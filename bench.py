@@ -112,10 +112,11 @@ def cpu_model():
 
 
 def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
-    """Times the CPU oracle (port of resize_plane_c, opt=0) on this host on a bounded sample of the same workload:
-    row-parallel over OpenMP threads (the reference's thr==0 design) and on one core.  The thread count is chosen from
-    >= scan_s seconds per candidate (a shorter probe picked counts that did not hold up), and `value` is a
-    second, longer run at that count, so scan and value can be compared."""
+    """Times the CPU checker code on this host on a bounded sample of the same workload, row-parallel over OpenMP threads
+    (the reference's thr==0 design) and on one core: the own AVX2+FMA code in the reference's opt=2 order (the fast CPU
+    path; `value`) and the opt=0 port.  The thread count is chosen from >= scan_s seconds per candidate (a shorter probe
+    picked counts that did not hold up), and `value` is a second, longer run at that count, so scan and value
+    can be compared."""
     O = entry.load_oracle()
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[cfg_name]
     fmt = O.FORMATS[fmt_name]
@@ -126,10 +127,13 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     except AttributeError:
         avail = os.cpu_count() or 1
 
-    def run(threads, budget):
+    def run(threads, budget, avx2=False):
         n, t0 = 0, time.perf_counter()
         while True:
-            flt.get_frame(src, threads=threads)
+            if avx2:
+                flt.get_frame_simd(2, src, threads=threads, avx2=True)
+            else:
+                flt.get_frame(src, threads=threads)
             n += 1
             el = time.perf_counter() - t0
             if el >= budget:
@@ -137,19 +141,28 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
 
     run(1, 0.0)  # touch tables once
     cands = sorted({t for t in (8, 16, 32, 64, 128, avail) if t <= avail} or {avail})
+    # the fast CPU path: own AVX2 + FMA code in the summation order of the reference's opt=2 path (oracle/simd_avx2.c; the
+    # reference itself cannot be built on this box).  Not bit-equal to opt=0 -- the GPU result is; it is the CPU SPEED baseline.
+    have_avx2 = bool(O.lib().oracle_avx2_available())
     scan = {}
     for t in cands:
-        run(t, 0.2)  # settle the thread pool at this size, untimed
-        scan[t] = run(t, scan_s)[0]
+        run(t, 0.2, have_avx2)  # settle the thread pool at this size, untimed
+        scan[t] = run(t, scan_s, have_avx2)[0]
     best = max(scan, key=scan.get)
-    run(best, 0.2)
-    v, n, el = run(best, sample_s)
-    v1, n1, el1 = run(1, 3.0)
+    run(best, 0.2, have_avx2)
+    v, n, el = run(best, sample_s, have_avx2)
+    v1, n1, el1 = run(1, 2.0, have_avx2)
+    o_best, _, _ = run(best, 2.0)   # the opt=0 port (strict sequential order) at the same thread count ...
+    o1, on1, oel1 = run(1, 2.0)     # ... and on one core
+    path = ("own AVX2+FMA code in the reference's opt=2 summation order (not bit-equal to opt=0)" if have_avx2
+            else "oracle (opt=0 port)")
     return {"value": round(v, 2), "unit": "Mpix/s", "cores": best, "kind": "port",
-            "sample": f"{n} frames of {cfg_name} in {el:.1f}s; oracle (opt=0 port) rows over {best} OpenMP threads, the fastest "
+            "sample": f"{n} frames of {cfg_name} in {el:.1f}s; {path}, rows over {best} OpenMP threads, the fastest "
                       f"of {cands} at {scan_s:.0f}s each, on a host with {avail} usable cores ({cpu_model()})",
+            "path": "avx2_order" if have_avx2 else "opt0_port",
             "cpu_model": cpu_model(), "host_cores": avail,
             "single_core_value": round(v1, 2), "single_core_sample": f"{n1} frames in {el1:.1f}s",
+            "opt0_port_value": round(o_best, 2), "opt0_port_single_core_value": round(o1, 2),
             "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in scan.items()}}
 
 

@@ -259,10 +259,23 @@ JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
  * (fork/join by events around every call); 0: all on the caller's stream, back to back. */
 JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
 
+/* Compatibility modes for users who diff against the reference's SIMD output: 1 / 2 / 3 reproduce
+ * the summation order of its opt = 1 (SSE4.1: 4 lane-partial sums, multiply + add), opt = 2 (AVX2: 8 partial sums, FMA)
+ * and opt = 3 (AVX-512: 16 partial sums, FMA) paths bit for bit -- horizontal-sum tree, cvtps_epi32 + packus saturation
+ * (to 65535 / 255, not to the clip's peak) and the lower clamp of float sources included (ref resize_plane_sse41.cpp:41-90,
+ * resize_plane_avx2.cpp:45-98, resize_plane_avx512.cpp:45-103).  0 (default) = the opt = 0 result, the parity target.
+ * A private switch: the public `opt` argument does not select it.  Slow path (no LDS staging). */
+JINC_API int jinc_filter_set_simd_order(jinc_filter *f, int order);
+
 /* Test hook: runs the kernels' own sum -> sample conversion (clamp to [0, peak], round-half-even, store;
  * ref :581-584) on `n` caller-supplied fp32 sums on device `device` and returns the samples
  * (sample_bytes 1, 2 or 4).  Lets tests probe ties, bounds, NaN and infinities directly. */
 JINC_API int jinc_debug_convert(const float *sums, void *out, int n, int sample_bytes, float peak, int device);
+
+/* Test hook: 1 when the device's buffer range check covers the scalar offset of buffer loads (the premise of the
+ * direct kernel's bounded segment fetches; probed once per device, the direct kernel is not used where it fails), 0 when
+ * it does not, negative status when the probe could not run. */
+JINC_API int jinc_debug_buffer_range_check(int device);
 
 /* ---- Kernel timing (benchmarks) ---------------------------------------------------------------
  * When enabled, every kernel launch made by jinc_filter_get_frame / jinc_filter_process_device is

@@ -69,6 +69,15 @@ void oracle_table_free(oracle_table *t);
 void oracle_resize_plane(const void *src, int src_pitch, void *dst, int dst_pitch,
                          const oracle_table *t, int sample_bytes, float peak, int threads);
 
+/* Summation order of the reference's SIMD paths (simd_order.c): order 1 = SSE4.1, 2 = AVX2, 3 = AVX-512.
+ * min_val: lower clamp of FLOAT source samples (-0.5 for planes 1.. of YUV clips, else 0; resize_plane_sse41.cpp:20). */
+void oracle_resize_plane_simd(int order, const void *src, int src_pitch, void *dst, int dst_pitch, const oracle_table *t,
+                              int sample_bytes, float min_val, int threads);
+/* Own AVX2 + FMA implementation in the order of opt = 2 (simd_avx2.c); bit-equal to oracle_resize_plane_simd(2, ...). */
+int oracle_avx2_available(void);
+void oracle_resize_plane_avx2(const void *src, int src_pitch, size_t src_bytes, void *dst, int dst_pitch, const oracle_table *t,
+                              int sample_bytes, float min_val, int threads);  /* src_bytes: size of the plane's allocation */
+
 /* the synthetic frame generator behind every KAT hash.
  * 32-bit LCG s = s*1664525 + 1013904223, r = s>>8; one stream across planes.
  * Fills `height` rows of `width` samples at `pitch` bytes; padding bytes are left untouched.

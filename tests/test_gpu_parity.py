@@ -436,6 +436,14 @@ def test_border_strips_and_gather_border_agree_with_oracle(gpu_pkg, O, case, str
     f.close()
 
 
+def test_buffer_range_check_premise(gpu_pkg):
+    """kernel_direct.hip bounds its whole-segment fetches with the buffer descriptor while the row offset travels in the
+    instruction's scalar offset: that is only safe if the hardware range check covers the scalar offset (it does on
+    gfx950 -- profiles/probes/soffset_probe.hip -- although LLVM documents the opposite).  The library probes this per
+    device and drops the direct kernel otherwise; this test pins the premise itself."""
+    assert gpu_pkg.lib().jinc_debug_buffer_range_check(0) == 1
+
+
 @pytest.mark.parametrize("fmt,slacks", [("Y8", (0, 1, 2, 3, 4, 2048)), ("Y16", (0, 2, 4, 6, 2050))], ids=["u8", "u16"])
 def test_plane_ending_on_a_page_boundary(gpu_pkg, O, fmt, slacks):
     """ewa_direct_kernel fetches naturally aligned dwords only, bounded by the dword that holds the plane's last
