@@ -1,15 +1,26 @@
-/* tests/mock_avs/avisynth_c.h -- TEST INFRASTRUCTURE ONLY.
+/* plugin/compat/avisynth_c.h -- COMPATIBILITY DECLARATION of the part of the AviSynth+ C API that
+ * plugin/jincresize_avs.cpp uses (the symbol list of SURVEY.md 8(b)).
  *
- * A self-written, minimal declaration of the part of the AviSynth+ C API that plugin/jincresize_avs.cpp uses
- * (the symbol list of SURVEY.md 8(b)), so that the plugin shell can be compiled and driven by the mock host in
- * mock_host.cpp.  It is NOT the upstream header (which this image does not have), it is written from the API's
- * documented names and call shapes, struct layouts are this file's own, and it is never used to compile any file of
- * /root/reference.  What a test against it proves: the plugin's argument parsing, alias forwarding, error
- * propagation, frame/property handling and look-ahead logic.  What it cannot prove: binary compatibility with a
- * real AviSynth+ host -- that needs a build against the SDK header.
+ * The AviSynth+ SDK header is not part of this repository or its build image.  This file is written from the API's
+ * public names and call shapes so that the plugin can be compiled here -- into plugin/lib/libjincresize.so by
+ * __graft_entry__.build(), and together with the mock host of tests/mock_avs/ for the plugin tests.  It is never used
+ * to compile any file of /root/reference.  When building against a real AviSynth+ installation, put the SDK's include
+ * directory FIRST on the include path so that its avisynth_c.h replaces this one; nothing in the plugin depends on this
+ * file's details.
+ *
+ * Struct layouts follow the upstream field order as far as the author knows it (AVS_VideoInfo, AVS_Value,
+ * AVS_FilterInfo: the plugin touches vi.width / vi.height / vi.num_frames, fi->child / vi / env / get_frame /
+ * set_cache_hints / free_filter / error / user_data, and AVS_Value only through the avs_* accessors).
+ * TO BE VERIFIED AGAINST UPSTREAM avisynth_c.h before trusting a binary built with this file:
+ *   - numeric values of AVS_PLANAR_*, AVS_CPUF_SSE4_1 / AVX2 / AVX512F, AVS_CACHE_GET_MTMODE, AVS_AEP_INTERFACE_BUGFIX
+ *   - field order and types of AVS_VideoInfo (esp. the audio fields before image_type), AVS_Value (type letters, the
+ *     64-bit members of newer interface versions), AVS_FilterInfo
+ *   - which avs_* accessors are inline in the SDK header and which are imported from the host library (here all that
+ *     need host state are plain external functions; the value accessors are inline)
+ *   - AVSC_CC (stdcall on 32-bit Windows) and the AVSC_EXPORT / avisynth_c_plugin_init declaration
  */
-#ifndef MOCK_AVISYNTH_C_H
-#define MOCK_AVISYNTH_C_H
+#ifndef JINCRESIZE_COMPAT_AVISYNTH_C_H
+#define JINCRESIZE_COMPAT_AVISYNTH_C_H
 
 #include <stdint.h>
 
@@ -33,24 +44,30 @@ typedef struct AVS_VideoFrame AVS_VideoFrame;
 typedef struct AVS_Map AVS_Map;
 
 typedef struct AVS_VideoInfo {
-    int width, height;
+    int width, height; /* width = 0 means no video */
     unsigned fps_numerator, fps_denominator;
     int num_frames;
-    int pixel_type;
-    /* mock-only description of the pixel type (the real API encodes these in pixel_type) */
-    int mock_bits, mock_component_size, mock_num_components, mock_planar, mock_rgb, mock_sub_w, mock_sub_h;
+    int pixel_type; /* opaque here: only the host's avs_is_* / avs_bits_per_component / ... interpret it */
+    int audio_samples_per_second; /* 0 means no audio */
+    int sample_type;
+    int64_t num_audio_samples;
+    int nchannels;
+    int image_type;
 } AVS_VideoInfo;
 
 typedef struct AVS_Value {
-    short type; /* 'v'oid, 'c'lip, 'b'ool, 'i'nt, 'f'loat, 's'tring, 'a'rray, 'e'rror */
+    short type; /* 'a'rray, 'c'lip, 'b'ool, 'i'nt, 'f'loat, 's'tring, 'v'oid, 'e'rror ('l'ong, 'd'ouble, fu'n'ction in newer hosts) */
     short array_size;
     union {
-        void* clip;
+        void* clip; /* do not use directly */
         char boolean;
         int integer;
         float floating_pt;
         const char* string;
         const struct AVS_Value* array;
+        void* function;
+        int64_t longlong;
+        double double_pt;
     } d;
 } AVS_Value;
 

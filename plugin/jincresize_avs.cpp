@@ -6,12 +6,14 @@
 // on top of the C ABI in include/jincresize_hip.h.  All resampling happens behind that ABI on the GPU; there is no CPU
 // path in this file.
 //
-// Build (needs the AviSynth+ SDK header, which this repository does not ship):
+// Build against an AviSynth+ installation (its SDK header first on the include path):
 //   g++ -std=c++17 -shared -fPIC plugin/jincresize_avs.cpp -Iinclude -I<avisynth sdk>/include
 //       -Lavisynth-jincresize_amd/lib -ljincresize_hip -o libjincresize.so
-// In this repository it is compiled only against tests/mock_avs/avisynth_c.h (a self-written subset of the API, for
-// the mock-host tests in tests/test_plugin_mock_host.py); see INTEGRATION.md section 6 for what that does and does not
-// prove.
+// In this repository, which does not ship the SDK header, it is compiled against plugin/compat/avisynth_c.h (a
+// self-written declaration of the API subset with the upstream struct layouts, see the list of points to verify at its
+// top): __graft_entry__.build() emits plugin/lib/libjincresize.so that way (plugin/Makefile), and the mock-host tests
+// (tests/test_plugin_mock_host.py) compile it together with tests/mock_avs/mock_host.cpp.  INTEGRATION.md section 6
+// says what that does and does not prove.
 #include "avisynth_c.h"
 
 #include <algorithm>
@@ -94,15 +96,21 @@ AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
     const int depth = inst->lookahead;
     const int last = fi->vi.num_frames - 1;
     Pending& want = inst->ring[n % depth];
+    auto drop = [&](Pending& p) {  // wait for a frame in flight and give its references back
+        jinc_filter_wait(inst->filter, p.ticket);
+        avs_release_video_frame(p.src);
+        avs_release_video_frame(p.dst);
+        p = Pending{};
+    };
     if (want.frame != n) {  // seek: wait for and drop whatever is in flight
-        for (Pending& p : inst->ring) {
-            if (p.frame < 0) continue;
-            jinc_filter_wait(inst->filter, p.ticket);
-            avs_release_video_frame(p.src);
-            avs_release_video_frame(p.dst);
-            p = Pending{};
-        }
+        for (Pending& p : inst->ring)
+            if (p.frame >= 0) drop(p);
         inst->next_submit = n;
+    } else {
+        // frames the client skipped (requests n, n+2, ...: SelectEven, a frame-dropping client) are still pending in
+        // their slots; drop them now, before the submit loop below reuses those slots
+        for (Pending& p : inst->ring)
+            if (p.frame >= 0 && p.frame < n) drop(p);
     }
     for (int k = std::max(inst->next_submit, n); k <= std::min(n + depth - 1, last); ++k) {
         Pending& p = inst->ring[k % depth];

@@ -16,6 +16,19 @@ struct AVS_Map {
     std::map<std::string, int64_t> ints;
 };
 
+// The mock's private encoding of the clip format in AVS_VideoInfo::pixel_type (a real host has its own AVS_CS_* bits; the
+// plugin never looks at pixel_type itself, only at what the host's avs_* accessors say).
+static inline int pt_pack(int bits, int component_size, int num_components, int planar, int rgb, int sub_w, int sub_h) {
+    return bits | component_size << 6 | num_components << 9 | (planar ? 1 : 0) << 12 | (rgb ? 1 : 0) << 13 | sub_w << 14 | sub_h << 16;
+}
+static inline int pt_bits(const AVS_VideoInfo* vi) { return vi->pixel_type & 63; }
+static inline int pt_component_size(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 6) & 7; }
+static inline int pt_num_components(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 9) & 7; }
+static inline int pt_planar(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 12) & 1; }
+static inline int pt_rgb(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 13) & 1; }
+static inline int pt_sub_w(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 14) & 3; }
+static inline int pt_sub_h(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 16) & 3; }
+
 struct AVS_VideoFrame {
     int refs = 1;
     AVS_ScriptEnvironment* counted_by = nullptr;  // frames made by avs_new_video_frame_p are counted while alive
@@ -63,13 +76,13 @@ AVS_VideoFrame* make_frame(const AVS_VideoInfo* vi, int pitch_align) {
     static const int yuv[4] = {AVS_PLANAR_Y, AVS_PLANAR_U, AVS_PLANAR_V, AVS_PLANAR_A};
     static const int rgb[4] = {AVS_PLANAR_G, AVS_PLANAR_B, AVS_PLANAR_R, AVS_PLANAR_A};
     auto* f = new AVS_VideoFrame;
-    f->nplanes = vi->mock_num_components;
+    f->nplanes = pt_num_components(vi);
     for (int i = 0; i < f->nplanes; ++i) {
-        const bool chroma = !vi->mock_rgb && (i == 1 || i == 2);
-        const int w = chroma ? vi->width >> vi->mock_sub_w : vi->width;
-        const int h = chroma ? vi->height >> vi->mock_sub_h : vi->height;
-        f->plane_id[i] = (vi->mock_rgb ? rgb : yuv)[i];
-        f->row_size[i] = w * vi->mock_component_size;
+        const bool chroma = !pt_rgb(vi) && (i == 1 || i == 2);
+        const int w = chroma ? vi->width >> pt_sub_w(vi) : vi->width;
+        const int h = chroma ? vi->height >> pt_sub_h(vi) : vi->height;
+        f->plane_id[i] = (pt_rgb(vi) ? rgb : yuv)[i];
+        f->row_size[i] = w * pt_component_size(vi);
         f->pitch[i] = (f->row_size[i] + pitch_align - 1) / pitch_align * pitch_align;
         f->height[i] = h;
         f->data[i].assign(static_cast<size_t>(f->pitch[i]) * h + 64, 0xCD);
@@ -90,16 +103,16 @@ AVS_Value avs_new_value_clip(AVS_Clip* clip) {
     return v;
 }
 
-int avs_is_planar(const AVS_VideoInfo* vi) { return vi->mock_planar; }
-int avs_is_rgb(const AVS_VideoInfo* vi) { return vi->mock_rgb; }
-int avs_bits_per_component(const AVS_VideoInfo* vi) { return vi->mock_bits; }
-int avs_component_size(const AVS_VideoInfo* vi) { return vi->mock_component_size; }
-int avs_num_components(const AVS_VideoInfo* vi) { return vi->mock_num_components; }
+int avs_is_planar(const AVS_VideoInfo* vi) { return pt_planar(vi); }
+int avs_is_rgb(const AVS_VideoInfo* vi) { return pt_rgb(vi); }
+int avs_bits_per_component(const AVS_VideoInfo* vi) { return pt_bits(vi); }
+int avs_component_size(const AVS_VideoInfo* vi) { return pt_component_size(vi); }
+int avs_num_components(const AVS_VideoInfo* vi) { return pt_num_components(vi); }
 int avs_get_plane_width_subsampling(const AVS_VideoInfo* vi, int plane) {
-    return (plane == AVS_PLANAR_U || plane == AVS_PLANAR_V) ? vi->mock_sub_w : 0;
+    return (plane == AVS_PLANAR_U || plane == AVS_PLANAR_V) ? pt_sub_w(vi) : 0;
 }
 int avs_get_plane_height_subsampling(const AVS_VideoInfo* vi, int plane) {
-    return (plane == AVS_PLANAR_U || plane == AVS_PLANAR_V) ? vi->mock_sub_h : 0;
+    return (plane == AVS_PLANAR_U || plane == AVS_PLANAR_V) ? pt_sub_h(vi) : 0;
 }
 
 int avs_check_version(AVS_ScriptEnvironment* env, int version) { return env->interface_version >= version ? 0 : -1; }
@@ -274,8 +287,7 @@ MOCK_API AVS_Clip* mock_source_new(AVS_ScriptEnvironment* env, int width, int he
     AVS_VideoInfo& vi = clip->vi;
     std::memset(&vi, 0, sizeof vi);
     vi.width = width, vi.height = height, vi.fps_numerator = 24, vi.fps_denominator = 1, vi.num_frames = num_frames;
-    vi.mock_bits = bits, vi.mock_component_size = component_size, vi.mock_num_components = num_components;
-    vi.mock_planar = planar, vi.mock_rgb = rgb, vi.mock_sub_w = sub_w, vi.mock_sub_h = sub_h;
+    vi.pixel_type = pt_pack(bits, component_size, num_components, planar, rgb, sub_w, sub_h);
     for (int n = 0; n < num_frames; ++n) {
         clip->frames.emplace_back(make_frame(&vi, pitch_align > 0 ? pitch_align : 64));
         if (chroma_location >= 0) clip->frames.back()->props.ints["_ChromaLocation"] = chroma_location;

@@ -24,10 +24,11 @@ def host(pkg):
     os.makedirs(out_dir, exist_ok=True)
     so = os.path.join(out_dir, "libmock_avs_plugin.so")
     srcs = [os.path.join(ROOT, "plugin", "jincresize_avs.cpp"), os.path.join(MOCK, "mock_host.cpp")]
-    deps = srcs + [os.path.join(MOCK, "avisynth_c.h"), os.path.join(ROOT, "include", "jincresize_hip.h")]
+    COMPAT = os.path.join(ROOT, "plugin", "compat")
+    deps = srcs + [os.path.join(COMPAT, "avisynth_c.h"), os.path.join(ROOT, "include", "jincresize_hip.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         cmd = ["g++", "-std=c++17", "-shared", "-fPIC", "-O1", "-Wall", "-Wextra", "-Wno-unused-parameter", "-fvisibility=hidden",
-               "-I" + MOCK, "-I" + os.path.join(ROOT, "include"), *srcs, "-L" + LIBDIR, "-ljincresize_hip",
+               "-I" + COMPAT, "-I" + os.path.join(ROOT, "include"), *srcs, "-L" + LIBDIR, "-ljincresize_hip",
                "-Wl,-rpath," + LIBDIR, "-o", so]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
@@ -306,6 +307,31 @@ def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(host, O)
     clip, err = h.invoke("JincResize", src, 256, 192)
     assert clip is None and err == "JincResize: invalid _ChromaLocation"
     host.mock_source_release(src)
+    h.close()
+
+
+@pytest.mark.gpu
+def test_lookahead_ring_with_skipped_frames_does_not_leak(host, O, monkeypatch):
+    """A client that skips frames (SelectEven: n, n+2, n+4, ...) leaves look-ahead frames unconsumed; they must be waited
+    for and released before their ring slot is reused (two frame references leaked per skipped frame)."""
+    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "3")
+    fmt = O.FORMATS["Y8"]
+    nframes = 12
+    frames = [O.lcg_frame(fmt, 64, 48, seed=900 + n) for n in range(nframes)]
+    of = O.OracleFilter(fmt, 64, 48, 128, 96)
+    h = Host(host)
+    src = h.source(fmt, 64, 48, frames)
+    clip, err = h.invoke("JincResize", src, 128, 96)
+    assert err is None
+    for n in (0, 2, 4, 5, 9, 11, 3):
+        fr = host.mock_clip_get_frame(clip, n)
+        assert host.mock_clip_error(clip) is None
+        got = [h.read_plane(fr, 0, np.uint8)]
+        assert_planes_equal(got, of.get_frame(frames[n], threads=2), fmt.plane_dims(128, 96), what=f"frame {n}")
+        host.mock_frame_release(fr)
+    host.mock_clip_release(clip)
+    host.mock_source_release(src)
+    assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
     h.close()
 
 
