@@ -1,0 +1,456 @@
+// device_plan.cpp -- device-resident plans of a filter instance: upload of the compact plan, and the launch planning
+// for every kernel family (which kernel computes which part of the output plane).  See DESIGN.md section 4.
+#include "filter_internal.h"
+
+namespace jinc {
+namespace host {
+
+namespace {
+
+
+// Smallest stride P <= 8 such that at least 90 % of the interior coordinates keep their class when
+// stepping by P (1 if there is none).  Exact for periodic plans; for drifting ratios (1.5x, 3x) it is
+// the nominal period, and the gather kernel's waterfall absorbs the deviations.
+int dominant_period(const std::vector<int32_t>& cls) {
+    const int n = static_cast<int>(cls.size());
+    for (int P = 1; P <= 8; ++P) {
+        long long same = 0, total = 0;
+        for (int i = 0; i + P < n; ++i) {
+            if (cls[i] < 0 || cls[i + P] < 0) continue;
+            ++total;
+            same += cls[i] == cls[i + P];
+        }
+        if (total > 0 && same * 10 >= total * 9) return P;
+    }
+    return 1;
+}
+
+void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) {
+    struct Piece {
+        const void* host;
+        size_t bytes;
+        size_t offset;
+    };
+    std::vector<Piece> pieces;
+    size_t off = 0;
+    auto add = [&](const void* host, size_t bytes) {
+        off = align_up(off, 256);
+        pieces.push_back({host, bytes, off});
+        off += bytes;
+        return pieces.size() - 1;
+    };
+    const size_t i_cs = add(p.col_start.data(), p.col_start.size() * 4);
+    const size_t i_rs = add(p.row_start.data(), p.row_start.size() * 4);
+    const size_t i_cc = add(p.col_class.data(), p.col_class.size() * 4);
+    const size_t i_rc = add(p.row_class.data(), p.row_class.size() * 4);
+    const size_t i_is = add(p.interior_set.data(), p.interior_set.size() * 4);
+    const size_t i_bc = add(p.bcol_set.data(), p.bcol_set.size() * 4);
+    const size_t i_br = add(p.brow_set.data(), p.brow_set.size() * 4);
+    // device layout of a set: fs rows of padded_fs floats (row stride a multiple of 16 bytes, zero padded)
+    const int fsp = (p.fs + 3) & ~3;
+    std::vector<float> padded(static_cast<size_t>(p.num_sets) * p.fs * fsp, 0.f);
+    for (int s = 0; s < p.num_sets; ++s)
+        for (int ly = 0; ly < p.fs; ++ly)
+            std::memcpy(&padded[(static_cast<size_t>(s) * p.fs + ly) * fsp], p.set_ptr(s) + static_cast<size_t>(ly) * p.fs,
+                        sizeof(float) * p.fs);
+    const size_t i_co = add(padded.data(), padded.size() * 4);
+    t.bytes = align_up(off, 256) + 256;  // slack: kernel_direct.hip fetches whole coefficient blocks (<= 16 floats)
+    hip_check(hipMalloc(&t.blob, t.bytes), "hipMalloc(plan)");
+    char* base = static_cast<char*>(t.blob);
+    for (const Piece& pc : pieces)
+        if (pc.bytes) hip_check(hipMemcpyAsync(base + pc.offset, pc.host, pc.bytes, hipMemcpyHostToDevice, stream), "plan upload");
+    hip_check(hipStreamSynchronize(stream), "plan upload sync");
+
+    auto ptr_i = [&](size_t i) { return reinterpret_cast<const int32_t*>(base + pieces[i].offset); };
+    t.plan.col_start = ptr_i(i_cs);
+    t.plan.row_start = ptr_i(i_rs);
+    t.plan.col_class = ptr_i(i_cc);
+    t.plan.row_class = ptr_i(i_rc);
+    t.plan.interior_set = ptr_i(i_is);
+    t.plan.bcol_set = ptr_i(i_bc);
+    t.plan.brow_set = ptr_i(i_br);
+    t.plan.coeffs = reinterpret_cast<const float*>(base + pieces[i_co].offset);
+    t.plan.src_w = p.g.src_w;
+    t.plan.src_h = p.g.src_h;
+    t.plan.dst_w = p.g.dst_w;
+    t.plan.dst_h = p.g.dst_h;
+    t.plan.fs = p.fs;
+    t.plan.n_col_classes = p.n_col_classes;
+    t.plan.gather_period_x = dominant_period(p.col_class);
+    t.plan.gather_period_y = dominant_period(p.row_class);
+}
+
+jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end);
+
+// Decides how the output plane is split between the periodic kernel and the gather kernel.
+void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
+    const int W = p.g.dst_w, H = p.g.dst_h;
+    t.whole = jinc::RectList{};
+    t.whole.n = 1;
+    t.whole.w[0] = W;
+    t.whole.h[0] = H;
+    // Without an exactly periodic interior the lanes of an item rarely share a coefficient set (drifting classes,
+    // or no structure at all): the gather kernel then skips its uniform passes and fetches coefficients per lane
+    // (1.5x tap 8: 16 -> 26 Gpix/s, 1.37x: 41 -> 65, 5/6: 47 -> 57).
+    t.whole.private_sets = !p.periodic;
+    t.use_periodic = false;
+    if (!p.periodic || !jinc::periodic_supported(p.fs, p.px, p.py, p.sx, p.sy)) return;
+
+    jinc::PeriodicArgs pa;
+    pa.coeffs = t.plan.coeffs;
+    pa.px = p.px;
+    pa.py = p.py;
+    pa.ix0 = p.ix0;
+    pa.iy0 = p.iy0;
+    pa.ni = (p.ix1 - p.ix0) / p.px;
+    pa.nj = (p.iy1 - p.iy0) / p.py;
+    if (pa.ni < 1 || pa.nj < 1) return;
+    int min_sx = INT32_MAX, max_sx = INT32_MIN, min_sy = INT32_MAX, max_sy = INT32_MIN;
+    for (int q = 0; q < p.px; ++q) {
+        pa.start_x[q] = p.col_start[p.ix0 + q];
+        min_sx = std::min(min_sx, pa.start_x[q]);
+        max_sx = std::max(max_sx, pa.start_x[q]);
+    }
+    for (int q = 0; q < p.py; ++q) {
+        pa.start_y[q] = p.row_start[p.iy0 + q];
+        min_sy = std::min(min_sy, pa.start_y[q]);
+        max_sy = std::max(max_sy, pa.start_y[q]);
+    }
+    // The kernel's LDS tile has room for a phase spread of one source sample per axis.
+    if (max_sx - min_sx > 1 || max_sy - min_sy > 1) return;
+    pa.min_sx = min_sx;
+    pa.min_sy = min_sy;
+    for (int q = 0; q < p.py; ++q)
+        for (int r = 0; r < p.px; ++r)
+            pa.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
+                                                  p.col_class[p.ix0 + r]];
+    pa.src_w = p.g.src_w;
+    pa.src_h = p.g.src_h;
+    pa.dst_h = p.g.dst_h;
+    t.periodic = pa;
+    t.use_periodic = true;
+
+    t.border_rects = border_frame(p, p.ix0 + p.px * pa.ni, p.iy0 + p.py * pa.nj);
+}
+
+// The up-to-four rectangles around the interior block [ix0, x_end) x [iy0, y_end) of the output plane.
+jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end) {
+    const int W = p.g.dst_w, H = p.g.dst_h;
+    jinc::RectList r;
+    auto add = [&](int x0, int y0, int w, int h) {
+        if (w <= 0 || h <= 0) return;
+        r.x0[r.n] = x0;
+        r.y0[r.n] = y0;
+        r.w[r.n] = w;
+        r.h[r.n] = h;
+        ++r.n;
+    };
+    add(0, 0, W, p.iy0);                     // top rows
+    add(0, y_end, W, H - y_end);             // bottom rows
+    add(0, p.iy0, p.ix0, y_end - p.iy0);     // left columns
+    add(x_end, p.iy0, W - x_end, y_end - p.iy0);  // right columns
+    return r;
+}
+
+// Quasi-periodic interior (see kernels.h): used when the plan is not exactly periodic but its window
+// origins are affine per residue, or when forced for A/B runs.
+void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
+    t.use_quasi = false;
+    int px, py, sx, sy;
+    // An exactly periodic plan keeps ITS period here too (the affine-origin period may be shorter): the border frame is
+    // laid out once per table for the extent ix0 + px * ni, whichever interior kernel then runs.
+    if (p.periodic) {
+        px = p.px, py = p.py, sx = p.sx, sy = p.sy;
+    } else if (p.quasi) {
+        px = p.qpx, py = p.qpy, sx = p.qsx, sy = p.qsy;
+    } else {
+        return;
+    }
+    if (!jinc::quasi_supported(p.fs, px, py, sx, sy, p.n_col_classes, p.n_row_classes)) return;
+    jinc::QuasiArgs qa;
+    qa.coeffs = t.plan.coeffs;
+    qa.col_class = t.plan.col_class;
+    qa.row_class = t.plan.row_class;
+    qa.interior_set = t.plan.interior_set;
+    qa.n_col_classes = p.n_col_classes;
+    qa.n_row_classes = p.n_row_classes;
+    qa.px = px, qa.py = py, qa.sx = sx, qa.sy = sy;
+    qa.exact = p.periodic ? 1 : 2;  // 1: one set per phase; 2: drifting classes, per-lane coefficient registers
+    qa.ix0 = p.ix0, qa.iy0 = p.iy0;
+    qa.ni = (p.ix1 - p.ix0) / px;
+    qa.nj = (p.iy1 - p.iy0) / py;
+    if (qa.ni < 1 || qa.nj < 1) return;
+    int min_sx = INT32_MAX, max_sx = INT32_MIN, min_sy = INT32_MAX, max_sy = INT32_MIN;
+    for (int k = 0; k < px; ++k) {
+        qa.start_x[k] = p.col_start[p.ix0 + k];
+        min_sx = std::min(min_sx, qa.start_x[k]);
+        max_sx = std::max(max_sx, qa.start_x[k]);
+    }
+    for (int k = 0; k < py; ++k) {
+        qa.start_y[k] = p.row_start[p.iy0 + k];
+        min_sy = std::min(min_sy, qa.start_y[k]);
+        max_sy = std::max(max_sy, qa.start_y[k]);
+    }
+    qa.min_sx = min_sx, qa.min_sy = min_sy;
+    qa.src_w = p.g.src_w, qa.src_h = p.g.src_h, qa.dst_h = p.g.dst_h;
+    if (p.periodic)
+        for (int q = 0; q < py; ++q)
+            for (int r = 0; r < px; ++r)
+                qa.phase_set[q * px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
+                                                          p.col_class[p.ix0 + r]];
+    if (!jinc::quasi_configure(qa, p.fs, max_sx - min_sx, max_sy - min_sy)) return;
+    t.quasi = qa;
+    t.use_quasi = true;
+    if (!t.use_periodic) {
+        t.border_rects = border_frame(p, p.ix0 + px * qa.ni, p.iy0 + py * qa.nj);
+        t.border_rects.private_sets = !p.periodic;
+        t.border_rects.unit_stride = !p.periodic;
+    }
+}
+
+// Exactly periodic plans: kernel_direct.hip can take the interior (it is the choice for down-scales and taps > 8,
+// which the register/LDS kernels do not cover) and, for every interior kernel, the border rows and columns.
+void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
+    t.use_direct = false;
+    if (!p.periodic || !jinc::direct_supported(p.fs, p.px, p.py, p.sx, p.sy)) return;
+    jinc::DirectArgs da;
+    da.coeffs = t.plan.coeffs;
+    da.fs = p.fs;
+    da.coeff_row = (p.fs + 3) & ~3;
+    da.px = p.px, da.py = p.py, da.sx = p.sx, da.sy = p.sy;
+    da.ix0 = p.ix0, da.iy0 = p.iy0;
+    da.ni = (p.ix1 - p.ix0) / p.px;
+    da.nj = (p.iy1 - p.iy0) / p.py;
+    if (da.ni < 1 || da.nj < 1) return;
+    for (int k = 0; k < p.px; ++k) da.start_x[k] = p.col_start[p.ix0 + k];
+    for (int k = 0; k < p.py; ++k) da.start_y[k] = p.row_start[p.iy0 + k];
+    da.dst_h = p.g.dst_h;
+    da.plan = t.plan;
+    const int x_end = p.ix0 + p.px * da.ni, y_end = p.iy0 + p.py * da.nj;
+    const int W = p.g.dst_w, H = p.g.dst_h;
+
+    t.row_strips = da;
+    t.row_strips.line0[0] = 0, t.row_strips.line_n[0] = p.iy0;
+    t.row_strips.line0[1] = y_end, t.row_strips.line_n[1] = H - y_end;
+    jinc::RectList c;
+    auto add = [&](int x0, int y0, int w, int h) {
+        if (w <= 0 || h <= 0) return;
+        c.x0[c.n] = x0, c.y0[c.n] = y0, c.w[c.n] = w, c.h[c.n] = h;
+        ++c.n;
+    };
+    add(0, 0, p.ix0, H);
+    add(x_end, 0, W - x_end, H);
+    t.column_rects = c;
+    c = jinc::RectList{};
+    add(0, 0, p.ix0, p.iy0);
+    add(x_end, 0, W - x_end, p.iy0);
+    add(0, y_end, p.ix0, H - y_end);
+    add(x_end, y_end, W - x_end, H - y_end);
+    c.private_sets = true;  // corner pixels own a coefficient set each
+    c.unit_stride = true;
+    t.corner_rects = c;
+
+    jinc::ColStripArgs ca;
+    ca.coeffs = t.plan.coeffs;
+    ca.fs = p.fs, ca.coeff_row = da.coeff_row;
+    ca.py = p.py, ca.sy = p.sy, ca.iy0 = p.iy0, ca.nj = da.nj;
+    int min_sy = INT32_MAX, max_sy = INT32_MIN;
+    for (int k = 0; k < p.py; ++k) {
+        ca.start_y[k] = da.start_y[k];
+        min_sy = std::min(min_sy, da.start_y[k]);
+        max_sy = std::max(max_sy, da.start_y[k]);
+    }
+    ca.min_sy = min_sy, ca.spread_y = max_sy - min_sy;
+    ca.x0[0] = 0, ca.nx[0] = p.ix0;
+    ca.x0[1] = x_end, ca.nx[1] = W - x_end;
+    for (int s = 0; s < 2; ++s) {
+        if (ca.nx[s] <= 0) continue;
+        int lo = INT32_MAX, hi = INT32_MIN;  // window origins are non-decreasing in x, but do not rely on it
+        for (int x = ca.x0[s]; x < ca.x0[s] + ca.nx[s]; ++x) {
+            lo = std::min(lo, p.col_start[x]);
+            hi = std::max(hi, p.col_start[x] + p.fs);
+        }
+        ca.src_c0[s] = lo, ca.src_w[s] = hi - lo;
+    }
+    ca.plan = t.plan;
+    t.use_colstrip = jinc::colstrip_configure(ca);
+    t.col_strips = ca;
+
+    // The strip kernels take ONE coefficient set per (border row, column phase) / (border column, row phase).  That
+    // holds when the border pixels' coefficients repeat with the interior's period (integer ratios, exact down-scales)
+    // -- but a plan can have a periodic interior and still private border sets: for 3/2 on a small frame the
+    // interior classes have not drifted yet, while the reference computes every border pixel's coefficients from its
+    // float-accumulated position, so no two are equal (found by the widened random sweep).  Check, do not assume.
+    bool uniform = true;
+    for (int y = 0; y < H && uniform; ++y) {
+        if (y >= p.iy0 && y < y_end) continue;
+        for (int r = 0; r < p.px && uniform; ++r) {
+            const int s0 = p.set_of(p.ix0 + r, y);
+            for (int i = 1; i < da.ni; ++i)
+                if (p.set_of(p.ix0 + p.px * i + r, y) != s0) {
+                    uniform = false;
+                    break;
+                }
+        }
+    }
+    for (int x = 0; x < W && uniform; ++x) {
+        if (x >= p.ix0 && x < x_end) continue;
+        for (int q = 0; q < p.py && uniform; ++q) {
+            const int s0 = p.set_of(x, p.iy0 + q);
+            for (int j = 1; j < da.nj; ++j)
+                if (p.set_of(x, p.iy0 + p.py * j + q) != s0) {
+                    uniform = false;
+                    break;
+                }
+        }
+    }
+    t.strips_ok = uniform;
+
+    for (int q = 0; q < p.py; ++q)
+        for (int r = 0; r < p.px; ++r)
+            da.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +
+                                                  p.col_class[p.ix0 + r]];
+    t.direct = da;
+    t.use_direct = true;
+    if (!t.use_periodic && !t.use_quasi) t.border_rects = border_frame(p, x_end, y_end);  // fallback border (gather)
+    if (!t.strips_ok) t.border_rects.private_sets = t.border_rects.unit_stride = true;  // coefficients per lane
+}
+
+}  // namespace
+
+// kernel_direct.hip passes the row offset of its segment fetches as the buffer instructions' scalar offset and relies
+// on the hardware range check covering it (measured on gfx950; LLVM's intrinsic documentation says otherwise).  Checked
+// once per device on the device itself; 1 = covered, 0 = not (the direct kernel is then not used), < 0 = HIP error.
+int buffer_range_check_covers_soffset(int device) {
+    static std::atomic<int> cache[64];  // 0: unknown, 1: not covered, 2: covered
+    if (device < 0 || device >= 64) return 0;
+    const int c = cache[device].load();
+    if (c != 0) return c - 1;
+    constexpr uint32_t N = 4096;
+    std::vector<uint32_t> h(2 * N / 4), r(128, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < h.size(); ++i) h[i] = i;
+    uint32_t *d = nullptr, *o = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc(&d, 2 * N) != hipSuccess) return -1;
+    if (hipMalloc(&o, 128 * 4) != hipSuccess) {
+        (void)hipFree(d);
+        return -1;
+    }
+    bool ok = hipMemcpy(d, h.data(), 2 * N, hipMemcpyHostToDevice) == hipSuccess &&
+              jinc::launch_soffset_probe(d, N, o, nullptr) == 0 && hipMemcpy(r.data(), o, 128 * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    (void)hipFree(o);
+    if (!ok) return -1;
+    bool covered = true;
+    for (uint32_t l = 0; l < 64; ++l) {
+        covered = covered && r[l] == (l < 32 ? (N - 128) / 4 + l : 0u);  // in range up to the descriptor's end, zero past it
+        covered = covered && r[64 + l] == 0u;                            // scalar offset alone past the end
+    }
+    cache[device].store(covered ? 2 : 1);
+    return covered ? 1 : 0;
+}
+
+// kernel_direct.hip fetches whole segments as naturally aligned dwords through a buffer resource that ends with the
+// aligned dword holding the plane's last sample, so it cannot touch memory outside the plane's own dwords.  It needs
+// 4-byte multiples for pitch and frame stride (the plane base may be anywhere) and 32-bit offsets.
+bool direct_fetch_is_safe(size_t frame_stride, int nframes, uint64_t plane_bytes, int pitch, int fs) {
+    if (plane_bytes + static_cast<uint64_t>(pitch) * (fs + 16) + 64 >= (1ull << 32)) return false;
+    if (pitch % 4 != 0) return false;
+    return nframes <= 1 || frame_stride % 4 == 0;
+}
+// Readable bytes from the aligned-down plane base: up to the end of the aligned dword that holds the last sample.
+uint32_t direct_src_bytes(const void* base, uint64_t plane_bytes) {
+    const uint64_t mis = reinterpret_cast<uintptr_t>(base) & 3u;
+    return static_cast<uint32_t>((mis + plane_bytes + 3) & ~3ull);
+}
+
+namespace {
+// Rectangles whose pixels own private coefficient sets (border frame of drifting plans, corners of periodic plans):
+// a lane-major copy of exactly those coefficients, in the gather kernel's item order, turns its per-lane coefficient
+// fetches (64 cache lines per wave and fetch) into contiguous ones.  See RectList::lane_coeffs.
+void attach_lane_coeffs(const jinc::PlanePlan& p, DeviceTable& t, jinc::RectList& rects, hipStream_t stream) {
+    if (!rects.private_sets || rects.n <= 0) return;
+    const int fs = p.fs, fsp = (p.fs + 3) & ~3;
+    const size_t item_floats = static_cast<size_t>(fs) * fsp * 64;
+    long long total = 0;
+    for (int r = 0; r < rects.n; ++r) {
+        int axis, P;
+        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], rects.unit_stride, axis, P);
+        rects.lane_item_base[r] = total;
+        total += jinc::gather_item_count(rects.w[r], rects.h[r], axis, P);
+    }
+    if (total <= 0 || static_cast<unsigned long long>(total) * item_floats * sizeof(float) > (512ull << 20)) return;
+    std::vector<float> buf(static_cast<size_t>(total) * item_floats, 0.f);
+    for (int r = 0; r < rects.n; ++r) {
+        int axis, P;
+        jinc::gather_rect_layout(t.plan, rects.w[r], rects.h[r], rects.unit_stride, axis, P);
+        const int along = axis == 0 ? rects.w[r] : rects.h[r], across = axis == 0 ? rects.h[r] : rects.w[r];
+        const int blocks = (along + 64 * P - 1) / (64 * P);
+        for (int line = 0; line < across; ++line)
+            for (int res = 0; res < P; ++res)
+                for (int ba = 0; ba < blocks; ++ba) {
+                    float* item = buf.data() + static_cast<size_t>(rects.lane_item_base[r] + static_cast<long long>(line * P + res) * blocks + ba) * item_floats;
+                    for (int l = 0; l < 64; ++l) {
+                        const int coord = ba * 64 * P + P * l + res;
+                        if (coord >= along) break;
+                        const int x = rects.x0[r] + (axis == 0 ? coord : line), y = rects.y0[r] + (axis == 0 ? line : coord);
+                        const float* src = p.set_ptr(p.set_of(x, y));
+                        for (int ly = 0; ly < fs; ++ly)
+                            for (int lx = 0; lx < fs; ++lx)
+                                item[((static_cast<size_t>(ly) * (fsp / 4) + lx / 4) * 64 + l) * 4 + lx % 4] = src[ly * fs + lx];
+                    }
+                }
+    }
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, buf.size() * sizeof(float)), "hipMalloc(lane-major coefficients)");
+    t.lane_blobs.push_back(dev);
+    hip_check(hipMemcpyAsync(dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, stream), "lane-major coefficient upload");
+    hip_check(hipStreamSynchronize(stream), "lane-major coefficient upload sync");
+    rects.lane_coeffs = static_cast<const float*>(dev);
+}
+
+}  // namespace
+
+void init_device(jinc_filter& f, int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw HipError("JincResize: no HIP device available.");
+    if (device >= count) throw HipError("JincResize: HIP device index out of range.");
+    hip_check(hipSetDevice(device), "hipSetDevice");
+    f.device = device;
+    hip_check(hipStreamCreateWithFlags(&f.stream, hipStreamNonBlocking), "hipStreamCreate");
+    {   // The side stream carries the small border kernels: at the highest priority its workgroups are dispatched as
+        // soon as slots free up instead of queueing behind the interior kernel, which can hold every wave slot.
+        int least = 0, greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        hip_check(hipStreamCreateWithPriority(&f.aux_stream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+    }
+    hip_check(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming), "hipEventCreate");
+    f.direct_premise = buffer_range_check_covers_soffset(device) == 1;
+    f.tables.resize(f.plans.size());
+    for (size_t i = 0; i < f.plans.size(); ++i) {
+        upload_table(f.plans[i], f.tables[i], f.stream);
+        plan_launches(f.plans[i], f.tables[i]);
+        plan_quasi(f.plans[i], f.tables[i]);
+        plan_direct(f.plans[i], f.tables[i]);
+        {   // every interior variant of a table must cover the same extent: the border frame is laid out once
+            const DeviceTable& t = f.tables[i];
+            int ex = -1, ey = -1;
+            auto same = [&](int x_end, int y_end) {
+                if (ex < 0) ex = x_end, ey = y_end;
+                if (ex != x_end || ey != y_end) throw std::runtime_error("JincResize: interior kernels disagree about the interior extent.");
+            };
+            if (t.use_periodic) same(t.periodic.ix0 + t.periodic.px * t.periodic.ni, t.periodic.iy0 + t.periodic.py * t.periodic.nj);
+            if (t.use_quasi) same(t.quasi.ix0 + t.quasi.px * t.quasi.ni, t.quasi.iy0 + t.quasi.py * t.quasi.nj);
+            if (t.use_direct) same(t.direct.ix0 + t.direct.px * t.direct.ni, t.direct.iy0 + t.direct.py * t.direct.nj);
+        }
+        attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].border_rects, f.stream);
+        attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].corner_rects, f.stream);
+        f.tables[i].use_framelane =
+            jinc::framelane_configure(f.plans[i], f.tables[i].whole, f.vi_in.component_size, 64, f.tables[i].fl_whole);
+        f.tables[i].fl_whole.plan = f.tables[i].plan;
+    }
+}
+
+}  // namespace host
+}  // namespace jinc

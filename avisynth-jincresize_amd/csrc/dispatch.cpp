@@ -1,0 +1,172 @@
+// dispatch.cpp -- the kernel launches of one frame call: per plane, which interior kernel and which border kernels run,
+// on which stream (the body of the process_frame call, ref /root/reference/src/JincResize.cpp:615, on device planes).
+#include "filter_internal.h"
+
+namespace jinc {
+namespace host {
+
+void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
+             void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
+    const int sb = f.vi_in.component_size;
+    // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
+    // kernel wherever it applies (also for exactly periodic plans)
+    auto wants_quasi = [&](const DeviceTable& t) {
+        return t.use_quasi && (f.kernel_mode == 7 || f.kernel_mode == 8 || f.kernel_mode == 10 || (f.kernel_mode != 1 && !t.use_periodic));
+    };
+    auto wants_periodic = [&](const DeviceTable& t) {
+        return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8 && f.kernel_mode != 10;
+    };
+    // Is kernel_direct.hip usable for plane i (interior and border strips)?  See direct_fetch_is_safe().
+    auto direct_ok = [&](const DeviceTable& t, int i) {
+        if (!t.use_direct || f.kernel_mode == 1 || !f.direct_premise) return false;
+        const uint64_t plane_bytes = static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb;
+        return direct_fetch_is_safe(src_fs ? src_fs[i] : 0, nframes, plane_bytes, src_pitch[i], t.plan.fs);
+    };
+    // kernel_mode 9: the direct kernel wherever it applies; otherwise it takes the interior of the exactly periodic
+    // plans the register/LDS kernels do not cover.
+    auto wants_direct = [&](const DeviceTable& t, int i) {
+        if (!direct_ok(t, i)) return false;
+        return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
+    };
+    // Frame-lane kernel (lanes = frames): the choice for batches whose plan has no phase structure for the other
+    // interior kernels (they would run on the gather kernel with per-lane coefficient traffic); kernel_mode 11 forces
+    // it for every plan and batch size.
+    auto wants_framelane = [&](const DeviceTable& t, int i) {
+        if (!t.use_framelane || f.kernel_mode == 1) return false;
+        if (f.kernel_mode == 11) return true;
+        if (f.kernel_mode != 0) return false;
+        if (nframes < kFrameLaneMinFrames) return false;
+        if (wants_periodic(t)) return false;
+        // Drifting plans with many phases (DVD -> 1080p: 8 x 9) leave the quasi-periodic kernel little to share per phase:
+        // measured at 64 frames 33 % of the VALU peak against 46 % here; with few phases (1.5x, 3x: 9) it stays ahead.
+        if (wants_quasi(t)) return !f.plans[f.table_of_plane(i)].periodic && t.quasi.px * t.quasi.py > 16 && nframes >= 48;
+        return !wants_direct(t, i);
+    };
+    bool any_periodic = false;
+    for (int i = 0; i < f.planecount; ++i) {
+        const DeviceTable& t = f.tables[f.table_of_plane(i)];
+        any_periodic |= f.simd_order == 0 && !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i));
+    }
+    // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
+    // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
+    const bool want_overlap = f.overlap_border != 0;
+    const bool fork = any_periodic && want_overlap;
+    if (fork) {  // border work may start once everything already queued on `stream` is done
+        hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");
+        hip_check(hipStreamWaitEvent(f.aux_stream, f.ev_fork, 0), "hipStreamWaitEvent(fork)");
+    }
+    hipStream_t border_stream = fork ? f.aux_stream : stream;
+    for (int i = 0; i < f.planecount; ++i) {
+        DeviceTable& t = f.tables[f.table_of_plane(i)];
+        if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
+        if (src_pitch[i] % sb || dst_pitch[i] % sb) throw ArgError("JincResize: plane pitch is not a multiple of the sample size.");
+        if (reinterpret_cast<uintptr_t>(src[i]) % sb || reinterpret_cast<uintptr_t>(dst[i]) % sb)
+            throw ArgError("JincResize: plane pointer is not aligned to the sample size.");
+        if (src_fs && nframes > 1 && src_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
+        if (dst_fs && nframes > 1 && dst_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
+        if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(t.plan.src_w) * sb ||
+            static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(t.plan.dst_w) * sb)
+            throw ArgError("JincResize: plane pitch is smaller than the row size.");
+        if (static_cast<uint64_t>(dst_pitch[i]) * t.plan.dst_h >= (1ull << 32))
+            throw ArgError("JincResize: destination plane larger than 4 GiB is not supported (32-bit store offsets).");
+        jinc::PlaneIO io;
+        io.src = src[i];
+        io.dst = dst[i];
+        io.src_pitch = src_pitch[i];
+        io.dst_pitch = dst_pitch[i];
+        io.src_frame_stride = src_fs ? src_fs[i] : 0;
+        io.dst_frame_stride = dst_fs ? dst_fs[i] : 0;
+        io.nframes = nframes;
+        io.sample_bytes = sb;
+        io.peak = f.peak;
+        auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
+            EventPair ev;
+            if (f.profiling) {
+                hip_check(hipEventCreate(&ev.start), "hipEventCreate");
+                hip_check(hipEventCreate(&ev.stop), "hipEventCreate");
+                hip_check(hipEventRecord(ev.start, s), "hipEventRecord");
+            }
+            hip_check(static_cast<hipError_t>(launch(s)), what);
+            if (f.profiling) {
+                hip_check(hipEventRecord(ev.stop, s), "hipEventRecord");
+                sink.push_back(ev);
+            }
+        };
+        if (f.simd_order != 0) {  // compatibility modes (private switch): whole plane on kernel_simdorder.hip
+            const float min_val = (i != 0 && !f.vi_in.is_rgb) ? -0.5f : 0.f;  // ref resize_plane_sse41.cpp:20
+            t.last_kernel = "ewa_simd_order_kernel";
+            timed(f.ev_gather, stream, "SIMD-order kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_simd_order(t.plan, io, f.simd_order, min_val, s); });
+            continue;
+        }
+        if (wants_framelane(t, i)) {
+            jinc::FrameLaneArgs fa = t.fl_whole;
+            fa.io = io;
+            const uintptr_t vec = static_cast<uintptr_t>(4 * sb);
+            fa.vec_store_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
+                              (nframes <= 1 || io.dst_frame_stride % vec == 0);
+            t.last_kernel = "ewa_framelane_kernel";
+            timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            continue;
+        }
+        const bool direct = wants_direct(t, i);
+        const bool quasi = !direct && wants_quasi(t);
+        const bool periodic = !direct && !quasi && wants_periodic(t);
+        t.last_kernel = direct ? "ewa_direct_kernel" : quasi ? "ewa_quasi_kernel" : periodic ? "ewa_periodic_kernel" : "ewa_gather_kernel";
+        if (direct || periodic || quasi) {
+            // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
+            const bool strips = f.border_strips != 0 && t.strips_ok && direct_ok(t, i);
+            if (strips) {
+                jinc::DirectArgs rs = t.row_strips;
+                rs.src_bytes = direct_src_bytes(
+                    src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                const bool colstrip = t.use_colstrip && f.border_strips != 2;
+                // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
+                // last it would start when the interior kernel already holds every wave slot
+                if (colstrip && t.corner_rects.n > 0)
+                    timed(f.ev_gather, border_stream, "corner kernel launch",
+                          [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
+                timed(f.ev_gather, border_stream, "border row kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
+                if (colstrip) {
+                    timed(f.ev_gather, border_stream, "border column kernel launch",
+                          [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
+                } else if (t.column_rects.n > 0) {
+                    timed(f.ev_gather, border_stream, "border column kernel launch",
+                          [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
+                }
+            } else if (t.border_rects.n > 0) {
+                timed(f.ev_gather, border_stream, "border kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
+            }
+            if (direct)
+                timed(f.ev_periodic, stream, "direct periodic kernel launch", [&](hipStream_t s) {
+                    jinc::DirectArgs da = t.direct;
+                    da.src_bytes = direct_src_bytes(
+                        src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                    return jinc::launch_direct(da, io, s);
+                });
+            else if (quasi)
+                timed(f.ev_periodic, stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
+                    jinc::QuasiArgs qa = t.quasi;
+                    if (f.kernel_mode == 8) qa.exact = 0;   // A/B: per-row lookup + waterfall over sets in SGPRs
+                    if (f.kernel_mode == 10) qa.exact = 2;  // A/B: per-row lookup + per-lane coefficient registers
+                    return jinc::launch_quasi(qa, t.plan.fs, io, s);
+                });
+            else
+                timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
+                    return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, f.kernel_mode >= 3 ? f.kernel_mode - 2 : 0);
+                });
+        } else {
+            timed(f.ev_gather, stream, "gather kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.whole, s); });
+        }
+    }
+    if (fork) {  // `stream` continues only after the border kernels have finished too
+        hip_check(hipEventRecord(f.ev_join, f.aux_stream), "hipEventRecord(join)");
+        hip_check(hipStreamWaitEvent(stream, f.ev_join, 0), "hipStreamWaitEvent(join)");
+    }
+}
+
+}  // namespace host
+}  // namespace jinc

@@ -343,7 +343,11 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
     ga.io = io;
     ga.rects = rects;
     ga.max_passes = rects.private_sets ? 0 : 4;
-    if (const char* e = std::getenv("JINC_GATHER_PASSES")) ga.max_passes = std::atoi(e);  // A/B knob
+    static const int env_passes = [] {  // A/B knob, read once
+        const char* e = std::getenv("JINC_GATHER_PASSES");
+        return e ? std::atoi(e) : -1;
+    }();
+    if (env_passes >= 0) ga.max_passes = env_passes;
     int total = 0;
     for (int r = 0; r < 4; ++r) {
         ga.block_begin[r] = total;
