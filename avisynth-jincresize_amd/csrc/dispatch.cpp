@@ -105,14 +105,20 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             const uintptr_t vec = static_cast<uintptr_t>(4 * sb);
             fa.vec_store_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
                               (nframes <= 1 || io.dst_frame_stride % vec == 0);
-            t.last_kernel = "ewa_framelane_kernel";
+            t.last_kernel = (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
+                                ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
             timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             continue;
         }
         const bool direct = wants_direct(t, i);
         const bool quasi = !direct && wants_quasi(t);
         const bool periodic = !direct && !quasi && wants_periodic(t);
-        t.last_kernel = direct ? "ewa_direct_kernel" : quasi ? "ewa_quasi_kernel" : periodic ? "ewa_periodic_kernel" : "ewa_gather_kernel";
+        t.last_kernel = direct     ? "ewa_direct_kernel"
+                        : quasi    ? "ewa_quasi_kernel"
+                        : periodic ? ((f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
+                                      : (f.kernel_mode == 3 || (t.plan.fs != 7 && t.plan.fs != 9)) ? "ewa_periodic_rows_kernel"
+                                                                                                    : "ewa_periodic_kernel")
+                                   : "ewa_gather_kernel";
         if (direct || periodic || quasi) {
             // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
             const bool strips = f.border_strips != 0 && t.strips_ok && direct_ok(t, i);
