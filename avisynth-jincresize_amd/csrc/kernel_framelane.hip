@@ -266,26 +266,21 @@ __device__ __forceinline__ float fl_win_mac(const float (&w)[FS][FS], const JINC
     float acc = 0.f;
 #pragma unroll
     for (int g0 = 0; g0 < FS; g0 += G) {
-        float c[G][FSP];
+        constexpr int NR = G;  // rows of this batch (the last batch may be shorter)
+        float c[NR * FSP];
+        const JINC_CONSTANT float* cp = reinterpret_cast<const JINC_CONSTANT float*>(cset + g0 * FSP * 4);
+        // one contiguous run of floats -> s_load_dwordx16 / x8 / x4 pieces, one address computation per batch
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            if (g0 + g < FS) {
-                const JINC_CONSTANT float* cp = reinterpret_cast<const JINC_CONSTANT float*>(cset + (g0 + g) * FSP * 4);
+        for (int i = 0; i < NR * FSP; ++i)
+            if (g0 * FSP + i < FS * FSP) c[i] = cp[i];
 #pragma unroll
-                for (int lx = 0; lx < FSP; ++lx) c[g][lx] = cp[lx];
-            }
-        }
+        for (int i = 0; i < NR * FSP; ++i)
+            if (g0 * FSP + i < FS * FSP) asm volatile("" : "+s"(c[i]));
 #pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (g0 + g < FS) {
-#pragma unroll
-                for (int lx = 0; lx < FSP; ++lx) asm volatile("" : "+s"(c[g][lx]));
-            }
-#pragma unroll
-        for (int g = 0; g < G; ++g)
+        for (int g = 0; g < NR; ++g)
             if (g0 + g < FS) {
 #pragma unroll
-                for (int lx = 0; lx < FS; ++lx) acc = acc + w[(PH + lx) % FS][g0 + g] * c[g][lx];
+                for (int lx = 0; lx < FS; ++lx) acc = acc + w[(PH + lx) % FS][g0 + g] * c[g * FSP + lx];
             }
     }
     return acc;
