@@ -1,7 +1,6 @@
 ulimit -c 0
-run() { timeout 60 python bench.py --config A137 --frames 64 --no-cpu-baseline --kernel-mode 11 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$1', d['value'], d['roofline']['valu_frac'])"; }
-JINC_FL_VARIANT=0 run base
-JINC_FL_VARIANT=2 run nostore
-JINC_FL_VARIANT=4 run nostage
-JINC_FL_VARIANT=8 run sameset
-JINC_FL_VARIANT=14 run all_off
+run() { timeout 60 python bench.py --config $2 --frames 64 --no-cpu-baseline --kernel-mode 11 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$2', '$1', d['value'], d['roofline']['valu_frac'])"; }
+for c in A137 A1875; do
+JINC_FL_VARIANT=0 run base $c
+for n in 1 2 4 8; do JINC_FL_VARIANT=$((16 + n*256)) run stagger$n $c; done
+done
