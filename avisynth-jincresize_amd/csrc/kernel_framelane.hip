@@ -300,22 +300,37 @@ __device__ __forceinline__ bool fl_win_step(float (&w)[FS][FS], const char*& pc,
                                             int setv, const JINC_CONSTANT char* cbase, float (&res)[4], char* drow, bool lane_on,
                                             bool vec_ok, float peak) {
     constexpr int SB = static_cast<int>(sizeof(T));
-    constexpr uint32_t kSetBytes = FS * padded_row(FS) * 4;
     if (s > s_last) return false;  // wave-uniform
     fl_win_load_col<T, FS>(w[(I + FS - 1) % FS], pc);  // column s + FS - 1
     pc += pc_step;
     while (j < npix && __builtin_amdgcn_readlane(csv, j) == s) {
-        const uint32_t soff = static_cast<uint32_t>(__builtin_amdgcn_readlane(setv, j)) * kSetBytes;
+        const uint32_t soff = static_cast<uint32_t>(__builtin_amdgcn_readlane(setv, j));
         const float acc = fl_win_mac<T, FS, I>(w, cbase + soff);
-        switch (j & 3) {
-            case 0: res[0] = acc; break;
-            case 1: res[1] = acc; break;
-            case 2: res[2] = acc; break;
-            default: res[3] = acc; break;
-        }
-        if ((j & 3) == 3 || j == npix - 1) {
-            const int nvx = (j & 3) + 1;
-            if (lane_on) fl_store4<T>(drow + static_cast<size_t>(j & ~3) * SB, res, nvx, vec_ok && nvx == 4, peak);
+        const int q = j & 3;
+        const bool flush = q == 3 || j == npix - 1;  // wave-uniform
+        if constexpr (std::is_same_v<T, uint8_t>) {
+            // 8-bit: the converted sample goes straight into byte q of the packed word (byte select from an SGPR): one
+            // vector instruction instead of a four-way compare / select on the result registers
+            uint32_t& pk = reinterpret_cast<uint32_t&>(res[0]);
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(acc, static_cast<uint32_t>(q), q == 0 ? 0u : pk);
+            if (flush && lane_on) {
+                char* d = drow + static_cast<size_t>(j & ~3);
+                if (vec_ok && q == 3) {
+                    *reinterpret_cast<uint32_t*>(d) = pk;
+                } else {
+#pragma unroll
+                    for (int xx = 0; xx < 4; ++xx)
+                        if (xx <= q) reinterpret_cast<uint8_t*>(d)[xx] = static_cast<uint8_t>(pk >> (8 * xx));
+                }
+            }
+        } else {
+            switch (q) {
+                case 0: res[0] = acc; break;
+                case 1: res[1] = acc; break;
+                case 2: res[2] = acc; break;
+                default: res[3] = acc; break;
+            }
+            if (flush && lane_on) fl_store4<T>(drow + static_cast<size_t>(j & ~3) * SB, res, q + 1, vec_ok && q == 3, peak);
         }
         ++j;
     }
@@ -361,7 +376,8 @@ __global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneA
     __syncthreads();
     asm volatile("" ::"v"(pf_keep));
     // Lanes without a frame (last group of the batch) stay active: the strip tables below live one pixel per LANE and are
-    // read with v_readlane, so every lane has to load its entry.  Such lanes compute on unwritten LDS and store nothing.
+    // read with v_readlane, so every lane has to load its entry.  Such lanes compute on unwritten LDS and store nothing
+    // (letting them skip the strip body with a divergent `continue` hung the test suite on the device).
     const bool lane_on = lane < t.nfg;
 
     char* dframe = static_cast<char*>(a.io.dst) + static_cast<size_t>(t.f0 + (lane_on ? lane : 0)) * a.io.dst_frame_stride;
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneA
         const int sy = __builtin_amdgcn_readfirstlane(rs[st]);
         const int pj = min(lane & 31, npix - 1);
         const int csv = cs[pj];                              // lane j: window origin of the strip's pixel j
-        const int setv = sets[st * kFrameLaneMaxTile + pj];  // ... and its coefficient set
+        const int setv = static_cast<int>(static_cast<uint32_t>(sets[st * kFrameLaneMaxTile + pj]) * kSetBytes);  // ... and the byte offset of its coefficient set
         const char* lrow = lds_lane + (sy - t.ty0) * PS;            // column c of the window rows: + (c - tx0) * thp * PS
         char* drow = dframe + static_cast<size_t>(t.by0 + st) * a.io.dst_pitch + static_cast<size_t>(t.bx0) * SB;
         // The strip is walked by WINDOW ORIGIN (source column), not by pixel: consecutive origins advance the ring by
