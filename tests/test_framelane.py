@@ -30,6 +30,10 @@ def test_single_frame_through_the_framelane_kernel(gpu_pkg, O, case):
 BATCH_CASES = [
     # (format, src, dst, args, batch sizes)
     ("Y8", 160, 90, 219, 123, {}, (1, 3, 16, 64, 70, 130)),                  # 1.37x: no phase structure, fs 7
+    ("Y8", 300, 200, 411, 274, {}, (64, 96)),                                # many tiles per launch
+    ("Y16", 300, 200, 411, 274, {}, (40,)),
+    ("Y32", 300, 200, 380, 250, {}, (64,)),
+    ("Y8", 400, 300, 333, 250, {}, (70,)),                                   # 5/6 down-scale (fs 8)
     ("Y16", 160, 90, 219, 123, {}, (17, 65)),
     ("Y32", 160, 90, 219, 123, {}, (17, 64)),
     ("Y8", 192, 108, 160, 90, {}, (33, 64)),                                 # 5/6 down-scale: fs 8
@@ -78,6 +82,35 @@ def test_batches_of_frames(gpu_pkg, O, case):
         for k in range(n):
             got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
             assert_planes_equal(got, wants[k], ddims, what=f"batch {n} frame {k}")
+    f.close()
+
+
+def test_full_size_batch(gpu_pkg, O):
+    """1280x720 -> 1754x986 (no phase structure), 64 + 5 frames (a full frame group and a partial one): all frames against
+    the forced gather kernel, four of them against the oracle."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th, n = "Y8", 1280, 720, 1754, 986, 69
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    src = torch.randint(0, 256, (n, sh, 1280), device="cuda", generator=gen, dtype=torch.int32).to(torch.uint8)
+    outs = []
+    for mode in (0, 1):
+        dst = torch.zeros((n, th, 1792), dtype=torch.uint8, device="cuda")
+        f.set_kernel_mode(mode)
+        stream = torch.cuda.current_stream()
+        f.process_device([src.data_ptr()], [src.stride(1)], [src.stride(0)], [dst.data_ptr()], [dst.stride(1)], [dst.stride(0)], n,
+                         stream=stream.cuda_stream)
+        stream.synchronize()
+        if mode == 0:
+            assert f.last_kernel(0) == "ewa_framelane_win_kernel", f.last_kernel(0)
+        outs.append(dst[:, :, :tw].cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    for k in (0, 31, 64, 68):
+        frame = [np.ascontiguousarray(src[k].cpu().numpy())]
+        want = of.get_frame(frame, threads=16)[0][:th, :tw]
+        assert np.array_equal(outs[0][k], want), f"frame {k}"
     f.close()
 
 
