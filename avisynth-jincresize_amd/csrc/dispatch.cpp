@@ -105,7 +105,8 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             const uintptr_t vec = static_cast<uintptr_t>(4 * sb);
             fa.vec_store_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
                               (nframes <= 1 || io.dst_frame_stride % vec == 0);
-            t.last_kernel = (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
+            t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
+                            : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
                                 ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
             timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             continue;

@@ -26,8 +26,13 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     // LDS per workgroup: a larger tile has less halo (fewer staged samples per output pixel), a smaller one lets more
     // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
     size_t budget = 64 * 1024;  // A/B (64 frames): 1.37x fs 7 48 KB = 64 KB; 5/6 down-scale fs 8 +28 % over 48 KB
+    // fs 7: the 1024-thread shape of the sliding-window kernel (two workgroups per CU at 64 VGPRs = 8 waves per SIMD) with
+    // tiles of up to 80 KB
+    bool big = p.fs == 7;
+    if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
+    if (big) budget = 80 * 1024;
     if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
-    budget = std::min<size_t>(budget, 64 * 1024);
+    budget = std::min<size_t>(budget, big ? 80 * 1024 : 64 * 1024);
     const int groups = std::max(1, (nframes_hint + 63) / 64);
 
     bool found = false, found_enough = false;
@@ -76,6 +81,7 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     out.block_begin[4] = total;
     const int units = (tx / 4) * (ty / 4);
     out.threads = 64 * std::min(8, std::max(1, units));
+    if (big && units >= 16) out.threads = 1024;  // (small tiles keep the 512-thread shape)
     if (const char* e = std::getenv("JINC_FL_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
     out.variant = 0;
     if (const char* e = std::getenv("JINC_FL_VARIANT")) out.variant = std::atoi(e);  // A/B knob: 1 = row-segment form always

@@ -339,87 +339,15 @@ __device__ __forceinline__ bool fl_win_step(float (&w)[FS][FS], const char*& pc,
 
 template <typename T, int FS>
 __global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char fl_smem[];
-    int* cs = reinterpret_cast<int*>(fl_smem);
-    int* rs = cs + kFrameLaneMaxTile;
-    int* sets = rs + kFrameLaneMaxTile;
-    char* tile = fl_smem + kFlTableInts * 4;
-    constexpr int PS = kFrameLanePosBytes(sizeof(T));
-    constexpr int SB = static_cast<int>(sizeof(T));
-    constexpr uint32_t kSetBytes = FS * padded_row(FS) * 4;
-    const DevicePlan& p = a.plan;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
-    FlTile t;
-    if (!fl_locate(a, FS, t)) return;  // whole block, before any barrier
-    fl_tables(a, t, cs, rs, sets);
-    __syncthreads();
+#include "kernel_framelane_win_body.inc"
+}
 
-    // Coefficient sets of a strip (one output row of the tile, <= 32 pixels), requested one strip ahead with VECTOR
-    // loads, one cache line per lane: see ewa_framelane_kernel.
-    const int nstrips = t.by1 - t.by0 + 1, npix = t.bx1 - t.bx0 + 1;
-    auto prefetch_strip = [&](int st) -> uint32_t {
-        uint32_t keep = 0;
-        if (st < nstrips) {
-            const int set = sets[st * kFrameLaneMaxTile + min(lane & 31, npix - 1)];  // (entries past the tile's width are not filled)
-            const char* sp = reinterpret_cast<const char*>(p.coeffs) + static_cast<size_t>(static_cast<uint32_t>(set) * kSetBytes);
-            for (uint32_t off = static_cast<uint32_t>(lane >> 5) * 64u; off < kSetBytes + 60u; off += 128u)
-                keep |= *reinterpret_cast<const uint32_t*>(sp + (off < kSetBytes - 4u ? off : kSetBytes - 4u));
-        }
-        return keep;
-    };
-    uint32_t pf_keep = prefetch_strip(wave);
-
-    const int thp = t.th | 1;  // odd column pitch: the staging writes of neighbouring columns fall on different banks
-    fl_stage<T>(a, t, tile, 1, thp, lane, wave, nwaves);
-    __syncthreads();
-    asm volatile("" ::"v"(pf_keep));
-    // Lanes without a frame (last group of the batch) stay active: the strip tables below live one pixel per LANE and are
-    // read with v_readlane, so every lane has to load its entry.  Such lanes compute on unwritten LDS and store nothing
-    // (letting them skip the strip body with a divergent `continue` hung the test suite on the device).
-    const bool lane_on = lane < t.nfg;
-
-    char* dframe = static_cast<char*>(a.io.dst) + static_cast<size_t>(t.f0 + (lane_on ? lane : 0)) * a.io.dst_frame_stride;
-    const char* lds_lane = tile + lane * SB;
-    const JINC_CONSTANT char* cbase = (const JINC_CONSTANT char*)(p.coeffs);
-    const bool vec_ok = a.vec_store_ok && ((t.bx0 & 3) == 0);
-    for (int st = wave; st < nstrips; st += nwaves) {
-        asm volatile("" ::"v"(pf_keep));
-        pf_keep = prefetch_strip(st + nwaves);
-        const int sy = __builtin_amdgcn_readfirstlane(rs[st]);
-        const int pj = min(lane & 31, npix - 1);
-        const int csv = cs[pj];                              // lane j: window origin of the strip's pixel j
-        const int setv = static_cast<int>(static_cast<uint32_t>(sets[st * kFrameLaneMaxTile + pj]) * kSetBytes);  // ... and the byte offset of its coefficient set
-        const char* lrow = lds_lane + (sy - t.ty0) * PS;            // column c of the window rows: + (c - tx0) * thp * PS
-        char* drow = dframe + static_cast<size_t>(t.by0 + st) * a.io.dst_pitch + static_cast<size_t>(t.bx0) * SB;
-        // The strip is walked by WINDOW ORIGIN (source column), not by pixel: consecutive origins advance the ring by
-        // exactly one column, so with the origin loop unrolled FS times the ring phase -- and with it every register index
-        // of the tap loop -- is a compile-time constant (a switch on a run-time phase makes the compiler copy the whole
-        // window between the cases).  An origin serves 0, 1 or 2 pixels (source step 0.5 .. 2).
-        float w[FS][FS];  // w[slot][ly]; source column c of the strip lives in slot (c - s_first) % FS
-        const int s_first = __builtin_amdgcn_readlane(csv, 0), s_last = __builtin_amdgcn_readlane(csv, npix - 1);
-        const char* pc = lrow + (s_first - t.tx0) * thp * PS;  // next column to load
-#pragma unroll
-        for (int i = 0; i < FS - 1; ++i) {
-            fl_win_load_col<T, FS>(w[i], pc);
-            pc += thp * PS;
-        }
-        int j = 0;
-        float res[4] = {0.f, 0.f, 0.f, 0.f};
-        static_assert(FS <= 9, "the step list below has nine entries");
-        for (int s0 = s_first; s0 <= s_last; s0 += FS) {
-#define JINC_FL_STEP(I)                                                                                                           \
-    if constexpr (I < FS) {                                                                                                        \
-        if (!fl_win_step<T, FS, (I < FS ? I : 0)>(w, pc, thp * PS, s0 + I, s_last, j, npix, csv, setv, cbase, res, drow, lane_on, \
-                                                  vec_ok, a.io.peak))                                                             \
-            break;                                                                                                                 \
-    }
-            JINC_FL_STEP(0) JINC_FL_STEP(1) JINC_FL_STEP(2) JINC_FL_STEP(3) JINC_FL_STEP(4) JINC_FL_STEP(5) JINC_FL_STEP(6)
-            JINC_FL_STEP(7) JINC_FL_STEP(8)
-#undef JINC_FL_STEP
-        }
-    }
+// The same kernel as 1024-thread workgroups held to 64 VGPRs: two workgroups per CU = 8 waves per SIMD (the kernel reacts
+// to waves per SIMD more than to anything else), each with a tile of up to 80 KB (32 x 32 pixels for up-scales: less halo,
+// half the barriers).  fs 7 only: the larger windows do not fit 64 registers.
+template <typename T, int FS>
+__global__ __launch_bounds__(1024, 8) void ewa_framelane_win1k_kernel(const FrameLaneArgs a) {
+#include "kernel_framelane_win_body.inc"
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,8 +506,24 @@ int launch_fl_win(const FrameLaneArgs& a, hipStream_t stream) {
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int FS>
+int launch_fl_win1k(const FrameLaneArgs& a, hipStream_t stream) {
+    static bool attr_set = false;  // dynamic LDS beyond 64 KB needs the attribute once per kernel
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ewa_framelane_win1k_kernel<T, FS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                80 * 1024) != hipSuccess)
+            return static_cast<int>(hipGetLastError());
+        attr_set = true;
+    }
+    const int ntiles = a.block_begin[4];
+    dim3 grid(static_cast<unsigned>((ntiles + 7) / 8) * 8u, static_cast<unsigned>((a.io.nframes + 63) / 64), 1), block(1024, 1, 1);
+    hipLaunchKernelGGL((ewa_framelane_win1k_kernel<T, FS>), grid, block, static_cast<size_t>(a.lds_bytes), stream, a);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T>
 int launch_fl_fs(const FrameLaneArgs& a, hipStream_t stream) {
+    if (a.threads == 1024 && a.plan.fs == 7) return launch_fl_win1k<T, 7>(a, stream);
     if (a.variant != 1) {  // sliding-window form for the small filter sizes (variant 1: A/B, the row-segment form)
         switch (a.plan.fs) {
             case 5: return launch_fl_win<T, 5>(a, stream);

@@ -104,7 +104,7 @@ def test_full_size_batch(gpu_pkg, O):
                          stream=stream.cuda_stream)
         stream.synchronize()
         if mode == 0:
-            assert f.last_kernel(0) == "ewa_framelane_win_kernel", f.last_kernel(0)
+            assert f.last_kernel(0) == "ewa_framelane_win1k_kernel", f.last_kernel(0)  # 1024 threads, 32 x 32 tiles
         outs.append(dst[:, :, :tw].cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     for k in (0, 31, 64, 68):
