@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rebuilds profiles/traffic.json (what bench.py copies into roofline.traffic) from the PMC summaries of a round.
 
-usage: make_traffic.py <round-dir> <tag>     e.g.  make_traffic.py round2 r2t  -> reads profiles/round2/r2t_c{2,3,4}.json
+usage: make_traffic.py <round-dir> <tag>     e.g.  make_traffic.py round2 r2t  -> reads profiles/round2/r2u_c{2,3,4}.json
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024, separate --pmc passes).  The x2 on the read side is the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the requests are 128 B); round 1
