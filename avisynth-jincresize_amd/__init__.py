@@ -29,6 +29,7 @@ SIMD_ORDER_ISA_PATH = os.path.join(_HERE, "lib", "kernel_simdorder-gfx950.s")  #
 ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_periodic", "kernel_direct", "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
                        "kernel_quasi_exact_fs9", "kernel_quasi_lane_fs7", "kernel_quasi_lane_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
+TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip_test.h")  # introspection, knobs, hooks
 
 
 def build(jobs: int = 6) -> str:

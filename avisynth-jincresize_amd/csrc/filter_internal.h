@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/jincresize_hip.h"
+#include "../../include/jincresize_hip_test.h"
 #include "jinc_lut.h"
 #include "kernels.h"
 #include "plan.h"

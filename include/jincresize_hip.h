@@ -207,58 +207,6 @@ JINC_API const char *jinc_batch_last_error(void);
  * (ref :1007-1029), plus tap = taps (3, 4, 6 or 8; ref :1037).  Everything else stays undefined. */
 JINC_API int jinc_alias_args(int taps, const jinc_args *alias_in, jinc_args *out);
 
-/* ---- Plan introspection (tests, tools, benchmarks) -------------------------------------------- */
-typedef struct jinc_plan_info {
-    int src_width, src_height, dst_width, dst_height;
-    int filter_size;      /* ref :356 */
-    int num_sets;         /* distinct coefficient sets kept (the reference keeps one per border pixel) */
-    int periodic;         /* 1 when the interior was recognised as phase-periodic (fast kernel) */
-    int period_x, period_y;   /* output-pixel period of the interior phase pattern */
-    int step_x, step_y;       /* source-pixel advance per period */
-    int interior_x0, interior_x1, interior_y0, interior_y1; /* half-open interior rectangle */
-    int64_t plan_bytes;   /* bytes of the device-resident plan for this table */
-    int quasi;            /* 1 when the window origins are affine per residue (quasi-periodic kernel applies) */
-    int quasi_period_x, quasi_period_y, quasi_step_x, quasi_step_y;
-} jinc_plan_info;
-
-/* table: 0 = luma / all planes, 1 = chroma table of subsampled formats (ref :552-558). */
-JINC_API int jinc_filter_num_tables(const jinc_filter *f);
-JINC_API int jinc_filter_plan_info(const jinc_filter *f, int table, jinc_plan_info *out);
-/* Expands the compact plan back to the reference's per-pixel view for output pixel (x, y):
- * start_x/start_y (EWAPixelCoeffMeta, JincResize.h:11-16) and the filter_size^2 coefficients
- * (row-major, no stride padding) that pixel uses.  coeffs may be NULL. */
-JINC_API int jinc_filter_plan_pixel(const jinc_filter *f, int table, int x, int y, int *start_x, int *start_y,
-                                    float *coeffs);
-/* Bulk form: fills start_x[dst_w], start_y[dst_h] and set_id[dst_h*dst_w]; any pointer may be NULL. */
-JINC_API int jinc_filter_plan_dump(const jinc_filter *f, int table, int *start_x, int *start_y, int *set_id);
-/* Copies the coefficient set `set` (filter_size^2 floats). */
-JINC_API int jinc_filter_plan_set(const jinc_filter *f, int table, int set, float *coeffs);
-/* The 1024-entry LUT (ref :265-275) as doubles. */
-JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
-
-/* Kernel selection override for tests/benchmarks: 0 = automatic, 1 = force the generic gather
- * kernel for every pixel, 2 = periodic fast kernel where the plan allows (same as automatic),
- * 3..6 = A/B variants of the periodic kernels (row-streamed, other tile heights, packed math),
- * 7 = the quasi-periodic kernel wherever it applies (it is the automatic choice only for drifting ratios),
- * 8 = its waterfall variant (coefficient sets in SGPRs, one pass per distinct set of a wave) and 10 = its per-lane
- * coefficient variant (the default for drifting ratios) on every plan they apply to, 9 = the direct (no-LDS) periodic kernel wherever
- * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8), 11 = the frame-lane kernel
- * (lanes of a wave = frames of the batch; the automatic choice for batches of >= 16 frames whose plan has no phase
- * structure) for every plan and batch size. */
-JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
-/* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
-JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);
-/* Name of the kernel that computed the interior of `table` in the most recent frame call (the choice depends on the
- * batch size: the frame-lane kernel needs a batch). "" before the first call. */
-JINC_API const char *jinc_filter_last_kernel(const jinc_filter *f, int table);
-/* Border frame of exactly periodic plans: 1 (default) = rows and columns on the strip kernels, corners on the
- * gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel; 0 = everything on the
- * gather kernel (A/B measurements, tests). */
-JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
-/* 1 or -1 (default): the border kernels run on a side stream concurrently with the interior kernel
- * (fork/join by events around every call); 0: all on the caller's stream, back to back. */
-JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
-
 /* Compatibility modes for users who diff against the reference's SIMD output: 1 / 2 / 3 reproduce
  * the summation order of its opt = 1 (SSE4.1: 4 lane-partial sums, multiply + add), opt = 2 (AVX2: 8 partial sums, FMA)
  * and opt = 3 (AVX-512: 16 partial sums, FMA) paths bit for bit -- horizontal-sum tree, cvtps_epi32 + packus saturation
@@ -267,24 +215,8 @@ JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
  * A private switch: the public `opt` argument does not select it.  Slow path (no LDS staging). */
 JINC_API int jinc_filter_set_simd_order(jinc_filter *f, int order);
 
-/* Test hook: runs the kernels' own sum -> sample conversion (clamp to [0, peak], round-half-even, store;
- * ref :581-584) on `n` caller-supplied fp32 sums on device `device` and returns the samples
- * (sample_bytes 1, 2 or 4).  Lets tests probe ties, bounds, NaN and infinities directly. */
-JINC_API int jinc_debug_convert(const float *sums, void *out, int n, int sample_bytes, float peak, int device);
-
-/* Test hook: 1 when the device's buffer range check covers the scalar offset of buffer loads (the premise of the
- * direct kernel's bounded segment fetches; probed once per device, the direct kernel is not used where it fails), 0 when
- * it does not, negative status when the probe could not run. */
-JINC_API int jinc_debug_buffer_range_check(int device);
-
-/* ---- Kernel timing (benchmarks) ---------------------------------------------------------------
- * When enabled, every kernel launch made by jinc_filter_get_frame / jinc_filter_process_device is
- * bracketed by a pair of hipEvents recorded on the launch stream.  jinc_filter_kernel_times waits
- * for the recorded events, returns the accumulated device time (milliseconds) and launch count
- * of the periodic-interior kernel and of the gather kernel since the last call, and resets them. */
-JINC_API int jinc_filter_set_profiling(jinc_filter *f, int enable);
-JINC_API int jinc_filter_kernel_times(jinc_filter *f, double *periodic_ms, int *periodic_launches,
-                                      double *gather_ms, int *gather_launches);
+/* Plan introspection, kernel-selection knobs for A/B measurements, test hooks and kernel timing live in
+ * jincresize_hip_test.h: they are exported by the same library but are not part of the drop-in boundary. */
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 #include <cstdio>
 #include <vector>
-#include "jincresize_hip.h"
+#include "jincresize_hip_test.h"
 int main() {
     struct Case { int sw, sh, tw, th, tap, bits, comp, planes, subw, subh; double left, top, w, h; unsigned def; };
     std::vector<Case> cases = {
