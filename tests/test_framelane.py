@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_planes_equal, oracle_kwargs
-from test_gpu_parity import SMALL_CASES, _id
+from test_gpu_parity import SMALL_CASES, _id, _random_case, _random_case_v2, _random_case_v3, _SWEEP
 
 pytestmark = pytest.mark.gpu
 
@@ -136,4 +136,51 @@ def test_unaligned_destination_takes_the_sample_stores(gpu_pkg, O):
             assert np.array_equal(body[k, :, :tw], want), f"pitch {pitch} offset {offset} frame {k}"
         assert (body[:, :, tw:] == 0xAB).all(), "padding between rows was written"
         assert (out[:offset] == 0xAB).all() and (out[offset + n * th * pitch:] == 0xAB).all()
+    f.close()
+
+
+@pytest.mark.parametrize("seed", range(_SWEEP))
+@pytest.mark.parametrize("gen", [1, 2, 3], ids=["small", "structured", "extreme"])
+def test_randomised_arguments_through_the_framelane_kernel(gpu_pkg, O, seed, gen):
+    """The seeded sweeps of test_gpu_parity.py (formats, ratios, taps, quantisation, blur, crops, chroma siting, extreme
+    geometry) with the frame-lane kernel forced: a single frame through jinc_filter_get_frame, and for every fourth seed a
+    device-resident batch of three distinct frames (lanes 0..2 of a wave)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(1000 * gen + seed)
+    fmt, sw, sh, tw, th, kw = {1: _random_case, 2: _random_case_v2, 3: _random_case_v3}[gen](rng)
+    try:
+        of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    except Exception:
+        pytest.skip("oracle rejects this geometry")
+    try:
+        f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    except gpu_pkg.JincError as e:
+        assert "smaller than the filter footprint" in str(e)
+        return
+    f.set_kernel_mode(11)
+    what = f"gen {gen} seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}"
+    frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=seed + 7 * k) for k in range(3 if seed % 4 == 0 else 1)]
+    wants = [of.get_frame(fr, threads=4) for fr in frames]
+    assert_planes_equal(f.get_frame(frames[0]), wants[0], f.out_dims(), what=what)
+    if len(frames) > 1:
+        gfmt = gpu_pkg.FORMATS[fmt]
+        np_dtype = frames[0][0].dtype
+        sb = np.dtype(np_dtype).itemsize
+        tdtype = {1: torch.uint8, 2: torch.int16, 4: torch.float32}[sb]
+        n = len(frames)
+
+        def to_t(a):
+            a = np.ascontiguousarray(a)
+            return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
+
+        src_t = [torch.stack([to_t(fr[i]) for fr in frames]).cuda() for i in range(gfmt.planes)]
+        dst_t = [torch.zeros((n, h, (w * sb + 63) // 64 * 64 // sb), dtype=tdtype, device="cuda") for (w, h) in f.out_dims()]
+        stream = torch.cuda.current_stream()
+        f.process_device([t.data_ptr() for t in src_t], [t.stride(1) * sb for t in src_t], [t.stride(0) * sb for t in src_t],
+                         [t.data_ptr() for t in dst_t], [t.stride(1) * sb for t in dst_t], [t.stride(0) * sb for t in dst_t],
+                         n, stream=stream.cuda_stream)
+        stream.synchronize()
+        for k in range(n):
+            got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
+            assert_planes_equal(got, wants[k], f.out_dims(), what=what + f" batch frame {k}")
     f.close()
