@@ -39,11 +39,11 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         if (wants_periodic(t)) return false;
         // Drifting plans with many phases (DVD -> 1080p: 8 x 9) leave the quasi-periodic kernel little to share per phase:
         // measured at 64 frames 33 % of the VALU peak against 46 % here; with few phases (1.5x, 3x: 9) it stays ahead.
-        // With a source step of 2 and fs 7 (1.5x) full frame groups are ahead too: 54 % against 52 %.
+        // With a source step of 2 (1.5x) full frame groups are ahead too: fs 7 54 % against 52 %, fs 9 46 % against 34 %.
         if (wants_quasi(t)) {
             if (f.plans[f.table_of_plane(i)].periodic) return false;
             if (t.quasi.px * t.quasi.py > 16 && nframes >= 48) return true;
-            return t.plan.fs == 7 && t.quasi.sx >= 2 && t.quasi.sy >= 2 && nframes >= 64;
+            return (t.plan.fs == 7 || t.plan.fs == 9) && t.quasi.sx >= 2 && t.quasi.sy >= 2 && nframes >= 64;
         }
         return !wants_direct(t, i);
     };

@@ -535,6 +535,9 @@ int launch_fl_fs(const FrameLaneArgs& a, hipStream_t stream) {
     }
     switch (a.plan.fs) {
         case 7: return launch_fl_t<T, 7, 4>(a, stream);
+        case 9: return launch_fl_t<T, 9, 4>(a, stream);
+        case 10: return launch_fl_t<T, 10, 4>(a, stream);
+        case 13: return launch_fl_t<T, 13, 4>(a, stream);
         case 17: return launch_fl_t<T, 17, 4>(a, stream);
         default: return launch_fl_t<T, 0, 4>(a, stream);
     }
