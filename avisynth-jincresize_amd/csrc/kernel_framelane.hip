@@ -26,6 +26,8 @@
 //     compile-time constants whatever the geometry -- only scalar addresses and wave-uniform branches are run-time.
 //   * The 4 horizontally adjacent results of a lane are packed and stored with one 4-sample store per row (a lane
 //     writes to its own frame: 64 different cache lines per store instruction, so bytes per store matter).
+#include <atomic>
+
 #include "device_common.hpp"
 
 #pragma clang fp contract(off)
@@ -508,12 +510,15 @@ int launch_fl_win(const FrameLaneArgs& a, hipStream_t stream) {
 
 template <typename T, int FS>
 int launch_fl_win1k(const FrameLaneArgs& a, hipStream_t stream) {
-    static bool attr_set = false;  // dynamic LDS beyond 64 KB needs the attribute once per kernel
-    if (!attr_set) {
+    // dynamic LDS beyond 64 KB needs the attribute once per kernel AND device (a process may drive several: jinc_batch_*)
+    static std::atomic<bool> attr_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return static_cast<int>(hipGetLastError());
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ewa_framelane_win1k_kernel<T, FS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 80 * 1024) != hipSuccess)
             return static_cast<int>(hipGetLastError());
-        attr_set = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true);
     }
     const int ntiles = a.block_begin[4];
     dim3 grid(static_cast<unsigned>((ntiles + 7) / 8) * 8u, static_cast<unsigned>((a.io.nframes + 63) / 64), 1), block(1024, 1, 1);
