@@ -31,6 +31,9 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     bool big = p.fs == 7;
     if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
     if (big) budget = 80 * 1024;
+    // the row-segment form (fs > 9: 80 VGPRs, 6 waves per SIMD) gains more from a third workgroup per CU than it loses to the
+    // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
+    if (p.fs > 9) budget = 48 * 1024;
     if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
     budget = std::min<size_t>(budget, big ? 80 * 1024 : 64 * 1024);
     const int groups = std::max(1, (nframes_hint + 63) / 64);
