@@ -26,7 +26,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JINC_LIB") or os.path.join(_HERE, "lib", "libjincresize_hip.so")  # JINC_LIB: A/B runs against another build
 SIMD_ORDER_ISA_PATH = os.path.join(_HERE, "lib", "kernel_simdorder-gfx950.s")  # the one unit with (explicit) fused multiply-adds
-ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_periodic", "kernel_direct", "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
+ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_periodic", "kernel_direct", *[f"kernel_direct_walk_{t}_sx{x}" for t in ("u8", "u16", "f32") for x in (1, 2, 3, 4)], "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
                        "kernel_quasi_exact_fs9", "kernel_quasi_lane_fs7", "kernel_quasi_lane_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
 TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip_test.h")  # introspection, knobs, hooks
@@ -80,7 +80,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
 
@@ -132,6 +132,7 @@ def lib():
         L.jinc_filter_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                                C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.jinc_debug_buffer_range_check.argtypes = [C.c_int]
+        L.jinc_debug_set_direct_shape.argtypes = [C.c_int]
         L.jinc_filter_set_simd_order.argtypes = [C.c_void_p, C.c_int]
         L.jinc_shard_device.argtypes = [C.c_int, C.c_int]
         L.jinc_batch_create.argtypes = [C.POINTER(VideoInfo), C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
@@ -148,6 +149,19 @@ def lib():
 
 def device_count() -> int:
     return int(lib().jinc_device_count())
+
+
+def set_direct_shape(shape: int) -> None:
+    """Process-wide A/B knob of ewa_direct_kernel's interior form (test hook): 0 per-chain fetches, 2 row walk, 3 row walk
+    with 8 columns per lane (where it applies), -1 automatic."""
+    rc = lib().jinc_debug_set_direct_shape(int(shape))
+    if rc != 0:
+        raise JincError(rc, lib().jinc_last_error().decode())
+
+
+def last_direct_shape() -> int:
+    """Interior form of the most recent ewa_direct_kernel interior launch in this process (test hook)."""
+    return int(lib().jinc_debug_last_direct_shape())
 
 
 def debug_convert(sums: np.ndarray, dtype, peak: float, device: int = 0) -> np.ndarray:

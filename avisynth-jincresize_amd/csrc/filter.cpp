@@ -370,6 +370,14 @@ int jinc_debug_buffer_range_check(int device) {
     return r;
 }
 
+int jinc_debug_set_direct_shape(int shape) {
+    if (shape != -1 && shape != 0 && shape != 2 && shape != 3) return fail(JINC_ERR_INVALID_ARG, "JincResize: direct shape must be -1, 0, 2 or 3.");
+    jinc::set_direct_shape(shape);
+    return JINC_OK;
+}
+
+int jinc_debug_last_direct_shape(void) { return jinc::last_direct_shape(); }
+
 const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {
     if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return "";
     return f->tables[table].last_kernel;

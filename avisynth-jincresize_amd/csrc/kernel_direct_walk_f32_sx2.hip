@@ -1,0 +1,5 @@
+// kernel_direct_walk_f32_sx2.hip -- see kernel_direct_walk.inc
+#define JINC_DIRECT_WALK_T float
+#define JINC_DIRECT_WALK_SX 2
+#define JINC_DIRECT_WALK_NAME launch_direct_walk_f32_sx2
+#include "kernel_direct_walk.inc"

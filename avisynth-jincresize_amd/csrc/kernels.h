@@ -143,6 +143,22 @@ bool direct_supported(int fs, int px, int py, int sx, int sy);
 // 2 * nbytes bytes with dword i = i, `out` 128 dwords.  See load_raw in kernel_direct.hip.
 int launch_soffset_probe(const uint32_t* buf, uint32_t nbytes, uint32_t* out, void* stream);
 int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream);
+// Interior form launch_direct picks (kernel_direct_impl.inc DirectShape: 0 per-chain fetches, 2 row walk, 3 row walk with 8
+// columns per lane); set_direct_shape forces one process-wide where it applies (tests, A/B runs; -1 = automatic),
+// last_direct_shape reports the most recent launch's.
+void set_direct_shape(int shape);
+int last_direct_shape();
+// row-walk interior forms (DirectShape 2 / 3), one translation unit per sample type and source step
+// (kernel_direct_walk_*_sx*.hip)
+#define JINC_DECLARE_DIRECT_WALK(tag)                                                            \
+    int launch_direct_walk_##tag##_sx1(const DirectArgs&, const PlaneIO&, void* stream, int shape); \
+    int launch_direct_walk_##tag##_sx2(const DirectArgs&, const PlaneIO&, void* stream, int shape); \
+    int launch_direct_walk_##tag##_sx3(const DirectArgs&, const PlaneIO&, void* stream, int shape); \
+    int launch_direct_walk_##tag##_sx4(const DirectArgs&, const PlaneIO&, void* stream, int shape);
+JINC_DECLARE_DIRECT_WALK(u8)
+JINC_DECLARE_DIRECT_WALK(u16)
+JINC_DECLARE_DIRECT_WALK(f32)
+#undef JINC_DECLARE_DIRECT_WALK
 int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream);
 
 // Left / right border columns of an exactly periodic plan over the interior's row range (kernel_colstrip.hip):

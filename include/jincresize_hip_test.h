@@ -74,6 +74,11 @@ JINC_API int jinc_debug_convert(const float *sums, void *out, int n, int sample_
  * direct kernel's bounded segment fetches; probed once per device, the direct kernel is not used where it fails), 0 when
  * it does not, negative status when the probe could not run. */
 JINC_API int jinc_debug_buffer_range_check(int device);
+/* Process-wide A/B knob of the direct kernel's interior form (avisynth-jincresize_amd/csrc/kernel_direct_impl.inc,
+ * DirectShape): 0 per-chain fetches, 2 row walk, 3 row walk with 8 columns per lane (where it applies), -1 automatic. */
+JINC_API int jinc_debug_set_direct_shape(int shape);
+/* DirectShape of the most recent interior launch of the direct kernel in this process (-1: none yet). */
+JINC_API int jinc_debug_last_direct_shape(void);
 
 /* ---- Kernel timing (benchmarks) ---------------------------------------------------------------
  * When enabled, every kernel launch made by jinc_filter_get_frame / jinc_filter_process_device is

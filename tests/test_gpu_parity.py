@@ -384,6 +384,77 @@ def test_direct_periodic_kernel(gpu_pkg, O, case, mode):
     f.close()
 
 
+# Interior forms of ewa_direct_kernel (kernel_direct_impl.inc DirectShape): every filter size the row walk's two loops
+# meet -- single-step rows (fs 9..16) at source steps 2..4, equal steps with a last step of nta, nta-1 and nta-2 taps --
+# for the three sample sizes, with ragged last chunks (rows % 4 != 0) and phases that start at every byte shift.
+WALK_CASES = [
+    ("Y8", 388, 218, 194, 109, dict(tap=2)),              # 1/2: fs 9
+    ("Y16", 388, 218, 194, 109, {}),                      # fs 13
+    ("Y32", 300, 210, 200, 140, {}),                      # 2/3: fs 10, period 2
+    ("Y8", 303, 213, 202, 142, dict(tap=4)),              # 2/3: fs 13
+    ("Y16", 306, 216, 204, 144, dict(tap=5)),             # 2/3: fs 16
+    ("Y8", 402, 222, 134, 74, dict(tap=2)),               # 1/3: fs 14
+    ("Y32", 402, 222, 134, 74, dict(tap=2)),
+    ("Y8", 404, 220, 101, 55, dict(tap=1)),               # 1/4 tap 1: fs 10 at source step 4
+    ("Y16", 400, 300, 100, 100, dict(tap=1)),             # 1/4 x 1/3
+    ("Y32", 400, 300, 200, 75, dict(tap=1)),              # 1/2 x 1/4: single-step rows, row step 4
+    ("Y8", 388, 218, 194, 109, dict(tap=4)),              # 1/2: fs 17 = 9 + 8
+    ("Y32", 388, 218, 194, 109, dict(tap=5)),             # fs 21 = 11 + 10
+    ("Y16", 402, 222, 134, 74, dict(tap=4)),              # 1/3: fs 26 = 13 + 13
+    ("Y8", 402, 222, 134, 74, dict(tap=6)),               # fs 39 = 13 * 3
+    ("Y8", 404, 220, 101, 55, dict(tap=4)),               # 1/4: fs 34 = 12 + 12 + 10
+    ("Y16", 404, 220, 101, 55, dict(tap=5)),              # fs 42 = 14 * 3
+    ("Y8", 404, 220, 101, 55, dict(tap=6)),               # fs 50: outside the walk, shape 0
+    ("Y8", 150, 110, 300, 220, dict(tap=9)),              # 2x tap 9: fs 19 = 10 + 9, source step 1
+    ("Y32", 150, 110, 300, 220, dict(tap=11)),            # fs 23 = 12 + 11
+    ("YUV420P8", 516, 292, 258, 146, {}),                 # luma and chroma tables
+]
+
+
+@pytest.mark.parametrize("shape", [0, 2, 3], ids=["per_chain", "walk", "walk_wide"])
+@pytest.mark.parametrize("case", WALK_CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}_{c[5].get('tap', 3)}")
+def test_direct_kernel_interior_forms(gpu_pkg, O, case, shape):
+    fmt, sw, sh, tw, th, kw = case
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    n = 3
+    frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=4242 + i) for i in range(n)]
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    assert f.plan_info().periodic == 1
+    gpu_pkg.set_direct_shape(shape)
+    try:
+        f.set_kernel_mode(9)
+        got = [f.get_frame(fr) for fr in frames]
+    finally:
+        gpu_pkg.set_direct_shape(-1)
+    assert f.last_kernel(0) == "ewa_direct_kernel"
+    assert gpu_pkg.last_direct_shape() in ((0,) if shape == 0 else (0, 2) if shape == 2 else (0, 2, 3))
+    for i in range(n):
+        assert_planes_equal(got[i], of.get_frame(frames[i], threads=4), f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th} shape {shape} frame {i}")
+    f.close()
+
+
+def test_direct_kernel_wide_walk_on_a_batch(gpu_pkg, O):
+    """The automatic choice takes the 8-column walk for 8-bit batches that fill the device: 4K -> 1080p, 6 frames; every frame
+    against the oracle's crc of the same frame."""
+    torch = pytest.importorskip("torch")
+    import zlib
+    fmt, sw, sh, tw, th, n = "Y8", 3840, 2160, 1920, 1080, 8
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=77 + i) for i in range(n)]
+    src = torch.from_numpy(np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])).cuda().contiguous()
+    dst = torch.zeros((n, th, tw), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+    f.process_device([src.data_ptr()], [sw], [sw * sh], [dst.data_ptr()], [tw], [tw * th], n, stream=stream.cuda_stream)
+    stream.synchronize()
+    assert gpu_pkg.last_direct_shape() == 3
+    out = dst.cpu().numpy()
+    for i in (0, n - 1):
+        want = of.get_frame(frames[i], threads=8)
+        assert zlib.crc32(out[i].tobytes()) == zlib.crc32(np.ascontiguousarray(want[0][:th, :tw]).tobytes()), f"frame {i}"
+    f.close()
+
+
 @pytest.mark.parametrize("sw", [200, 202], ids=["pitch200", "pitch202_not_multiple_of_4"])
 def test_direct_kernel_tight_pitch_device_batch(gpu_pkg, O, sw):
     """Device entry with pitch == row size (no padding at all) and a batch of frames: the direct kernel fetches
