@@ -53,8 +53,12 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
         for (int ly = 0; ly < p.fs; ++ly)
             std::memcpy(&padded[(static_cast<size_t>(s) * p.fs + ly) * fsp], p.set_ptr(s) + static_cast<size_t>(ly) * p.fs,
                         sizeof(float) * p.fs);
+    // slack around the coefficient array: the direct kernel fetches whole coefficient blocks (<= 16 floats), its row walk
+    // coefficient rows of the neighbouring sets (kDirectCoeffSlackRows, never used)
+    const size_t slack = static_cast<size_t>(jinc::kDirectCoeffSlackRows) * fsp * sizeof(float) + 256;
+    off = align_up(off, 256) + slack;
     const size_t i_co = add(padded.data(), padded.size() * 4);
-    t.bytes = align_up(off, 256) + 256;  // slack: kernel_direct.hip fetches whole coefficient blocks (<= 16 floats)
+    t.bytes = align_up(off, 256) + slack;
     hip_check(hipMalloc(&t.blob, t.bytes), "hipMalloc(plan)");
     char* base = static_cast<char*>(t.blob);
     for (const Piece& pc : pieces)

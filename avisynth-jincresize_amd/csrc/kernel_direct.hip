@@ -28,11 +28,8 @@ int launch_direct_mode(const DirectArgs& args, const PlaneIO& io, hipStream_t s)
     }
 }
 
-// Lanes a shape launches per lane that owns chains (columns only; rows cost whole waves in every shape).
-inline int direct_lane_slots(int ni, int k) { return (ni + 64 * k - 1) / (64 * k) * 64 * k; }
-
 // Interior shape of a launch (DirectShape): row walk where its step scheme covers the filter size; 8 columns per lane
-// for 8-bit down-scales where that leaves no more lanes idle than 4 and still fills the device with waves.  JINC_DIRECT_SHAPE = 0 / 2 / 3
+// for 8-bit down-scales where that still fills the device with waves.  JINC_DIRECT_SHAPE = 0 / 2 / 3
 // forces one (A/B runs).
 std::atomic<int> g_last_shape{-1};    // shape of the most recent interior launch (test hook)
 std::atomic<int> g_forced_shape{-2};  // -2: not read yet, -1: automatic, 0 / 2 / 3: forced (set_direct_shape, JINC_DIRECT_SHAPE)
@@ -47,10 +44,10 @@ int interior_shape(const DirectArgs& da, const PlaneIO& io) {
     if (!walk_supported(da.fs) || forced == 0) return 0;
     if (!walk_wide_supported(da.fs, da.sx)) return 2;
     if (forced == 2 || forced == 3) return forced;
-    const long long waves8 = static_cast<long long>((da.ni + 511) / 512) * ((da.nj + 3) / 4) * da.px * da.py * io.nframes;
+    const long long waves8 = (static_cast<long long>((da.ni + 7) / 8) * ((da.nj + 3) / 4) + 63) / 64 * da.px * da.py * io.nframes;
     // 8-bit only: 16-bit and float planes hold too many raw words per lane at 8 columns (measured 4K -> 1080p:
     // 8-bit 146 against 138 Gpix/s, 16-bit 71 against 73, float 31 against 35)
-    const bool wide = io.sample_bytes == 1 && direct_lane_slots(da.ni, 8) <= direct_lane_slots(da.ni, 4) && waves8 >= 8192;
+    const bool wide = io.sample_bytes == 1 && waves8 >= 6144;  // one full residency of the device (6 waves per SIMD)
     return wide ? 3 : 2;
 }
 

@@ -126,6 +126,9 @@ int launch_quasi(const QuasiArgs& args, int fs, const PlaneIO& io, void* stream)
 //               (start_x[p] + sx*i, start_y[q] + sy*j) with coefficient set set[q*px + p];
 //   row strips: the output rows line0[k] .. line0[k]+line_n[k]-1 (k = 0, 1: above / below the interior) over the
 //               interior's column range; window row and coefficient set come from the plan tables per row and phase.
+// The row walk of kernel_direct_impl.inc loads coefficient rows up to this many rows before / after a set without using
+// them ((R-1) * sy = 3 * 4); upload_table keeps that much addressable memory around the coefficient array.
+constexpr int kDirectCoeffSlackRows = 12;
 struct DirectArgs {
     const float* coeffs = nullptr;
     int fs = 0, coeff_row = 0;   // filter size; floats per coefficient row on the device (padded_row(fs))
