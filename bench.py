@@ -60,6 +60,8 @@ CONFIGS = {
     "D12H": ("YUV420P16", 3840, 2160, 1920, 1080, dict(tap=3), 16),  # 4K 16-bit 4:2:0 -> 1080p
     "D12F": ("RGBPS", 3840, 2160, 1920, 1080, dict(tap=3), 8),       # 4K float RGB -> 1080p
     "D13": ("Y8", 3840, 2160, 1280, 720, dict(tap=3), 32),    # 1/3 down-scale: fs = 20, period 1, source step 3
+    "D12T4": ("Y8", 3840, 2160, 1920, 1080, dict(tap=4), 16),   # Jinc64 at 1/2: fs = 17 (9 + 8 taps per kernel row)
+    "D12T8": ("Y8", 3840, 2160, 1920, 1080, dict(tap=8), 8),    # Jinc256 at 1/2: fs = 33 (3 x 11)
     "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 16),    # Jinc144: fs = 13
     "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 4),   # tap 16: fs = 33 (1089 taps)
 }

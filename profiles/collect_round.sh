@@ -18,7 +18,7 @@ for c in C2 C3 C4; do
   tail -1 gpurun_out/${tag}_stats_$c.log > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_$c.json
 done
 cp profiles/$JINC_PROFILE_DIR/${tag}_* gpurun_out/$JINC_PROFILE_DIR/ 2>/dev/null
-for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D169 T6 T16 N15T8 A137 A1875; do
+for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875; do
   timeout 120 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
   python profiles/bench_line.py < gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
 done
