@@ -453,6 +453,9 @@ void init_device(jinc_filter& f, int device) {
         f.tables[i].use_framelane =
             jinc::framelane_configure(f.plans[i], f.tables[i].whole, f.vi_in.component_size, 64, f.tables[i].fl_whole);
         f.tables[i].fl_whole.plan = f.tables[i].plan;
+        f.tables[i].use_framelane_pair = f.tables[i].use_framelane &&
+            jinc::framelane_pair_configure(f.plans[i], f.tables[i].whole, f.vi_in.component_size, 128, f.tables[i].fl_pair);
+        f.tables[i].fl_pair.plan = f.tables[i].plan;
     }
 }
 

@@ -33,7 +33,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     // it for every plan and batch size.
     auto wants_framelane = [&](const DeviceTable& t, int i) {
         if (!t.use_framelane || f.kernel_mode == 1) return false;
-        if (f.kernel_mode == 11) return true;
+        if (f.kernel_mode == 11 || (f.kernel_mode == 12 && t.use_framelane_pair)) return true;
         if (f.kernel_mode != 0) return false;
         if (nframes < kFrameLaneMinFrames) return false;
         if (wants_periodic(t)) return false;
@@ -105,15 +105,43 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             continue;
         }
         if (wants_framelane(t, i)) {
-            jinc::FrameLaneArgs fa = t.fl_whole;
-            fa.io = io;
             const uintptr_t vec = static_cast<uintptr_t>(4 * sb);
-            fa.vec_store_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
-                              (nframes <= 1 || io.dst_frame_stride % vec == 0);
-            t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
-                            : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
-                                ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
-            timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            const int vec_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
+                               (nframes <= 1 || io.dst_frame_stride % vec == 0);
+            // Whole groups of 128 frames of plans with many coefficient sets go to the frame-pair form (two frames per lane:
+            // half the per-pixel coefficient traffic and scalar work, packed multiplies / adds): measured at 256 frames
+            // 1.37x 47 % of the VALU peak against 42 %, DVD -> 1080p (72 phases) 52 % against 49 %, 15 / 8 (period 15)
+            // equal; drifting plans with few phases (1.5x) reuse their sets out of the scalar cache and lose 3 % to the
+            // smaller tiles, so they stay on the 64-frame form, which also takes what is left of a batch and every batch
+            // below 128 frames.  kernel_mode 12 (tests, A/B): the frame-pair form for the whole batch.
+            int npair = 0;
+            if (t.use_framelane_pair && f.kernel_mode != 11) {
+                const bool many_sets = !wants_quasi(t) || t.quasi.px * t.quasi.py > 16;
+                npair = f.kernel_mode == 12 ? nframes
+                        : many_sets         ? nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames
+                                            : 0;
+            }
+            if (npair > 0) {
+                jinc::FrameLaneArgs fa = t.fl_pair;
+                fa.io = io;
+                fa.io.nframes = npair;
+                fa.vec_store_ok = vec_ok;
+                t.last_kernel = "ewa_framelane_pair_kernel";
+                timed(f.ev_periodic, stream, "frame-pair kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_pair(fa, s); });
+            }
+            if (npair < nframes) {
+                jinc::FrameLaneArgs fa = t.fl_whole;
+                fa.io = io;
+                fa.io.src = static_cast<const char*>(io.src) + static_cast<size_t>(npair) * io.src_frame_stride;
+                fa.io.dst = static_cast<char*>(io.dst) + static_cast<size_t>(npair) * io.dst_frame_stride;
+                fa.io.nframes = nframes - npair;
+                fa.vec_store_ok = vec_ok;
+                if (npair == 0)
+                    t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
+                                    : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
+                                        ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
+                timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            }
             continue;
         }
         const bool direct = wants_direct(t, i);

@@ -59,6 +59,8 @@ struct DeviceTable {
     jinc::RectList whole;         // gather work when it does not
     bool use_framelane = false;   // frame-lane kernel configured for the whole plane (batches of frames, any plan)
     jinc::FrameLaneArgs fl_whole;
+    bool use_framelane_pair = false;  // ... and its frame-pair form (128 frames per workgroup; filter sizes 5 and 7)
+    jinc::FrameLaneArgs fl_pair;
     const char* last_kernel = "";  // interior kernel of the most recent call (reports)
 };
 

@@ -20,23 +20,14 @@ int max_extent(const std::vector<int32_t>& start, int i0, int i1, int t, int fs)
 }
 }  // namespace
 
-bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out) {
-    const int ps = kFrameLanePosBytes(static_cast<size_t>(sample_bytes));
+namespace {
+// Tile choice and rectangle bookkeeping for one frame-lane form: `ps` LDS bytes per source position, `budget` bytes of LDS
+// per workgroup, `frames_per_group` frames per workgroup; `col_weight` prices the window columns a strip loads per pixel
+// (wide tiles) against the staged footprint per pixel.
+bool configure_tiles(const PlanePlan& p, const RectList& rects, int ps, size_t budget, int frames_per_group, int nframes_hint,
+                     double col_weight, FrameLaneArgs& out) {
     const int table_bytes = (2 * kFrameLaneMaxTile + kFrameLaneMaxTile * kFrameLaneMaxTile) * 4;
-    // LDS per workgroup: a larger tile has less halo (fewer staged samples per output pixel), a smaller one lets more
-    // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
-    size_t budget = 64 * 1024;  // A/B (64 frames): 1.37x fs 7 48 KB = 64 KB; 5/6 down-scale fs 8 +28 % over 48 KB
-    // fs 7: the 1024-thread shape of the sliding-window kernel (two workgroups per CU at 64 VGPRs = 8 waves per SIMD) with
-    // tiles of up to 80 KB
-    bool big = p.fs == 7;
-    if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
-    if (big) budget = 80 * 1024;
-    // the row-segment form (fs > 9: 80 VGPRs, 6 waves per SIMD) gains more from a third workgroup per CU than it loses to the
-    // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
-    if (p.fs > 9) budget = 48 * 1024;
-    if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
-    budget = std::min<size_t>(budget, big ? 80 * 1024 : 64 * 1024);
-    const int groups = std::max(1, (nframes_hint + 63) / 64);
+    const int groups = std::max(1, (nframes_hint + frames_per_group - 1) / frames_per_group);
 
     bool found = false, found_enough = false;
     double best_cost = 0.0;
@@ -55,7 +46,7 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
             // (+ 1 row: the sliding-window form pads the column pitch of its column-major tile to an odd number)
             const size_t bytes = table_bytes + (static_cast<size_t>(max_tw) * (max_th + 1) + 8) * ps;
             if (bytes > budget) continue;
-            const double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty);
+            const double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty) + col_weight * max_tw / tx;
             const bool enough = tiles * groups >= 1024;  // >= 2 workgroups in flight per CU, twice over
             if (found && ((found_enough && !enough) || (enough == found_enough && cost >= best_cost))) continue;
             found = true;
@@ -82,13 +73,50 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
         }
     }
     out.block_begin[4] = total;
+    return total > 0;
+}
+}  // namespace
+
+bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out) {
+    const int ps = kFrameLanePosBytes(static_cast<size_t>(sample_bytes));
+    // LDS per workgroup: a larger tile has less halo (fewer staged samples per output pixel), a smaller one lets more
+    // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
+    size_t budget = 64 * 1024;  // A/B (64 frames): 1.37x fs 7 48 KB = 64 KB; 5/6 down-scale fs 8 +28 % over 48 KB
+    // fs 7: the 1024-thread shape of the sliding-window kernel (two workgroups per CU at 64 VGPRs = 8 waves per SIMD) with
+    // tiles of up to 80 KB
+    bool big = p.fs == 7;
+    if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
+    if (big) budget = 80 * 1024;
+    // the row-segment form (fs > 9: 80 VGPRs, 6 waves per SIMD) gains more from a third workgroup per CU than it loses to the
+    // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
+    if (p.fs > 9) budget = 48 * 1024;
+    if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
+    budget = std::min<size_t>(budget, big ? 80 * 1024 : 64 * 1024);
+    if (!configure_tiles(p, rects, ps, budget, 64, nframes_hint, 0.0, out)) return false;
+    const int tx = 1 << out.tx_shift, ty = 1 << out.ty_shift;
     const int units = (tx / 4) * (ty / 4);
     out.threads = 64 * std::min(8, std::max(1, units));
     if (big && units >= 16) out.threads = 1024;  // (small tiles keep the 512-thread shape)
     if (const char* e = std::getenv("JINC_FL_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
     out.variant = 0;
     if (const char* e = std::getenv("JINC_FL_VARIANT")) out.variant = std::atoi(e);  // A/B knob: 1 = row-segment form always
-    return total > 0;
+    out.pair = 0;
+    return true;
+}
+
+// Frame-pair form (kernel_framelane_pair.hip): 128 frames per workgroup in up to 80 KB of LDS (two workgroups per CU).
+bool framelane_pair_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out) {
+    if (p.fs != 5 && p.fs != 7) return false;
+    const int ps = kFrameLanePairPosBytes(static_cast<size_t>(sample_bytes));
+    size_t budget = 80 * 1024;
+    if (const char* e = std::getenv("JINC_FLP_LDS_KB")) budget = std::min<size_t>(budget, static_cast<size_t>(std::atoi(e)) * 1024);  // tuning knob
+    if (!configure_tiles(p, rects, ps, budget, kFrameLanePairFrames, nframes_hint, 0.5, out)) return false;
+    const int ty = 1 << out.ty_shift;
+    out.threads = 64 * std::min(8, ty);  // a wave walks whole strips (output rows of the tile)
+    if (const char* e = std::getenv("JINC_FLP_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
+    out.variant = 0;
+    out.pair = 1;
+    return true;
 }
 
 }  // namespace jinc

@@ -35,39 +35,7 @@
 namespace jinc {
 namespace {
 
-constexpr int kFlTableInts = 2 * kFrameLaneMaxTile + kFrameLaneMaxTile * kFrameLaneMaxTile;
-
-template <typename T>
-struct FlPack;  // four horizontally adjacent samples of one frame
-template <>
-struct FlPack<uint8_t> {
-    using type = uint32_t;
-};
-template <>
-struct FlPack<uint16_t> {
-    using type = uint2;
-};
-template <>
-struct FlPack<float> {
-    using type = float4;
-};
-
-template <typename T>
-__device__ __forceinline__ typename FlPack<T>::type fl_pack(const float (&r)[4], float peak) {
-    if constexpr (std::is_same_v<T, uint8_t>) {
-        uint32_t w = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w = __builtin_amdgcn_cvt_pk_u8_f32(r[i], static_cast<uint32_t>(i), w);
-        return w;
-    } else if constexpr (std::is_same_v<T, uint16_t>) {
-        uint2 w;
-        w.x = round_sample(r[0], peak) | (round_sample(r[1], peak) << 16);
-        w.y = round_sample(r[2], peak) | (round_sample(r[3], peak) << 16);
-        return w;
-    } else {
-        return make_float4(r[0], r[1], r[2], r[3]);
-    }
-}
+#include "kernel_framelane_common.inc"
 
 // One chunk of N <= 8 taps of one source row for the chains KLO..KHI of an output column (all of them hold this source
 // row): samples from the LDS tile (read and converted once), one coefficient row per chain through scalar loads.
@@ -155,103 +123,6 @@ __device__ __forceinline__ void fl_rows_dispatch(int klo, int khi, float (&acc)[
         default: break;
     }
 #undef JINC_FL_ROWS
-}
-
-// Tile of a workgroup and its source footprint (all wave-uniform).
-struct FlTile {
-    int bx0, by0, bx1, by1;  // output pixels, inclusive
-    int tx0, ty0, tw, th;    // source footprint: origin and extent
-    int f0, nfg;             // first frame of the group, frames in it (<= 64)
-};
-
-// block -> tile.  Workgroups are dealt round-robin over the 8 XCDs by linear id; XCD k walks the contiguous run of
-// tiles [k*q + min(k, rem), ...) so that the halos shared by neighbouring tiles stay in one L2.  False: padding block.
-__device__ __forceinline__ bool fl_locate(const FrameLaneArgs& a, int fs, FlTile& t) {
-    const DevicePlan& p = a.plan;
-    const int ntiles = a.block_begin[4];
-    const int q = ntiles / 8, rem = ntiles % 8;
-    const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    if (idx >= q + (xcd < rem ? 1 : 0)) return false;
-    const int tid = xcd * q + (xcd < rem ? xcd : rem) + idx;
-    int r = 0;
-    while (r + 1 < a.rects.n && tid >= a.block_begin[r + 1]) ++r;
-    const int local = tid - a.block_begin[r];
-    const int tcx = local % a.tiles_x[r], tcy = local / a.tiles_x[r];
-    const int rx1 = a.rects.x0[r] + a.rects.w[r], ry1 = a.rects.y0[r] + a.rects.h[r];
-    t.bx0 = a.rects.x0[r] + (tcx << a.tx_shift), t.by0 = a.rects.y0[r] + (tcy << a.ty_shift);
-    t.bx1 = min(t.bx0 + (1 << a.tx_shift), rx1) - 1, t.by1 = min(t.by0 + (1 << a.ty_shift), ry1) - 1;
-    t.tx0 = p.col_start[t.bx0], t.ty0 = p.row_start[t.by0];
-    t.tw = p.col_start[t.bx1] + fs - t.tx0;  // <= 64 (host: framelane_configure)
-    t.th = p.row_start[t.by1] + fs - t.ty0;
-    t.f0 = blockIdx.y * 64;
-    t.nfg = min(64, a.io.nframes - t.f0);
-    return true;
-}
-
-// Per-tile tables in LDS: window origins and the coefficient set of every pixel (looked up once per pixel for 64 frames).
-__device__ __forceinline__ void fl_tables(const FrameLaneArgs& a, const FlTile& t, int* cs, int* rs, int* sets) {
-    const DevicePlan& p = a.plan;
-    for (int i = threadIdx.x; i < (1 << a.tx_shift); i += blockDim.x) cs[i] = p.col_start[min(t.bx0 + i, t.bx1)];
-    for (int i = threadIdx.x; i < (1 << a.ty_shift); i += blockDim.x) rs[i] = p.row_start[min(t.by0 + i, t.by1)];
-    for (int i = threadIdx.x; i < (1 << (a.tx_shift + a.ty_shift)); i += blockDim.x) {
-        const int ix = i & ((1 << a.tx_shift) - 1), iy = i >> a.tx_shift;
-        const int qx = min(t.bx0 + ix, t.bx1), qy = min(t.by0 + iy, t.by1);
-        const int rc = p.row_class[qy], cc = p.col_class[qx];
-        int set;
-        if (rc < 0)
-            set = p.brow_set[static_cast<size_t>(~rc) * p.dst_w + qx];
-        else if (cc < 0)
-            set = p.bcol_set[static_cast<size_t>(~cc) * p.dst_h + qy];
-        else
-            set = p.interior_set[rc * p.n_col_classes + cc];
-        sets[iy * kFrameLaneMaxTile + ix] = set;
-    }
-}
-
-// Stages the source footprint of the group's frames in LDS in the source format, one position per source sample of the
-// tile and 64 frames per position: position (row, col) = row * row_pos + col * col_pos.  Global loads run along the
-// columns of one frame (coalesced), 16 in flight per lane.
-template <typename T>
-__device__ __forceinline__ void fl_stage(const FrameLaneArgs& a, const FlTile& t, char* tile, int row_pos, int col_pos, int lane,
-                                         int wave, int nwaves) {
-    constexpr int PS = kFrameLanePosBytes(sizeof(T));
-    constexpr int SB = static_cast<int>(sizeof(T));
-    const int tw = t.tw, th = t.th;
-    const int sh = tw <= 1 ? 0 : 32 - __builtin_clz(static_cast<unsigned>(tw - 1));  // lanes per row = 1 << sh >= tw
-    const int lc = lane & ((1 << sh) - 1), lr = lane >> sh, rps = 64 >> sh;
-    const int nsteps = (th + rps - 1) >> (6 - sh);
-    const int colc = min(lc, tw - 1);
-    constexpr int U = 16;
-    for (int fi = wave; fi < t.nfg; fi += nwaves) {
-        const char* sframe = static_cast<const char*>(a.io.src) + static_cast<size_t>(t.f0 + fi) * a.io.src_frame_stride +
-                             static_cast<size_t>(t.ty0) * a.io.src_pitch + static_cast<size_t>(t.tx0 + colc) * SB;
-        char* lds_f = tile + fi * SB + lc * col_pos * PS;
-        for (int s0 = 0; s0 < nsteps; s0 += U) {
-            T v[U];
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int row = min((s0 + j) * rps + lr, th - 1);
-                v[j] = *reinterpret_cast<const T*>(sframe + static_cast<size_t>(row) * a.io.src_pitch);
-            }
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int row = (s0 + j) * rps + lr;
-                if (row < th && lc < tw) *reinterpret_cast<T*>(lds_f + row * row_pos * PS) = v[j];
-            }
-        }
-    }
-}
-
-// Stores up to four horizontally adjacent results of a lane's frame: one packed store where the address allows it.
-template <typename T>
-__device__ __forceinline__ void fl_store4(char* d, const float (&res)[4], int nvx, bool vec, float peak) {
-    if (vec) {
-        *reinterpret_cast<typename FlPack<T>::type*>(d) = fl_pack<T>(res, peak);
-    } else {
-#pragma unroll
-        for (int xx = 0; xx < 4; ++xx)
-            if (xx < nvx) store_sample<T>(reinterpret_cast<T*>(d) + xx, res[xx], peak);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -185,6 +185,10 @@ int launch_colstrip(const ColStripArgs& args, const PlaneIO& io, void* stream);
 // pixel of 64 different frames, so coefficients are wave-uniform (SGPRs) whatever the plan's structure.
 constexpr int kFrameLaneMaxTile = 32;  // output tile edge limit
 constexpr int kFrameLanePosBytes(size_t sample_bytes) { return static_cast<int>(64 * sample_bytes + 4); }  // LDS bytes per source position
+// Frame-pair form (kernel_framelane_pair.hip): 128 frames per workgroup, a lane owns two adjacent frames; 8-byte pad for
+// float planes keeps a lane's pair 8-byte aligned at every position.
+constexpr int kFrameLanePairFrames = 128;
+constexpr int kFrameLanePairPosBytes(size_t sample_bytes) { return static_cast<int>(128 * sample_bytes + (sample_bytes == 4 ? 8 : 4)); }
 struct FrameLaneArgs {
     DevicePlan plan;
     PlaneIO io;
@@ -196,12 +200,16 @@ struct FrameLaneArgs {
     int lds_bytes = 0;
     int vec_store_ok = 0;     // destination base, pitch and frame stride are multiples of 4 samples
     int variant = 0;          // 0: automatic (sliding-window form for filter sizes 5, 7, 8, 9), 1: row-segment form always
+    int pair = 0;             // 1: configured for the frame-pair form (128 frames per workgroup)
 };
 // Chooses the tile size for the rectangles `rects` of plane plan `p` (host arrays) so that every tile's source
 // footprint fits the LDS budget and is at most 64 columns wide; false if no tile size fits (huge filter footprints).
 struct PlanePlan;
 bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out);
 int launch_framelane(const FrameLaneArgs& args, void* stream);
+// Frame-pair form: filter sizes 5 and 7 only (two windows per lane in 128 registers); false otherwise or if no tile fits.
+bool framelane_pair_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out);
+int launch_framelane_pair(const FrameLaneArgs& args, void* stream);
 
 // Generic gather kernel: one lane per output pixel, any plan.  Returns a hipError_t value as int.
 int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rects, void* stream);

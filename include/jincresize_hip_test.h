@@ -50,7 +50,9 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * coefficient variant (the default for drifting ratios) on every plan they apply to, 9 = the direct (no-LDS) periodic kernel wherever
  * the plan is exactly periodic (it is the automatic choice for down-scales and taps > 8), 11 = the frame-lane kernel
  * (lanes of a wave = frames of the batch; the automatic choice for batches of >= 16 frames whose plan has no phase
- * structure) for every plan and batch size. */
+ * structure) for every plan and batch size, always in its 64-frame form, 12 = its frame-pair form (two frames per lane,
+ * 128 frames per workgroup; the automatic choice for whole groups of 128 frames, filter sizes 5 and 7) for the whole batch
+ * wherever it is configured. */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
 JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);

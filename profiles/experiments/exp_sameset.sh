@@ -1,0 +1,9 @@
+cd "$GRAFT_REPO_ROOT"
+line() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('$1', d['config']['kernel'], 'Gpix/s=%.1f'%(d['value']/1e3), 'valu_frac=%.3f'%r['valu_frac'], 'kernel_ms=%.3f'%r['kernel_ms_per_launch'])"; }
+for c in A137 A1875 D169 N15; do
+  python bench.py --config $c --frames 256 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | line "$c normal"
+  JINC_FL_EXP_SAMESET=1 python bench.py --config $c --frames 256 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | line "$c sameset(8 sets)"
+done
