@@ -105,9 +105,12 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             continue;
         }
         if (wants_framelane(t, i)) {
-            const uintptr_t vec = static_cast<uintptr_t>(4 * sb);
-            const int vec_ok = reinterpret_cast<uintptr_t>(dst[i]) % vec == 0 && static_cast<uintptr_t>(dst_pitch[i]) % vec == 0 &&
-                               (nframes <= 1 || io.dst_frame_stride % vec == 0);
+            auto aligned_to = [&](uintptr_t bytes) {
+                return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
+                       (nframes <= 1 || io.dst_frame_stride % bytes == 0);
+            };
+            // bit 0: packed stores of 4 samples, bit 1: 16-byte stores (8-bit planes in the frame-pair form)
+            const int vec_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
             // Whole groups of 128 frames of plans with many coefficient sets go to the frame-pair form (two frames per lane:
             // half the per-pixel coefficient traffic and scalar work, packed multiplies / adds): measured at 256 frames
             // 1.37x 47 % of the VALU peak against 42 %, DVD -> 1080p (72 phases) 52 % against 49 %, 15 / 8 (period 15)

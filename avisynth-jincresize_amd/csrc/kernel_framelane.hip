@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512) void ewa_framelane_kernel(const FrameLaneArgs 
         }
 
         // ---- store: one 4-sample store per row where the address allows it ----
-        const bool vec = nvx == 4 && a.vec_store_ok && ((x0 & 3) == 0);  // wave-uniform
+        const bool vec = nvx == 4 && (a.vec_store_ok & 1) && ((x0 & 3) == 0);  // wave-uniform
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (k < kvalid)

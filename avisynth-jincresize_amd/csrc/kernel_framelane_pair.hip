@@ -132,8 +132,8 @@ struct FlpOut<uint8_t> {
 // (see fl_win_step in kernel_framelane.hip).  False: past the strip's last origin.
 template <typename T, int FS, int I>
 __device__ __forceinline__ bool flp_step(f32x2 (&w)[FS][FS], const char*& pc, int pc_step, int s, int s_last, int& j, int npix, int csv,
-                                         int setv, const JINC_CONSTANT char* cbase, FlpOut<T>& res, char* drow, size_t fstride, bool on_a,
-                                         bool on_b, bool vec_ok, float peak) {
+                                         int setv, const JINC_CONSTANT char* cbase, FlpOut<T>& res, uint32_t (&oba)[4], uint32_t (&obb)[4], char* drow, size_t fstride,
+                                         bool on_a, bool on_b, bool vec_ok, int vec_strip, float peak) {
     constexpr int SB = static_cast<int>(sizeof(T));
     if (s > s_last) return false;  // wave-uniform
     flp_load_col<T, FS>(w[(I + FS - 1) % FS], pc);  // column s + FS - 1
@@ -146,18 +146,13 @@ __device__ __forceinline__ bool flp_step(f32x2 (&w)[FS][FS], const char*& pc, in
         if constexpr (std::is_same_v<T, uint8_t>) {
             res.a = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, static_cast<uint32_t>(q), q == 0 ? 0u : res.a);
             res.b = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, static_cast<uint32_t>(q), q == 0 ? 0u : res.b);
-            if (flush) {
-                char* d = drow + static_cast<size_t>(j & ~3);
-                if (vec_ok && q == 3) {
-                    if (on_a) *reinterpret_cast<uint32_t*>(d) = res.a;
-                    if (on_b) *reinterpret_cast<uint32_t*>(d + fstride) = res.b;
-                } else {
-#pragma unroll
-                    for (int xx = 0; xx < 4; ++xx)
-                        if (xx <= q) {
-                            if (on_a) reinterpret_cast<uint8_t*>(d)[xx] = static_cast<uint8_t>(res.a >> (8 * xx));
-                            if (on_b) reinterpret_cast<uint8_t*>(d + fstride)[xx] = static_cast<uint8_t>(res.b >> (8 * xx));
-                        }
+            if (flush) {  // a finished word is parked; 16 pixels (or the strip's tail) leave as one store per frame
+                fl_park4(oba, j >> 2, res.a);
+                fl_park4(obb, j >> 2, res.b);
+                if ((j & 15) == 15 || j == npix - 1) {
+                    char* d = drow + static_cast<size_t>(j & ~15);
+                    if (on_a) fl_flush16_u8(oba, d, (j & 15) + 1, vec_strip);
+                    if (on_b) fl_flush16_u8(obb, d + fstride, (j & 15) + 1, vec_strip);
                 }
             }
         } else {
@@ -224,7 +219,8 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_pair_kernel(const FrameL
     char* dframe = static_cast<char*>(a.io.dst) + static_cast<size_t>(t.f0 + (on_a ? 2 * lane : 0)) * fstride;
     const char* lds_lane = tile + lane * 2 * SB;
     const JINC_CONSTANT char* cbase = (const JINC_CONSTANT char*)(p.coeffs);
-    const bool vec_ok = a.vec_store_ok && ((t.bx0 & 3) == 0);
+    const bool vec_ok = (a.vec_store_ok & 1) && ((t.bx0 & 3) == 0);
+    const int vec_strip = (vec_ok ? 1 : 0) | (((a.vec_store_ok & 2) && (t.bx0 & 15) == 0) ? 2 : 0);  // 8-bit: dword / 16-byte stores
     for (int st = wave; st < nstrips; st += nwaves) {
         asm volatile("" ::"v"(pf_keep));
         pf_keep = prefetch_strip(st + nwaves);
@@ -246,12 +242,13 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_pair_kernel(const FrameL
         }
         int j = 0;
         FlpOut<T> res = {};
+        uint32_t oba[4] = {0u, 0u, 0u, 0u}, obb[4] = {0u, 0u, 0u, 0u};  // 8-bit: packed results of the current 16 pixels, per frame
         static_assert(FS <= 7, "the step list below has seven entries");
         for (int s0 = s_first; s0 <= s_last; s0 += FS) {
 #define JINC_FLP_STEP(I)                                                                                                               \
     if constexpr (I < FS) {                                                                                                            \
-        if (!flp_step<T, FS, (I < FS ? I : 0)>(w, pc, thp * PS, s0 + I, s_last, j, npix, csv, setv, cbase, res, drow, fstride, on_a, on_b, \
-                                               vec_ok, a.io.peak))                                                                     \
+        if (!flp_step<T, FS, (I < FS ? I : 0)>(w, pc, thp * PS, s0 + I, s_last, j, npix, csv, setv, cbase, res, oba, obb, drow, fstride, on_a, \
+                                               on_b, vec_ok, vec_strip, a.io.peak))                                                                     \
             break;                                                                                                                     \
     }
             JINC_FLP_STEP(0) JINC_FLP_STEP(1) JINC_FLP_STEP(2) JINC_FLP_STEP(3) JINC_FLP_STEP(4) JINC_FLP_STEP(5) JINC_FLP_STEP(6)

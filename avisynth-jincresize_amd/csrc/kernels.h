@@ -198,7 +198,7 @@ struct FrameLaneArgs {
     int tx_shift = 5, ty_shift = 5;        // tile = (1 << tx_shift) x (1 << ty_shift) output pixels, tx >= 4, ty >= 4
     int threads = 512;
     int lds_bytes = 0;
-    int vec_store_ok = 0;     // destination base, pitch and frame stride are multiples of 4 samples
+    int vec_store_ok = 0;     // bit 0: destination base, pitch and frame stride are multiples of 4 samples; bit 1: of 16 bytes
     int variant = 0;          // 0: automatic (sliding-window form for filter sizes 5, 7, 8, 9), 1: row-segment form always
     int pair = 0;             // 1: configured for the frame-pair form (128 frames per workgroup)
 };
