@@ -42,8 +42,8 @@ CONFIGS = {
     # BASELINE.json configs[4]: ONE clip of 512 frames sharded over the ranks (strong scaling: the per-rank batch shrinks
     # with N); the default C2 run is the weak-scaling form of the same workload
     "C5": ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 512),
-    "C3": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=8, cplace="mpeg2"), 16),
-    "C4": ("RGBPS", 3840, 2160, 7680, 4320, dict(tap=4, blur=0.98), 8),
+    "C3": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=8, cplace="mpeg2"), 32),
+    "C4": ("RGBPS", 3840, 2160, 7680, 4320, dict(tap=4, blur=0.98), 16),
     # not a BASELINE.json config: a non-periodic ratio (1.5x, float drift => gather kernel for every pixel)
     "C1": ("Y8", 640, 360, 1280, 720, dict(tap=3), 256),     # BASELINE configs[0] shape (the reference's CPU case), on the GPU
     "N15": ("Y8", 1280, 720, 1920, 1080, dict(tap=3), 64),
@@ -63,7 +63,7 @@ CONFIGS = {
     "D12T4": ("Y8", 3840, 2160, 1920, 1080, dict(tap=4), 16),   # Jinc64 at 1/2: fs = 17 (9 + 8 taps per kernel row)
     "D12T8": ("Y8", 3840, 2160, 1920, 1080, dict(tap=8), 8),    # Jinc256 at 1/2: fs = 33 (3 x 11)
     "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 16),    # Jinc144: fs = 13
-    "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 4),   # tap 16: fs = 33 (1089 taps)
+    "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 16),  # tap 16: fs = 33 (1089 taps)
 }
 
 
