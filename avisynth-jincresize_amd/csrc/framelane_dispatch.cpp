@@ -91,15 +91,18 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
     if (p.fs > 9) budget = 48 * 1024;
     if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
-    budget = std::min<size_t>(budget, big ? 80 * 1024 : 64 * 1024);
+    // (sliding-window forms may take up to 80 KB -- two workgroups per CU; the row-segment form is launched without the attribute)
+    int variant = 0;
+    if (const char* e = std::getenv("JINC_FL_VARIANT")) variant = std::atoi(e);  // A/B knob: 1 = row-segment form always
+    const bool window_form = variant != 1 && (p.fs == 5 || p.fs == 7 || p.fs == 8 || p.fs == 9);
+    budget = std::min<size_t>(budget, (big || (window_form && p.fs != 7)) ? 80 * 1024 : 64 * 1024);
     if (!configure_tiles(p, rects, ps, budget, 64, nframes_hint, 0.0, out)) return false;
     const int tx = 1 << out.tx_shift, ty = 1 << out.ty_shift;
     const int units = (tx / 4) * (ty / 4);
     out.threads = 64 * std::min(8, std::max(1, units));
     if (big && units >= 16) out.threads = 1024;  // (small tiles keep the 512-thread shape)
     if (const char* e = std::getenv("JINC_FL_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
-    out.variant = 0;
-    if (const char* e = std::getenv("JINC_FL_VARIANT")) out.variant = std::atoi(e);  // A/B knob: 1 = row-segment form always
+    out.variant = variant;
     out.pair = 0;
     return true;
 }

@@ -372,6 +372,17 @@ int launch_fl_t(const FrameLaneArgs& a, hipStream_t stream) {
 
 template <typename T, int FS>
 int launch_fl_win(const FrameLaneArgs& a, hipStream_t stream) {
+    if (a.lds_bytes > 64 * 1024) {  // dynamic LDS beyond 64 KB needs the attribute once per kernel AND device
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return static_cast<int>(hipGetLastError());
+        if (dev < 0 || dev >= 64 || !attr_set[dev].load()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&ewa_framelane_win_kernel<T, FS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    80 * 1024) != hipSuccess)
+                return static_cast<int>(hipGetLastError());
+            if (dev >= 0 && dev < 64) attr_set[dev].store(true);
+        }
+    }
     const int ntiles = a.block_begin[4];
     dim3 grid(static_cast<unsigned>((ntiles + 7) / 8) * 8u, static_cast<unsigned>((a.io.nframes + 63) / 64), 1);
     dim3 block(static_cast<unsigned>(a.threads), 1, 1);
