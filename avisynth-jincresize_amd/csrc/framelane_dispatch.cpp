@@ -82,20 +82,22 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     // LDS per workgroup: a larger tile has less halo (fewer staged samples per output pixel), a smaller one lets more
     // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
     size_t budget = 64 * 1024;  // A/B (64 frames): 1.37x fs 7 48 KB = 64 KB; 5/6 down-scale fs 8 +28 % over 48 KB
-    // fs 7: the 1024-thread shape of the sliding-window kernel (two workgroups per CU at 64 VGPRs = 8 waves per SIMD) with
-    // tiles of up to 80 KB
-    bool big = p.fs == 7;
-    if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
-    if (big) budget = 80 * 1024;
-    // the row-segment form (fs > 9: 80 VGPRs, 6 waves per SIMD) gains more from a third workgroup per CU than it loses to the
-    // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
-    if (p.fs > 9) budget = 48 * 1024;
-    if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
-    // (sliding-window forms may take up to 80 KB -- two workgroups per CU; the row-segment form is launched without the attribute)
     int variant = 0;
     if (const char* e = std::getenv("JINC_FL_VARIANT")) variant = std::atoi(e);  // A/B knob: 1 = row-segment form always
     const bool window_form = variant != 1 && (p.fs == 5 || p.fs == 7 || p.fs == 8 || p.fs == 9);
-    budget = std::min<size_t>(budget, (big || (window_form && p.fs != 7)) ? 80 * 1024 : 64 * 1024);
+    // fs 7: the 1024-thread shape of the sliding-window kernel (two workgroups per CU at 64 VGPRs = 8 waves per SIMD) with
+    // tiles of up to 80 KB
+    bool big = window_form && p.fs == 7;
+    if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
+    // the other sliding-window forms (512 threads, two workgroups per CU either way) take up to 80 KB too: 1.5x with tap 4
+    // (fs 9) gets 32 x 32 tiles, 46.6 -> 50.4 % of the VALU peak; the row-segment form is launched without the attribute
+    if (big || (window_form && p.fs != 7)) budget = 80 * 1024;
+    // the row-segment form (fs > 9: 80 VGPRs, 6 waves per SIMD) gains more from a third workgroup per CU than it loses to the
+    // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
+    if (p.fs > 9) budget = 48 * 1024;
+    const size_t cap = (big || (window_form && p.fs != 7)) ? 80 * 1024 : 64 * 1024;
+    if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
+    budget = std::min(budget, cap);
     if (!configure_tiles(p, rects, ps, budget, 64, nframes_hint, 0.0, out)) return false;
     const int tx = 1 << out.tx_shift, ty = 1 << out.ty_shift;
     const int units = (tx / 4) * (ty / 4);

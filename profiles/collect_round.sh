@@ -15,13 +15,13 @@ for c in C2 C3 C4; do
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   python profiles/summarize.py ${tag}_$(echo $c | tr A-Z a-z) gpurun_out/${tag}_stats_$c gpurun_out/${tag}_fetch_$c gpurun_out/${tag}_write_$c > /dev/null 2>&1
-  tail -1 gpurun_out/${tag}_stats_$c.log > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_$c.json
+  grep "^{" gpurun_out/${tag}_stats_$c.log | tail -1 > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_$c.json
 done
 # the frame-pair kernel under the profiler (kernel-trace stats only; its PMC passes: profiles/pmc_fl.sh)
 export JINC_FRAMES_PER_LAUNCH=$(python -c "import bench; print(bench.CONFIGS['A137'][6])")
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_A137 -- python bench.py --config A137 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_stats_A137.log 2>&1
 python profiles/summarize.py ${tag}_a137 gpurun_out/${tag}_stats_A137 > /dev/null 2>&1
-tail -1 gpurun_out/${tag}_stats_A137.log > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_A137.json
+grep "^{" gpurun_out/${tag}_stats_A137.log | tail -1 > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_A137.json
 cp profiles/$JINC_PROFILE_DIR/${tag}_* gpurun_out/$JINC_PROFILE_DIR/ 2>/dev/null
 for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875; do
   timeout 120 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
