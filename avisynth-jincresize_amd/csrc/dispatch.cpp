@@ -41,6 +41,9 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         // measured at 64 frames 33 % of the VALU peak against 46 % here; with few phases (1.5x, 3x: 9) it stays ahead.
         // With a source step of 2 (1.5x) full frame groups are ahead too: fs 7 54 % against 52 %, fs 9 46 % against 34 %.
         if (wants_quasi(t)) {
+            // whole groups of 128 frames: the frame-pair form is ahead of the quasi-periodic kernel on every plan measured
+            // (256 frames: 1.5x 62 against 52 % of the VALU peak, 3x 69 against 68 %, 4/3x 60 against 54 %)
+            if (t.use_framelane_pair && nframes >= jinc::kFrameLanePairFrames) return true;
             if (f.plans[f.table_of_plane(i)].periodic) return false;
             if (t.quasi.px * t.quasi.py > 16 && nframes >= 48) return true;
             return (t.plan.fs == 7 || t.plan.fs == 9) && t.quasi.sx >= 2 && t.quasi.sy >= 2 && nframes >= 64;
@@ -111,19 +114,14 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             };
             // bit 0: packed stores of 4 samples, bit 1: 16-byte stores (8-bit planes in the frame-pair form)
             const int vec_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
-            // Whole groups of 128 frames of plans with many coefficient sets go to the frame-pair form (two frames per lane:
-            // half the per-pixel coefficient traffic and scalar work, packed multiplies / adds): measured at 256 frames
-            // 1.37x 47 % of the VALU peak against 42 %, DVD -> 1080p (72 phases) 52 % against 49 %, 15 / 8 (period 15)
-            // equal; drifting plans with few phases (1.5x) reuse their sets out of the scalar cache and lose 3 % to the
-            // smaller tiles, so they stay on the 64-frame form, which also takes what is left of a batch and every batch
-            // below 128 frames.  kernel_mode 12 (tests, A/B): the frame-pair form for the whole batch.
+            // Whole groups of 128 frames go to the frame-pair form (two frames per lane: half the per-pixel coefficient
+            // traffic and scalar work, packed multiplies / adds; measured at 256 frames against the 64-frame form: 1.37x
+            // 55 against 42 % of the VALU peak, 1.5x 62 against 54 %, DVD -> 1080p 63 against 49 %, 15 / 8 61 against 52 %);
+            // what is left of the batch, and every batch below 128 frames, to the 64-frame form.  kernel_mode 12 (tests,
+            // A/B): the frame-pair form for the whole batch, 11: the 64-frame form for the whole batch.
             int npair = 0;
-            if (t.use_framelane_pair && f.kernel_mode != 11) {
-                const bool many_sets = !wants_quasi(t) || t.quasi.px * t.quasi.py > 16;
-                npair = f.kernel_mode == 12 ? nframes
-                        : many_sets         ? nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames
-                                            : 0;
-            }
+            if (t.use_framelane_pair && f.kernel_mode != 11)
+                npair = f.kernel_mode == 12 ? nframes : nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames;
             if (npair > 0) {
                 jinc::FrameLaneArgs fa = t.fl_pair;
                 fa.io = io;

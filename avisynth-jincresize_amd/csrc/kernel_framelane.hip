@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void ewa_framelane_kernel(const FrameLaneArgs 
     };
     uint32_t pf_keep = prefetch_unit(wave);  // the wave's first unit: in flight during the staging below
 
-    fl_stage<T>(a, t, tile, tw, 1, lane, wave, nwaves);  // row-major positions: a row segment is fs consecutive positions
+    fl_stage<T, PS, 8, 2>(a, t, tile, tw, 1, lane, wave, nwaves);  // row-major positions: a row segment is fs consecutive positions
     __syncthreads();
     asm volatile("" ::"v"(pf_keep));
     if (lane >= nfg) return;  // lanes without a frame (last group of the batch); no barrier below

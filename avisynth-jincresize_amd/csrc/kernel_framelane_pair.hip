@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_pair_kernel(const FrameL
     uint32_t pf_keep = prefetch_strip(wave);
 
     const int thp = t.th | 1;  // odd column pitch: the staging writes of neighbouring columns fall on different banks
-    fl_stage<T, PS>(a, t, tile, 1, thp, lane, wave, nwaves);
+    fl_stage<T, PS, 16, 1>(a, t, tile, 1, thp, lane, wave, nwaves);  // 8 waves, 128 frames: 16 frames per wave
     __syncthreads();
     asm volatile("" ::"v"(pf_keep));
     // Lanes without a frame (last group of the batch) stay active -- the strip tables live one pixel per LANE and are read

@@ -48,9 +48,9 @@ CONFIGS = {
     "C1": ("Y8", 640, 360, 1280, 720, dict(tap=3), 256),     # BASELINE configs[0] shape (the reference's CPU case), on the GPU
     "N15": ("Y8", 1280, 720, 1920, 1080, dict(tap=3), 256),
     "D23": ("Y8", 1920, 1080, 1280, 720, dict(tap=3), 64),   # 2/3 down-scale: fs = 10, period 2, source step 3
-    "N3": ("Y8", 1280, 720, 3840, 2160, dict(tap=3), 64),     # 3x: drifting phases, quasi-periodic kernel
+    "N3": ("Y8", 1280, 720, 3840, 2160, dict(tap=3), 128),    # 3x: drifting phases (>= 128 frames: frame-pair kernel; below: quasi-periodic kernel)
     "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 128),  # 1.5x with Jinc256: fs 17, drifting (batches: frame-lane kernel, row-segment form)
-    "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 64),   # 4/3x: exactly periodic, period 4 / source step 3
+    "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 128),  # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 256),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables (>= 128 frames: frame-pair kernel)
     "N15T4": ("Y8", 1280, 720, 1920, 1080, dict(tap=4), 256),  # 1.5x with Jinc64: fs 9, drifting (batches: frame-lane kernel)
     "A137": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 256),    # 1.37x: no phase structure at all (>= 128 frames: frame-pair kernel)
