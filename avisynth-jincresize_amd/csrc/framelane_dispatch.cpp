@@ -115,7 +115,9 @@ bool framelane_pair_configure(const PlanePlan& p, const RectList& rects, int sam
     const int ps = kFrameLanePairPosBytes(static_cast<size_t>(sample_bytes));
     size_t budget = 80 * 1024;
     if (const char* e = std::getenv("JINC_FLP_LDS_KB")) budget = std::min<size_t>(budget, static_cast<size_t>(std::atoi(e)) * 1024);  // tuning knob
-    if (!configure_tiles(p, rects, ps, budget, kFrameLanePairFrames, nframes_hint, 0.5, out)) return false;
+    double colw = 0.5;
+    if (const char* e = std::getenv("JINC_FLP_COLW")) colw = std::atof(e);  // tuning knob: price of a strip's window columns
+    if (!configure_tiles(p, rects, ps, budget, kFrameLanePairFrames, nframes_hint, colw, out)) return false;
     const int ty = 1 << out.ty_shift;
     out.threads = 64 * std::min(8, ty);  // a wave walks whole strips (output rows of the tile)
     if (const char* e = std::getenv("JINC_FLP_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob

@@ -185,7 +185,8 @@ __device__ __forceinline__ bool fl_win_step(float (&w)[FS][FS], const char*& pc,
             // 8-bit: the converted sample goes straight into byte q of the packed word (byte select from an SGPR): one
             // vector instruction instead of a four-way compare / select on the result registers
             uint32_t& pk = reinterpret_cast<uint32_t&>(res[0]);
-            pk = __builtin_amdgcn_cvt_pk_u8_f32(acc, static_cast<uint32_t>(q), q == 0 ? 0u : pk);
+            // (byte q replaced, the others kept: bytes above q are stale until the group is complete and never stored before)
+            pk = __builtin_amdgcn_cvt_pk_u8_f32(acc, static_cast<uint32_t>(q), pk);
             if (flush && lane_on) {
                 char* d = drow + static_cast<size_t>(j & ~3);
                 if (vec_ok && q == 3) {

@@ -144,8 +144,9 @@ __device__ __forceinline__ bool flp_step(f32x2 (&w)[FS][FS], const char*& pc, in
         const int q = j & 3;
         const bool flush = q == 3 || j == npix - 1;  // wave-uniform
         if constexpr (std::is_same_v<T, uint8_t>) {
-            res.a = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, static_cast<uint32_t>(q), q == 0 ? 0u : res.a);
-            res.b = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, static_cast<uint32_t>(q), q == 0 ? 0u : res.b);
+            // (byte q replaced, the others kept: bytes above q are stale until the group is complete and never stored before)
+            res.a = __builtin_amdgcn_cvt_pk_u8_f32(acc.x, static_cast<uint32_t>(q), res.a);
+            res.b = __builtin_amdgcn_cvt_pk_u8_f32(acc.y, static_cast<uint32_t>(q), res.b);
             if (flush) {  // a finished word is parked; 16 pixels (or the strip's tail) leave as one store per frame
                 fl_park4(oba, j >> 2, res.a);
                 fl_park4(obb, j >> 2, res.b);
