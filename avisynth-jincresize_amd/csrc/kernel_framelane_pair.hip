@@ -111,93 +111,6 @@ __device__ __forceinline__ f32x2 flp_mac(const f32x2 (&w)[FS][FS], const JINC_CO
     return acc;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Coefficient pipeline.  A set travels in two halves: A = the first kA kernel rows, B = the rest.  While the chain runs
-// through A's rows, B is in flight; while it runs through B's rows, the NEXT pixel's A is in flight -- the scalar loads'
-// latency (a scalar-cache hit is ~200 cycles, and every wave stood still for it once per pixel) hides behind multiplies
-// of the same wave.  Scalar loads return out of order, so the only usable wait is lgkmcnt(0); the compiler places it in
-// front of the first use of ANY loaded register and so would wait for the half just requested.  The loads and waits are
-// therefore explicit (asm volatile keeps their order; the waits pass the landed registers and the accumulator through,
-// which orders them against the row statements).
-// ------------------------------------------------------------------------------------------------
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x8 __attribute__((ext_vector_type(8)));
-// (the accumulator passes through every request: the row statements before / after it in program order stay there)
-template <int OFF>
-__device__ __forceinline__ f32x16 flp_sload16(const JINC_CONSTANT char* base, uint32_t soff, f32x2& acc) {
-    f32x16 r;
-    asm volatile("s_load_dwordx16 %0, %2, %3 offset:%4" : "=&s"(r), "+v"(acc) : "s"(base), "s"(soff), "n"(OFF));
-    return r;
-}
-template <int OFF>
-__device__ __forceinline__ f32x8 flp_sload8(const JINC_CONSTANT char* base, uint32_t soff, f32x2& acc) {
-    f32x8 r;
-    asm volatile("s_load_dwordx8 %0, %2, %3 offset:%4" : "=&s"(r), "+v"(acc) : "s"(base), "s"(soff), "n"(OFF));
-    return r;
-}
-// Rows of a set are padded to 8 floats (fs 5 and 7): 16 dwords = two rows.
-template <int FS>
-struct FlpSetA {  // the first 4 (fs 7) / 2 (fs 5) rows
-    static constexpr int kRows = FS == 7 ? 4 : 2;
-    f32x16 r01;
-    f32x16 r23;  // fs 7 only
-};
-template <int FS>
-struct FlpSetB {  // the last three rows
-    f32x16 r01;
-    f32x8 r2;
-};
-template <int FS>
-__device__ __forceinline__ void flp_request_a(FlpSetA<FS>& a, const JINC_CONSTANT char* cbase, uint32_t soff, f32x2& acc) {
-    a.r01 = flp_sload16<0>(cbase, soff, acc);
-    if constexpr (FS == 7) a.r23 = flp_sload16<64>(cbase, soff, acc);
-}
-template <int FS>
-__device__ __forceinline__ void flp_request_b(FlpSetB<FS>& b, const JINC_CONSTANT char* cbase, uint32_t soff, f32x2& acc) {
-    constexpr int kOff = FlpSetA<FS>::kRows * 32;
-    b.r01 = flp_sload16<kOff>(cbase, soff, acc);
-    b.r2 = flp_sload8<kOff + 64>(cbase, soff, acc);
-}
-template <int FS>
-__device__ __forceinline__ void flp_landed_a(FlpSetA<FS>& a, f32x2& acc) {
-    if constexpr (FS == 7)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a.r01), "+s"(a.r23), "+v"(acc));
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a.r01), "+v"(acc));
-}
-template <int FS>
-__device__ __forceinline__ void flp_landed_b(FlpSetB<FS>& b, f32x2& acc) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b.r01), "+s"(b.r2), "+v"(acc));
-}
-#define JINC_FLP_PAIR(V, I) (f32x2{(V)[2 * (I)], (V)[2 * (I) + 1]})
-// one kernel row LY of the chain with the coefficient row held in dwords 8 * H .. 8 * H + 7 of v
-template <int FS, int PH, int LY, int H, typename V>
-__device__ __forceinline__ void flp_row_from(f32x2& acc, const f32x2 (&w)[FS][FS], const V& v) {
-    if constexpr (FS == 7)
-        flp_row7(acc, w[(PH + 0) % FS][LY], w[(PH + 1) % FS][LY], w[(PH + 2) % FS][LY], w[(PH + 3) % FS][LY], w[(PH + 4) % FS][LY],
-                 w[(PH + 5) % FS][LY], w[(PH + 6) % FS][LY], JINC_FLP_PAIR(v, 4 * H), JINC_FLP_PAIR(v, 4 * H + 1), JINC_FLP_PAIR(v, 4 * H + 2),
-                 JINC_FLP_PAIR(v, 4 * H + 3));
-    else
-        flp_row5(acc, w[(PH + 0) % FS][LY], w[(PH + 1) % FS][LY], w[(PH + 2) % FS][LY], w[(PH + 3) % FS][LY], w[(PH + 4) % FS][LY],
-                 JINC_FLP_PAIR(v, 4 * H), JINC_FLP_PAIR(v, 4 * H + 1), JINC_FLP_PAIR(v, 4 * H + 2));
-}
-template <int FS, int PH>
-__device__ __forceinline__ void flp_half_a(f32x2& acc, const f32x2 (&w)[FS][FS], const FlpSetA<FS>& a) {
-    flp_row_from<FS, PH, 0, 0>(acc, w, a.r01);
-    flp_row_from<FS, PH, 1, 1>(acc, w, a.r01);
-    if constexpr (FS == 7) {
-        flp_row_from<FS, PH, 2, 0>(acc, w, a.r23);
-        flp_row_from<FS, PH, 3, 1>(acc, w, a.r23);
-    }
-}
-template <int FS, int PH>
-__device__ __forceinline__ void flp_half_b(f32x2& acc, const f32x2 (&w)[FS][FS], const FlpSetB<FS>& b) {
-    constexpr int R = FlpSetA<FS>::kRows;
-    flp_row_from<FS, PH, R, 0>(acc, w, b.r01);
-    flp_row_from<FS, PH, R + 1, 1>(acc, w, b.r01);
-    flp_row_from<FS, PH, R + 2, 0>(acc, w, b.r2);
-}
-
 template <typename T, int FS>
 __device__ __forceinline__ void flp_load_col(f32x2 (&col)[FS], const char* p) {
     constexpr int PS = kFrameLanePairPosBytes(sizeof(T));
@@ -219,25 +132,15 @@ struct FlpOut<uint8_t> {
 // (see fl_win_step in kernel_framelane.hip).  False: past the strip's last origin.
 template <typename T, int FS, int I>
 __device__ __forceinline__ bool flp_step(f32x2 (&w)[FS][FS], const char*& pc, int pc_step, int s, int s_last, int& j, int npix, int csv,
-                                         int setv, const JINC_CONSTANT char* cbase, FlpSetA<FS>& ca, FlpOut<T>& res, uint32_t (&oba)[4], uint32_t (&obb)[4], char* drow, size_t fstride,
+                                         int setv, const JINC_CONSTANT char* cbase, FlpOut<T>& res, uint32_t (&oba)[4], uint32_t (&obb)[4], char* drow, size_t fstride,
                                          bool on_a, bool on_b, bool vec_ok, int vec_strip, float peak) {
     constexpr int SB = static_cast<int>(sizeof(T));
     if (s > s_last) return false;  // wave-uniform
     flp_load_col<T, FS>(w[(I + FS - 1) % FS], pc);  // column s + FS - 1
     pc += pc_step;
     while (j < npix && __builtin_amdgcn_readlane(csv, j) == s) {
-        // ca holds the first rows of pixel j's set (landed); the rest is requested now, the next pixel's first rows once that
-        // has landed (coefficient pipeline, above)
         const uint32_t soff = static_cast<uint32_t>(__builtin_amdgcn_readlane(setv, j));
-        const uint32_t soff_next = static_cast<uint32_t>(__builtin_amdgcn_readlane(setv, min(j + 1, npix - 1)));
-        FlpSetB<FS> cb;
-        f32x2 acc = {0.f, 0.f};
-        flp_request_b<FS>(cb, cbase, soff, acc);
-        flp_half_a<FS, I>(acc, w, ca);
-        flp_landed_b<FS>(cb, acc);
-        flp_request_a<FS>(ca, cbase, soff_next, acc);
-        flp_half_b<FS, I>(acc, w, cb);
-        flp_landed_a<FS>(ca, acc);
+        const f32x2 acc = flp_mac<FS, I>(w, cbase + soff);
         const int q = j & 3;
         const bool flush = q == 3 || j == npix - 1;  // wave-uniform
         if constexpr (std::is_same_v<T, uint8_t>) {
@@ -339,19 +242,13 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_pair_kernel(const FrameL
             pc += thp * PS;
         }
         int j = 0;
-        FlpSetA<FS> ca;  // first rows of the coefficient set of the strip's next pixel
-        {
-            f32x2 none = {0.f, 0.f};
-            flp_request_a<FS>(ca, cbase, static_cast<uint32_t>(__builtin_amdgcn_readlane(setv, 0)), none);
-            flp_landed_a<FS>(ca, none);
-        }
         FlpOut<T> res = {};
         uint32_t oba[4] = {0u, 0u, 0u, 0u}, obb[4] = {0u, 0u, 0u, 0u};  // 8-bit: packed results of the current 16 pixels, per frame
         static_assert(FS <= 7, "the step list below has seven entries");
         for (int s0 = s_first; s0 <= s_last; s0 += FS) {
 #define JINC_FLP_STEP(I)                                                                                                               \
     if constexpr (I < FS) {                                                                                                            \
-        if (!flp_step<T, FS, (I < FS ? I : 0)>(w, pc, thp * PS, s0 + I, s_last, j, npix, csv, setv, cbase, ca, res, oba, obb, drow, fstride, on_a, \
+        if (!flp_step<T, FS, (I < FS ? I : 0)>(w, pc, thp * PS, s0 + I, s_last, j, npix, csv, setv, cbase, res, oba, obb, drow, fstride, on_a, \
                                                on_b, vec_ok, vec_strip, a.io.peak))                                                                     \
             break;                                                                                                                     \
     }
