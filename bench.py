@@ -45,9 +45,9 @@ CONFIGS = {
     "C3": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=8, cplace="mpeg2"), 32),
     "C4": ("RGBPS", 3840, 2160, 7680, 4320, dict(tap=4, blur=0.98), 16),
     # not a BASELINE.json config: a non-periodic ratio (1.5x, float drift => gather kernel for every pixel)
-    "C1": ("Y8", 640, 360, 1280, 720, dict(tap=3), 256),     # BASELINE configs[0] shape (the reference's CPU case), on the GPU
+    "C1": ("Y8", 640, 360, 1280, 720, dict(tap=3), 1024),     # BASELINE configs[0] shape (the reference's CPU case), on the GPU
     "N15": ("Y8", 1280, 720, 1920, 1080, dict(tap=3), 256),
-    "D23": ("Y8", 1920, 1080, 1280, 720, dict(tap=3), 64),   # 2/3 down-scale: fs = 10, period 2, source step 3
+    "D23": ("Y8", 1920, 1080, 1280, 720, dict(tap=3), 256),   # 2/3 down-scale: fs = 10, period 2, source step 3
     "N3": ("Y8", 1280, 720, 3840, 2160, dict(tap=3), 128),    # 3x: drifting phases (>= 128 frames: frame-pair kernel; below: quasi-periodic kernel)
     "N15T8": ("Y8", 1280, 720, 1920, 1080, dict(tap=8), 128),  # 1.5x with Jinc256: fs 17, drifting (batches: frame-lane kernel, row-segment form)
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 128),  # 4/3x: exactly periodic, period 4 / source step 3
@@ -56,13 +56,13 @@ CONFIGS = {
     "A137": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 256),    # 1.37x: no phase structure at all (>= 128 frames: frame-pair kernel)
     "A1875": ("Y8", 1024, 576, 1920, 1080, dict(tap=3), 256),  # PAL -> 1080p, 15/8: period 15, source step 8
     "D169": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 256),   # 5/6 down-scale: drifting, period 5, source step 6, fs 8
-    "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 32),   # 1/2 down-scale: fs = 13, period 1, source step 2
-    "D12H": ("YUV420P16", 3840, 2160, 1920, 1080, dict(tap=3), 16),  # 4K 16-bit 4:2:0 -> 1080p
-    "D12F": ("RGBPS", 3840, 2160, 1920, 1080, dict(tap=3), 8),       # 4K float RGB -> 1080p
-    "D13": ("Y8", 3840, 2160, 1280, 720, dict(tap=3), 32),    # 1/3 down-scale: fs = 20, period 1, source step 3
-    "D12T4": ("Y8", 3840, 2160, 1920, 1080, dict(tap=4), 16),   # Jinc64 at 1/2: fs = 17 (9 + 8 taps per kernel row)
-    "D12T8": ("Y8", 3840, 2160, 1920, 1080, dict(tap=8), 8),    # Jinc256 at 1/2: fs = 33 (3 x 11)
-    "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 16),    # Jinc144: fs = 13
+    "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 128),   # 1/2 down-scale: fs = 13, period 1, source step 2
+    "D12H": ("YUV420P16", 3840, 2160, 1920, 1080, dict(tap=3), 64),  # 4K 16-bit 4:2:0 -> 1080p
+    "D12F": ("RGBPS", 3840, 2160, 1920, 1080, dict(tap=3), 32),       # 4K float RGB -> 1080p
+    "D13": ("Y8", 3840, 2160, 1280, 720, dict(tap=3), 128),    # 1/3 down-scale: fs = 20, period 1, source step 3
+    "D12T4": ("Y8", 3840, 2160, 1920, 1080, dict(tap=4), 64),   # Jinc64 at 1/2: fs = 17 (9 + 8 taps per kernel row)
+    "D12T8": ("Y8", 3840, 2160, 1920, 1080, dict(tap=8), 32),    # Jinc256 at 1/2: fs = 33 (3 x 11)
+    "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 64),    # Jinc144: fs = 13
     "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 16),  # tap 16: fs = 33 (1089 taps)
 }
 
