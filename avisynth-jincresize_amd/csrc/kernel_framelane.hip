@@ -213,7 +213,9 @@ __device__ __forceinline__ bool fl_win_step(float (&w)[FS][FS], const char*& pc,
 
 template <typename T, int FS>
 __global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneArgs a) {
+#define JINC_FL_WIN_STAGE_FRAMES 8
 #include "kernel_framelane_win_body.inc"
+#undef JINC_FL_WIN_STAGE_FRAMES
 }
 
 // The same kernel as 1024-thread workgroups held to 64 VGPRs: two workgroups per CU = 8 waves per SIMD (the kernel reacts
@@ -221,7 +223,9 @@ __global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneA
 // half the barriers).  fs 7 only: the larger windows do not fit 64 registers.
 template <typename T, int FS>
 __global__ __launch_bounds__(1024, 8) void ewa_framelane_win1k_kernel(const FrameLaneArgs a) {
+#define JINC_FL_WIN_STAGE_FRAMES 4
 #include "kernel_framelane_win_body.inc"
+#undef JINC_FL_WIN_STAGE_FRAMES
 }
 
 // ------------------------------------------------------------------------------------------------
