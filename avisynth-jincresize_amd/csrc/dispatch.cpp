@@ -35,18 +35,19 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         if (!t.use_framelane || f.kernel_mode == 1) return false;
         if (f.kernel_mode == 11 || (f.kernel_mode == 12 && t.use_framelane_pair)) return true;
         if (f.kernel_mode != 0) return false;
-        if (nframes < kFrameLaneMinFrames) return false;
+        // batch sizes from which the frame-lane kernels (rate proportional to the filled lanes) pass the single-frame
+        // kernels, measured (profiles/round2/fl_threshold.log): against the gather kernel 11 frames for 1.37x, 14 for the
+        // 5/6 down-scale, 21 for 1.5x with tap 8 (row-segment form); against the quasi-periodic kernel 33 frames for DVD ->
+        // 1080p (72 phases), 42 for 1.5x with tap 4, ~50 for 1.5x
+        if (nframes < (t.plan.fs > 9 ? 24 : kFrameLaneMinFrames)) return false;
         if (wants_periodic(t)) return false;
-        // Drifting plans with many phases (DVD -> 1080p: 8 x 9) leave the quasi-periodic kernel little to share per phase:
-        // measured at 64 frames 33 % of the VALU peak against 46 % here; with few phases (1.5x, 3x: 9) it stays ahead.
-        // With a source step of 2 (1.5x) full frame groups are ahead too: fs 7 54 % against 52 %, fs 9 46 % against 34 %.
         if (wants_quasi(t)) {
             // whole groups of 128 frames: the frame-pair form is ahead of the quasi-periodic kernel on every plan measured
             // (256 frames: 1.5x 62 against 52 % of the VALU peak, 3x 69 against 68 %, 4/3x 60 against 54 %)
             if (t.use_framelane_pair && nframes >= jinc::kFrameLanePairFrames) return true;
             if (f.plans[f.table_of_plane(i)].periodic) return false;
-            if (t.quasi.px * t.quasi.py > 16 && nframes >= 48) return true;
-            return (t.plan.fs == 7 || t.plan.fs == 9) && t.quasi.sx >= 2 && t.quasi.sy >= 2 && nframes >= 64;
+            if (t.quasi.px * t.quasi.py > 16 && nframes >= 36) return true;
+            return (t.plan.fs == 7 || t.plan.fs == 9) && t.quasi.sx >= 2 && t.quasi.sy >= 2 && nframes >= (t.plan.fs == 9 ? 48 : 64);
         }
         return !wants_direct(t, i);
     };

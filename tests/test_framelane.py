@@ -51,7 +51,8 @@ BATCH_CASES = [
 def test_batches_of_frames(gpu_pkg, O, case):
     """jinc_filter_process_device on distinct frames: every frame of the batch against the oracle, for batch sizes that
     leave lanes idle, fill a wave exactly and spill into further frame groups.  Batches of >= 16 frames of plans
-    without phase structure take the frame-lane kernel by themselves; smaller ones are forced (kernel mode 11)."""
+    without phase structure take the frame-lane kernel by themselves (from 24 for filter sizes above 9); smaller ones are
+    forced (kernel mode 11)."""
     torch = pytest.importorskip("torch")
     fmt, sw, sh, tw, th, kw, sizes = case
     ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
@@ -72,7 +73,7 @@ def test_batches_of_frames(gpu_pkg, O, case):
     for n in sizes:
         src_t = [torch.stack([to_t(fr[i]) for fr in frames[:n]]).cuda() for i in range(gfmt.planes)]
         dst_t = [torch.zeros((n, h, (w * sb + 63) // 64 * 64 // sb), dtype=tdtype, device="cuda") for (w, h) in ddims]
-        f.set_kernel_mode(0 if n >= 16 else 11)
+        f.set_kernel_mode(0 if n >= 24 else 11)  # (automatic from 16 frames, from 24 for filter sizes above 9)
         stream = torch.cuda.current_stream()
         f.process_device([t.data_ptr() for t in src_t], [t.stride(1) * sb for t in src_t], [t.stride(0) * sb for t in src_t],
                          [t.data_ptr() for t in dst_t], [t.stride(1) * sb for t in dst_t], [t.stride(0) * sb for t in dst_t],
