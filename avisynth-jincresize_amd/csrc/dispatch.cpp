@@ -58,7 +58,19 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     }
     // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
     // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
-    const bool want_overlap = f.overlap_border != 0;
+    // ... but not for calls so small that the fork / join through events costs more than the border kernels in front of
+    // the interior (measured, one frame per call: C2 114 against 103 Gpix/s without the side stream, 4K->1080p 27 against
+    // 23; from ~1e9 taps per call the side stream wins: C2 at 4 frames 319 against 287, C3 at 1 frame 24 against 20).
+    // -1: this automatic rule, 1: always, 0: never.
+    bool want_overlap = f.overlap_border != 0;
+    if (f.overlap_border < 0) {
+        double taps = 0.0;
+        for (int i = 0; i < f.planecount; ++i) {
+            const DeviceTable& t = f.tables[f.table_of_plane(i)];
+            taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
+        }
+        want_overlap = taps * nframes >= 1e9;
+    }
     const bool fork = any_periodic && want_overlap;
     if (fork) {  // border work may start once everything already queued on `stream` is done
         hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");

@@ -109,7 +109,7 @@ struct jinc_filter {
     int border_strips = 1;  // border rows/columns of exactly periodic plans on kernel_direct.hip (0: gather kernel)
     bool direct_premise = false;  // buffer_range_check_covers_soffset(device) == 1
     int simd_order = 0;  // 0: opt=0 results (default); 1 / 2 / 3: summation order of the reference's SSE4.1 / AVX2 / AVX-512 path
-    int overlap_border = -1;  // -1: automatic (side stream when the border frame is heavy: fs > 9), 0: off, 1: on
+    int overlap_border = -1;  // -1: automatic (side stream unless the call is tiny: dispatch.cpp), 0: off, 1: on
 
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
     hipStream_t stream = nullptr;

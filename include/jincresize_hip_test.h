@@ -63,8 +63,9 @@ JINC_API const char *jinc_filter_last_kernel(const jinc_filter *f, int table);
  * gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel; 0 = everything on the
  * gather kernel (A/B measurements, tests). */
 JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
-/* 1 or -1 (default): the border kernels run on a side stream concurrently with the interior kernel
- * (fork/join by events around every call); 0: all on the caller's stream, back to back. */
+/* 1: the border kernels run on a side stream concurrently with the interior kernel (fork/join by events around
+ * every call); 0: all on the caller's stream, back to back; -1 (default): the side stream unless the call is so small
+ * (below ~1e9 taps) that the fork/join costs more than it hides. */
 JINC_API int jinc_filter_set_border_overlap(jinc_filter *f, int enable);
 
 /* Test hook: runs the kernels' own sum -> sample conversion (clamp to [0, peak], round-half-even, store;
