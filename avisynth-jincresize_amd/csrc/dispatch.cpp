@@ -1,9 +1,23 @@
 // dispatch.cpp -- the kernel launches of one frame call: per plane, which interior kernel and which border kernels run,
 // on which stream (the body of the process_frame call, ref /root/reference/src/JincResize.cpp:615, on device planes).
+#include <algorithm>
+#include <cstdlib>
+
 #include "filter_internal.h"
 
 namespace jinc {
 namespace host {
+
+namespace {
+// A/B knob JINC_QUASI_SPLIT: workgroups per tile of the quasi-periodic kernel (0 / 1: no split); read once.
+int quasi_split_knob() {
+    static const int v = [] {
+        const char* e = std::getenv("JINC_QUASI_SPLIT");
+        return e ? std::atoi(e) : -1;
+    }();
+    return v;
+}
+}  // namespace
 
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
              void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
@@ -205,6 +219,19 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                     jinc::QuasiArgs qa = t.quasi;
                     if (f.kernel_mode == 8) qa.exact = 0;   // A/B: per-row lookup + waterfall over sets in SGPRs
                     if (f.kernel_mode == 10) qa.exact = 2;  // A/B: per-row lookup + per-lane coefficient registers
+                    {   // Calls that do not fill the chip split a tile's phases over several workgroups (each stages the tile
+                        // again): one DVD -> 1080p frame is 72 + 2 x 20 workgroups of 18 phases per wave, 0.23 ms whether the
+                        // call holds one frame or four.  Aim: ~1024 workgroups per launch (fs 9, whose tiles cost more to
+                        // stage: ~400).  Measured, one frame per call: DVD -> 1080p 8.8 -> 21 Gpix/s, 3x 102 -> 156, 1.5x 49 -> 61,
+                        // 1.5x with tap 4 38 -> 45; equal from 4 .. 16 frames per call on.
+                        const int tile_rows = qa.rg * t.plan.fs;
+                        const long long wgs = static_cast<long long>((qa.ni + 63) / 64) * ((qa.nj + tile_rows - 1) / tile_rows) * nframes;
+                        const int per_wave = (qa.px * qa.py + qa.nwaves - 1) / std::max(1, qa.nwaves);
+                        const long long target = t.plan.fs == 9 ? 400 : 1024;
+                        int split = wgs > 0 ? static_cast<int>((target + wgs - 1) / wgs) : 1;
+                        qa.phase_split = std::max(1, std::min(split, per_wave));
+                        if (quasi_split_knob() >= 0) qa.phase_split = std::max(1, std::min(quasi_split_knob(), per_wave));
+                    }
                     return jinc::launch_quasi(qa, t.plan.fs, io, s);
                 });
             else

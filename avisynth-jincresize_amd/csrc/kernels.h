@@ -102,6 +102,7 @@ struct QuasiArgs {
     int rg = 1;                                     // row groups (of fs output rows) per tile
     int nwaves = 4;                                 // waves per workgroup (divides px*py evenly where possible)
     int exact = 0;                                  // plan is exactly periodic: one set per phase, no per-row lookup
+    int phase_split = 1;                            // workgroups per (tile, frame): each takes every phase_split-th share of the phases
     int phase_set[256] = {0};                       // exact plans: set id of phase q*px + p
     int src_w = 0, src_h = 0, dst_h = 0;
 };
