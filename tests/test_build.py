@@ -37,12 +37,14 @@ def test_no_fused_multiply_add_in_device_code(pkg):
     isa = "\n".join(open(p).read() for p in pkg.ISA_PATHS)
     kernels = re.findall(r"^(_ZN4jinc\S*kernel\S*):", isa, flags=re.M)
     for name in ("ewa_gather_kernel", "ewa_periodic_kernel", "ewa_periodic_rows_kernel", "ewa_periodic_pk_kernel",
-                 "ewa_quasi_kernel", "ewa_framelane_kernel", "ewa_framelane_win_kernel", "ewa_framelane_win1k_kernel", "ewa_direct_kernel", "ewa_colstrip_kernel"):
+                 "ewa_quasi_kernel", "ewa_framelane_kernel", "ewa_framelane_win_kernel", "ewa_framelane_win1k_kernel", "ewa_framelane_pair_kernel", "ewa_direct_kernel", "ewa_colstrip_kernel"):
         assert any(name in k for k in kernels), name
     fused = re.findall(r"^\s+(v_fma_f32|v_fmac_f32|v_mad_f32|v_mac_f32|v_pk_fma_f32|v_fma_mix\w*|v_mfma\w*)\b", isa, flags=re.M)
     assert fused == [], f"fused ops in device code: {sorted(set(fused))}"
     assert len(re.findall(r"^\s+v_mul_f32", isa, flags=re.M)) > 100
     assert len(re.findall(r"^\s+v_add_f32", isa, flags=re.M)) > 100
+    # the packed forms (frame-pair kernel, packed periodic variant) are un-fused too: v_pk_mul_f32 + v_pk_add_f32, never v_pk_fma_f32
+    assert len(re.findall(r"^\s+v_pk_mul_f32", isa, flags=re.M)) > 100 and len(re.findall(r"^\s+v_pk_add_f32", isa, flags=re.M)) > 100
     # ... except in the SIMD-order compatibility kernels, which emulate the reference's FMA paths on purpose
     so = open(pkg.SIMD_ORDER_ISA_PATH).read()
     assert re.findall(r"^\s+v_fma_f32", so, flags=re.M), "kernel_simdorder.hip must use explicit FMAs for orders 2 and 3"
