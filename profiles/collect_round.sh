@@ -1,15 +1,15 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box (run through gpurun from the repo root):
 #   profiles/collect_round.sh <tag> [round-dir]
-# kernel-trace stats for C2/C3/C4 with the DEFAULT bench command, FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs,
-# each alone with --kernel-trace) for C2/C3/C4, and one bench line per configuration.  Raw output lands in
+# kernel-trace stats for C2/C3/C4 and two frame-pair configurations (A137, N15) with the DEFAULT bench command, FETCH_SIZE /
+# WRITE_SIZE passes (separate --pmc runs, each alone with --kernel-trace) for the same five, and one bench line per configuration.  Raw output lands in
 # gpurun_out/<tag>_*; profiles/summarize.py condenses it into profiles/<round-dir>/ (copied to gpurun_out/ as well).
 tag=${1:-r2x}
 export JINC_PROFILE_DIR=${2:-round2}
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/$JINC_PROFILE_DIR
-for c in C2 C3 C4; do
+for c in C2 C3 C4 A137 N15; do
   export JINC_FRAMES_PER_LAUNCH=$(python -c "import bench; print(bench.CONFIGS['$c'][6])")
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$c -- python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_stats_$c.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
@@ -17,11 +17,6 @@ for c in C2 C3 C4; do
   python profiles/summarize.py ${tag}_$(echo $c | tr A-Z a-z) gpurun_out/${tag}_stats_$c gpurun_out/${tag}_fetch_$c gpurun_out/${tag}_write_$c > /dev/null 2>&1
   grep "^{" gpurun_out/${tag}_stats_$c.log | tail -1 > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_$c.json
 done
-# the frame-pair kernel under the profiler (kernel-trace stats only; its PMC passes: profiles/pmc_fl.sh)
-export JINC_FRAMES_PER_LAUNCH=$(python -c "import bench; print(bench.CONFIGS['A137'][6])")
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_A137 -- python bench.py --config A137 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_stats_A137.log 2>&1
-python profiles/summarize.py ${tag}_a137 gpurun_out/${tag}_stats_A137 > /dev/null 2>&1
-grep "^{" gpurun_out/${tag}_stats_A137.log | tail -1 > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_A137.json
 cp profiles/$JINC_PROFILE_DIR/${tag}_* gpurun_out/$JINC_PROFILE_DIR/ 2>/dev/null
 for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875; do
   timeout 120 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json

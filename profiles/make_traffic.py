@@ -21,7 +21,7 @@ out = {"_comment": "HBM bytes per launch of the dominant (interior) kernel from 
                    f"profiles/{rdir}/{tag}_c*.json (profiles/collect_round.sh). For C3/C4 a step has three launches (one per "
                    "plane); the figure is the mean over them, like roofline.algorithmic_bytes_per_launch. bench.py copies the "
                    "value for its config into roofline.traffic, scaled to the frames per launch of the run."}
-for cfg in ("C2", "C3", "C4"):
+for cfg in ("C2", "C3", "C4", "A137", "N15"):
     path = os.path.join(HERE, rdir, f"{tag}_{cfg.lower()}.json")
     if not os.path.exists(path):
         continue
