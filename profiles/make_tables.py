@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Prints the Markdown table of BASELINE.md section 6 from the bench lines of a round: make_tables.py round2 r2v"""
+import glob, json, os, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+rdir, tag = sys.argv[1], sys.argv[2]
+order = ["C2", "C1", "C3", "C4", "A137", "A1875", "N15", "N3", "U43", "N480", "N15T4", "N15T8", "D169", "D12", "D23", "D13", "D12H", "D12F",
+         "D12T4", "D12T8", "T6", "T16"]
+print("| config (frames per step) | GPU Mpix/s | of the VALU ceiling | HBM fraction (algorithmic bytes) | interior kernel |")
+print("|---|---|---|---|---|")
+for c in order:
+    p = os.path.join(HERE, rdir, f"{tag}_bench_{c}.json")
+    if not os.path.exists(p):
+        continue
+    d = json.loads(open(p).read())
+    r, cfg = d["roofline"], d["config"]
+    print(f"| {cfg['workload']} ({cfg['frames_per_step_per_gpu']}) | {d['value']:,.0f} | {100 * r['valu_frac']:.1f} % | {100 * r['frac']:.1f} % | `{cfg['kernel']}` |")
