@@ -26,7 +26,6 @@ namespace {
 // (wide tiles) against the staged footprint per pixel.
 bool configure_tiles(const PlanePlan& p, const RectList& rects, int ps, size_t budget, int frames_per_group, int nframes_hint,
                      double col_weight, FrameLaneArgs& out) {
-    const int table_bytes = (2 * kFrameLaneMaxTile + kFrameLaneMaxTile * kFrameLaneMaxTile) * 4;
     const int groups = std::max(1, (nframes_hint + frames_per_group - 1) / frames_per_group);
 
     bool found = false, found_enough = false;
@@ -44,7 +43,7 @@ bool configure_tiles(const PlanePlan& p, const RectList& rects, int ps, size_t b
             }
             if (tiles <= 0 || tiles > (1ll << 30) || max_tw > 64) continue;
             // (+ 1 row: the sliding-window form pads the column pitch of its column-major tile to an odd number)
-            const size_t bytes = table_bytes + (static_cast<size_t>(max_tw) * (max_th + 1) + 8) * ps;
+            const size_t bytes = kFrameLaneTableBytes(tys) + (static_cast<size_t>(max_tw) * (max_th + 1) + 8) * ps;
             if (bytes > budget) continue;
             const double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty) + col_weight * max_tw / tx;
             const bool enough = tiles * groups >= 1024;  // >= 2 workgroups in flight per CU, twice over

@@ -211,8 +211,9 @@ __device__ __forceinline__ bool fl_win_step(float (&w)[FS][FS], const char*& pc,
     return true;
 }
 
+// (fs 8: 80 registers, so that three workgroups of a 53 KB tile share a CU: 6 waves per SIMD instead of 4)
 template <typename T, int FS>
-__global__ __launch_bounds__(512) void ewa_framelane_win_kernel(const FrameLaneArgs a) {
+__global__ __launch_bounds__(512, (FS == 8 ? 6 : 4)) void ewa_framelane_win_kernel(const FrameLaneArgs a) {
 #define JINC_FL_WIN_STAGE_FRAMES 8
 #include "kernel_framelane_win_body.inc"
 #undef JINC_FL_WIN_STAGE_FRAMES
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(512) void ewa_framelane_kernel(const FrameLaneArgs 
     int* cs = reinterpret_cast<int*>(fl_smem);  // window origin of the tile's columns
     int* rs = cs + kFrameLaneMaxTile;           // ... and rows
     int* sets = rs + kFrameLaneMaxTile;         // coefficient set of every pixel of the tile
-    char* tile = fl_smem + kFlTableInts * 4;
+    char* tile = fl_smem + kFrameLaneTableBytes(a.ty_shift);
     constexpr int PS = kFrameLanePosBytes(sizeof(T));
     constexpr int SB = static_cast<int>(sizeof(T));
 

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_pair_kernel(const FrameL
     int* cs = reinterpret_cast<int*>(fl_smem);
     int* rs = cs + kFrameLaneMaxTile;
     int* sets = rs + kFrameLaneMaxTile;
-    char* tile = fl_smem + kFlTableInts * 4;
+    char* tile = fl_smem + kFrameLaneTableBytes(a.ty_shift);
     constexpr int PS = kFrameLanePairPosBytes(sizeof(T));
     constexpr int SB = static_cast<int>(sizeof(T));
     constexpr uint32_t kSetBytes = FS * padded_row(FS) * 4;

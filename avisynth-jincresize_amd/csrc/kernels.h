@@ -185,6 +185,9 @@ int launch_colstrip(const ColStripArgs& args, const PlaneIO& io, void* stream);
 // Frame-lane kernel (kernel_framelane.hip): batches of frames, any plan.  The 64 lanes of a wave are the same output
 // pixel of 64 different frames, so coefficients are wave-uniform (SGPRs) whatever the plan's structure.
 constexpr int kFrameLaneMaxTile = 32;  // output tile edge limit
+// LDS bytes of a workgroup's tables in front of its tile: window origins of the tile's columns and rows, and the coefficient
+// set of every pixel (row pitch kFrameLaneMaxTile) for the tile's (1 << ty_shift) rows.
+constexpr int kFrameLaneTableBytes(int ty_shift) { return (2 * kFrameLaneMaxTile + kFrameLaneMaxTile * (1 << ty_shift)) * 4; }
 constexpr int kFrameLanePosBytes(size_t sample_bytes) { return static_cast<int>(64 * sample_bytes + 4); }  // LDS bytes per source position
 // Frame-pair form (kernel_framelane_pair.hip): 128 frames per workgroup, a lane owns two adjacent frames; 8-byte pad for
 // float planes keeps a lane's pair 8-byte aligned at every position.
