@@ -24,7 +24,21 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     const int sb = f.vi_in.component_size;
     // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
     // kernel wherever it applies (also for exactly periodic plans)
+    // Calls of fewer than ~3e6 output samples (one 1080p frame, two 960 x 540 frames) leave the quasi-periodic kernel with a
+    // few dozen workgroups of long serial phase loops even after the phase split below; the gather kernel's many small
+    // blocks finish sooner: one frame per call 4/3x 45 -> 68 Gpix/s, 4/3x with tap 4 37 -> 46, 960 x 540 at 1.5x 16.5 -> 28
+    // (two frames: 33 -> 44), 5/4x and 1.5x at 1080p equal; 1.5x with tap 4 loses 11 % (45 -> 40).
+    double call_samples = 0.0;
+    for (int i = 0; i < f.planecount; ++i) {
+        const DeviceTable& t = f.tables[f.table_of_plane(i)];
+        call_samples += static_cast<double>(t.plan.dst_w) * t.plan.dst_h;
+    }
+    call_samples *= nframes;
+    auto quasi_declined = [&](const DeviceTable& t) {  // (... in favour of the gather kernel, not of the direct kernel)
+        return f.kernel_mode == 0 && call_samples < 3.0e6 && t.use_quasi && !t.use_periodic;
+    };
     auto wants_quasi = [&](const DeviceTable& t) {
+        if (quasi_declined(t)) return false;
         return t.use_quasi && (f.kernel_mode == 7 || f.kernel_mode == 8 || f.kernel_mode == 10 || (f.kernel_mode != 1 && !t.use_periodic));
     };
     auto wants_periodic = [&](const DeviceTable& t) {
@@ -39,7 +53,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     // kernel_mode 9: the direct kernel wherever it applies; otherwise it takes the interior of the exactly periodic
     // plans the register/LDS kernels do not cover.
     auto wants_direct = [&](const DeviceTable& t, int i) {
-        if (!direct_ok(t, i)) return false;
+        if (!direct_ok(t, i) || quasi_declined(t)) return false;
         return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
     };
     // Frame-lane kernel (lanes = frames): the choice for batches whose plan has no phase structure for the other

@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default per config)")
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="C2", choices=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
