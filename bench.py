@@ -229,11 +229,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default per config)")
-    ap.add_argument("--config", default="C2", choices=None)
+    ap.add_argument("--config", default="C2", help="one of CONFIGS (scripts may add entries before calling main())")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
     args = ap.parse_args()
+    if args.config not in CONFIGS:
+        ap.error(f"unknown --config {args.config}; choose from {', '.join(sorted(CONFIGS))}")
 
     import torch
     import torch.distributed as dist
