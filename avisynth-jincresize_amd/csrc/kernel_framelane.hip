@@ -26,6 +26,8 @@
 //     compile-time constants whatever the geometry -- only scalar addresses and wave-uniform branches are run-time.
 //   * The 4 horizontally adjacent results of a lane are packed and stored with one 4-sample store per row (a lane
 //     writes to its own frame: 64 different cache lines per store instruction, so bytes per store matter).
+//   * Whole groups of 128 frames of filter sizes 5 and 7 run on kernel_framelane_pair.hip instead (two frames per lane);
+//     the pieces both share -- tile location, per-tile tables, staging, packed stores -- are kernel_framelane_common.inc.
 #include <atomic>
 
 #include "device_common.hpp"
