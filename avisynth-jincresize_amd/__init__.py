@@ -81,6 +81,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
+           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_debug_last_call",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
 
@@ -110,6 +111,11 @@ def lib():
         L.jinc_filter_process_device.argtypes = [C.c_void_p, _P4, _I4, _S4, _P4, _I4, _S4, C.c_int, C.c_void_p]
         L.jinc_filter_sync.argtypes = [C.c_void_p]
         L.jinc_filter_set_pipeline.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.jinc_filter_set_pipeline_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.jinc_filter_pipeline_group.argtypes = [C.c_void_p]
+        L.jinc_filter_flush.argtypes = [C.c_void_p]
+        L.jinc_debug_last_call.argtypes = [C.POINTER(C.c_int)]
+        L.jinc_debug_last_call.restype = C.c_char_p
         L.jinc_filter_submit.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4, C.POINTER(C.c_longlong)]
         L.jinc_filter_wait.argtypes = [C.c_void_p, C.c_longlong]
         L.jinc_alias_args.argtypes = [C.c_int, C.POINTER(Args), C.POINTER(Args)]
@@ -149,6 +155,13 @@ def lib():
 
 def device_count() -> int:
     return int(lib().jinc_device_count())
+
+
+def last_call() -> Tuple[str, int]:
+    """(interior kernel of table 0, frames) of the most recent kernel call of any filter instance in this process (test hook)."""
+    n = C.c_int()
+    name = lib().jinc_debug_last_call(C.byref(n))
+    return (name or b"").decode(), n.value
 
 
 def set_direct_shape(shape: int) -> None:
@@ -392,8 +405,17 @@ class Filter:
         return outs
 
     # -- look-ahead pipeline: several frames in flight per instance --
-    def set_pipeline(self, depth: int, register_host_buffers: bool = False) -> None:
-        self._check(lib().jinc_filter_set_pipeline(self._h, int(depth), int(register_host_buffers)))
+    def set_pipeline(self, depth: int, register_host_buffers: bool = False, group: int = 0) -> None:
+        """Up to `depth` frames in flight; `group` of them coalesced into one launch (0: automatic = depth / 2)."""
+        self._check(lib().jinc_filter_set_pipeline_group(self._h, int(depth), int(group), int(register_host_buffers)))
+
+    @property
+    def pipeline_group(self) -> int:
+        return int(lib().jinc_filter_pipeline_group(self._h))
+
+    def flush(self) -> None:
+        """Launch the frames submitted so far (a client that knows no more are coming)."""
+        self._check(lib().jinc_filter_flush(self._h))
 
     def submit(self, src_planes: Sequence[np.ndarray], dst_planes: Sequence[np.ndarray]) -> int:
         """Enqueue one frame; dst_planes (from alloc_plane) are filled when wait(ticket) returns."""

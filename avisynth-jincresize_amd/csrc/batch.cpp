@@ -3,9 +3,10 @@
 //
 // Frames are independent units (JincResize_GetFrame touches frame n only, ref /root/reference/src/JincResize.cpp:603-630)
 // and the plan is read-only, so the shard needs no exchange between devices: frame n goes to device n mod G; every
-// device owns a replica of the plan (one jinc_filter) with `streams` frames in flight (the look-ahead pipeline of
-// filter.cpp: per-slot device buffers and streams), driven by one host thread per device.  No RCCL, no peer traffic.
-// Built on the public C ABI only (jinc_filter_create / _set_pipeline / _submit / _wait).
+// device owns a replica of the plan (one jinc_filter) with `streams` frames in flight through the look-ahead pipeline of
+// pipeline.cpp -- which coalesces them into groups of streams / 2 frames per launch, so a device's share of the clip runs
+// on the batch kernels -- driven by one host thread per device.  No RCCL, no peer traffic.
+// Built on the public C ABI only (jinc_filter_create / _set_pipeline / _submit / _flush / _wait).
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -47,8 +48,8 @@ int jinc_batch_create(const jinc_video_info* vi, const jinc_args* args, int ndev
     const int avail = jinc_device_count();
     if (avail <= 0) return batch_fail(JINC_ERR_NO_DEVICE, "JincResize: no HIP device available.", err, err_len);
     if (ndevices <= 0 || ndevices > avail) ndevices = avail;
-    if (streams_per_device < 1 || streams_per_device > 16)
-        return batch_fail(JINC_ERR_INVALID_ARG, "JincResize: streams per device must be 1..16.", err, err_len);
+    if (streams_per_device < 1 || streams_per_device > 256)
+        return batch_fail(JINC_ERR_INVALID_ARG, "JincResize: frames in flight per device must be 1..256.", err, err_len);
     jinc_batch* b = new (std::nothrow) jinc_batch();
     if (!b) return batch_fail(JINC_ERR_NOMEM, "JincResize: out of memory.");
     b->streams = streams_per_device;
@@ -122,6 +123,7 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
             rc = jinc_filter_submit(f, s, src_pitch, t, dst_pitch, &ticket);
             if (rc == JINC_OK) tickets.push_back(ticket);
         }
+        if (rc == JINC_OK) rc = jinc_filter_flush(f);  // the device's last frames do not wait for company
         while (!tickets.empty()) {  // drain, also after an error: buffers must not be in use when we return
             const int w = wait_oldest();
             if (rc == JINC_OK) rc = w;

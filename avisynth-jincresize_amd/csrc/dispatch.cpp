@@ -9,6 +9,47 @@ namespace jinc {
 namespace host {
 
 namespace {
+// Cross-over points of the automatic kernel choice, each from a measurement on MI355X (file under profiles/):
+struct Rules {
+    // calls below this many output samples of plans the quasi-periodic kernel owns go to the gather kernel
+    // (round2/single_frame_rates.log: 4/3x one frame per call 45 -> 68 Gpix/s)
+    static constexpr double kQuasiMinSamples = 3.0e6;
+    // border kernels move to the side stream from this many taps per call (experiments/overlap_small_batches.sh)
+    static constexpr double kOverlapMinTaps = 1.0e9;
+    // frame-lane forms against the single-frame kernels (round2/fl_threshold.log): gather-kernel plans from
+    // kFrameLaneMinFrames (16) frames, filter sizes above 9 from 24, drifting plans with more than 16 phases from 36,
+    // drifting fs-9 / fs-7 plans with a source step of 2 from 48 / 64
+    static constexpr int kFrameLaneMinFramesBigFs = 24;
+    static constexpr int kFrameLaneMinFramesManyPhases = 36;
+    static constexpr int kFrameLaneMinFramesStep2Fs9 = 48;
+    static constexpr int kFrameLaneMinFramesStep2Fs7 = 64;
+    // window kernels take half-height tiles below this many workgroups per launch (round2 small-call rules)
+    static constexpr long long kHalfTileMaxWorkgroups = 6144;
+    // workgroups a quasi-periodic launch aims for when it splits a tile's phases (fs 9 tiles cost more to stage)
+    static constexpr long long kQuasiSplitTarget = 1024, kQuasiSplitTargetFs9 = 400;
+};
+
+// Everything the launches below assume about the caller's planes, checked BEFORE anything is queued: an error on plane 2
+// must not leave plane 0's border kernels running on the side stream with no join recorded.
+void validate_planes(const jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
+                     void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes) {
+    const int sb = f.vi_in.component_size;
+    for (int i = 0; i < f.planecount; ++i) {
+        const DeviceTable& t = f.tables[f.table_of_plane(i)];
+        if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
+        if (src_pitch[i] % sb || dst_pitch[i] % sb) throw ArgError("JincResize: plane pitch is not a multiple of the sample size.");
+        if (reinterpret_cast<uintptr_t>(src[i]) % sb || reinterpret_cast<uintptr_t>(dst[i]) % sb)
+            throw ArgError("JincResize: plane pointer is not aligned to the sample size.");
+        if (src_fs && nframes > 1 && src_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
+        if (dst_fs && nframes > 1 && dst_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
+        if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(t.plan.src_w) * sb ||
+            static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(t.plan.dst_w) * sb)
+            throw ArgError("JincResize: plane pitch is smaller than the row size.");
+        if (static_cast<uint64_t>(dst_pitch[i]) * t.plan.dst_h >= (1ull << 32))
+            throw ArgError("JincResize: destination plane larger than 4 GiB is not supported (32-bit store offsets).");
+    }
+}
+
 // A/B knob JINC_QUASI_SPLIT: workgroups per tile of the quasi-periodic kernel (0 / 1: no split); read once.
 int quasi_split_knob() {
     static const int v = [] {
@@ -19,8 +60,29 @@ int quasi_split_knob() {
 }
 }  // namespace
 
+namespace {
+void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4], void* const dst[4],
+                 const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream, bool may_split);
+// test hook (jinc_debug_last_call): interior kernel of table 0 and frame count of the most recent enqueue in this process,
+// for callers that cannot reach the filter handle (the plugin shell's instances)
+std::atomic<const char*> g_last_interior_kernel{""};
+std::atomic<int> g_last_call_frames{0};
+}
+
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
              void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream) {
+    validate_planes(f, src, src_pitch, src_fs, dst, dst_pitch, dst_fs, nframes);
+    enqueue_run(f, src, src_pitch, src_fs, dst, dst_pitch, dst_fs, nframes, stream, true);
+    g_last_interior_kernel.store(f.tables[0].last_kernel, std::memory_order_relaxed);
+    g_last_call_frames.store(nframes, std::memory_order_relaxed);
+}
+
+const char* last_interior_kernel_in_process() { return g_last_interior_kernel.load(std::memory_order_relaxed); }
+int last_call_frames_in_process() { return g_last_call_frames.load(std::memory_order_relaxed); }
+
+namespace {
+void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4], void* const dst[4],
+                 const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream, bool may_split) {
     const int sb = f.vi_in.component_size;
     // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
     // kernel wherever it applies (also for exactly periodic plans)
@@ -35,7 +97,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     }
     call_samples *= nframes;
     auto quasi_declined = [&](const DeviceTable& t) {  // (... in favour of the gather kernel, not of the direct kernel)
-        return f.kernel_mode == 0 && call_samples < 3.0e6 && t.use_quasi && !t.use_periodic;
+        return f.kernel_mode == 0 && call_samples < Rules::kQuasiMinSamples && t.use_quasi && !t.use_periodic;
     };
     auto wants_quasi = [&](const DeviceTable& t) {
         if (quasi_declined(t)) return false;
@@ -67,18 +129,41 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         // kernels, measured (profiles/round2/fl_threshold.log): against the gather kernel 11 frames for 1.37x, 14 for the
         // 5/6 down-scale, 21 for 1.5x with tap 8 (row-segment form); against the quasi-periodic kernel 33 frames for DVD ->
         // 1080p (72 phases), 42 for 1.5x with tap 4, ~50 for 1.5x
-        if (nframes < (t.plan.fs > 9 ? 24 : kFrameLaneMinFrames)) return false;
+        if (nframes < (t.plan.fs > 9 ? Rules::kFrameLaneMinFramesBigFs : kFrameLaneMinFrames)) return false;
         if (wants_periodic(t)) return false;
         if (wants_quasi(t)) {
             // whole groups of 128 frames: the frame-pair form is ahead of the quasi-periodic kernel on every plan measured
             // (256 frames: 1.5x 62 against 52 % of the VALU peak, 3x 69 against 68 %, 4/3x 60 against 54 %)
             if (t.use_framelane_pair && nframes >= jinc::kFrameLanePairFrames) return true;
             if (f.plans[f.table_of_plane(i)].periodic) return false;
-            if (t.quasi.px * t.quasi.py > 16 && nframes >= 36) return true;
-            return (t.plan.fs == 7 || t.plan.fs == 9) && t.quasi.sx >= 2 && t.quasi.sy >= 2 && nframes >= (t.plan.fs == 9 ? 48 : 64);
+            if (t.quasi.px * t.quasi.py > 16 && nframes >= Rules::kFrameLaneMinFramesManyPhases) return true;
+            return (t.plan.fs == 7 || t.plan.fs == 9) && t.quasi.sx >= 2 && t.quasi.sy >= 2 &&
+                   nframes >= (t.plan.fs == 9 ? Rules::kFrameLaneMinFramesStep2Fs9 : Rules::kFrameLaneMinFramesStep2Fs7);
         }
         return !wants_direct(t, i);
     };
+    // A batch of 128 k + r frames whose whole groups of 128 go to the frame-pair form: the r frames left over are a call of
+    // their own, chosen by the same rules with their own frame count (as a 64-frame frame-lane launch a
+    // remainder of 1..15 frames cost as much as 64 frames; 129 frames took ~1.5 x the time of 128).
+    if (may_split && f.kernel_mode == 0 && f.simd_order == 0 && nframes > jinc::kFrameLanePairFrames && nframes % jinc::kFrameLanePairFrames != 0) {
+        bool pair_somewhere = false;
+        for (int i = 0; i < f.planecount; ++i) {
+            const DeviceTable& t = f.tables[f.table_of_plane(i)];
+            pair_somewhere |= t.use_framelane_pair && wants_framelane(t, i);
+        }
+        if (pair_somewhere) {
+            const int whole = nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames;
+            const void* s2[4] = {nullptr, nullptr, nullptr, nullptr};
+            void* d2[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int i = 0; i < f.planecount; ++i) {
+                s2[i] = static_cast<const char*>(src[i]) + static_cast<size_t>(whole) * src_fs[i];
+                d2[i] = static_cast<char*>(dst[i]) + static_cast<size_t>(whole) * dst_fs[i];
+            }
+            enqueue_run(f, src, src_pitch, src_fs, dst, dst_pitch, dst_fs, whole, stream, false);
+            enqueue_run(f, s2, src_pitch, src_fs, d2, dst_pitch, dst_fs, nframes - whole, stream, false);
+            return;
+        }
+    }
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
@@ -97,7 +182,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
             const DeviceTable& t = f.tables[f.table_of_plane(i)];
             taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
         }
-        want_overlap = taps * nframes >= 1e9;
+        want_overlap = taps * nframes >= Rules::kOverlapMinTaps;
     }
     const bool fork = any_periodic && want_overlap;
     if (fork) {  // border work may start once everything already queued on `stream` is done
@@ -107,17 +192,6 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     hipStream_t border_stream = fork ? f.aux_stream : stream;
     for (int i = 0; i < f.planecount; ++i) {
         DeviceTable& t = f.tables[f.table_of_plane(i)];
-        if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
-        if (src_pitch[i] % sb || dst_pitch[i] % sb) throw ArgError("JincResize: plane pitch is not a multiple of the sample size.");
-        if (reinterpret_cast<uintptr_t>(src[i]) % sb || reinterpret_cast<uintptr_t>(dst[i]) % sb)
-            throw ArgError("JincResize: plane pointer is not aligned to the sample size.");
-        if (src_fs && nframes > 1 && src_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
-        if (dst_fs && nframes > 1 && dst_fs[i] % sb) throw ArgError("JincResize: frame stride is not a multiple of the sample size.");
-        if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(t.plan.src_w) * sb ||
-            static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(t.plan.dst_w) * sb)
-            throw ArgError("JincResize: plane pitch is smaller than the row size.");
-        if (static_cast<uint64_t>(dst_pitch[i]) * t.plan.dst_h >= (1ull << 32))
-            throw ArgError("JincResize: destination plane larger than 4 GiB is not supported (32-bit store offsets).");
         jinc::PlaneIO io;
         io.src = src[i];
         io.dst = dst[i];
@@ -241,7 +315,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                         const int tile_rows = qa.rg * t.plan.fs;
                         const long long wgs = static_cast<long long>((qa.ni + 63) / 64) * ((qa.nj + tile_rows - 1) / tile_rows) * nframes;
                         const int per_wave = (qa.px * qa.py + qa.nwaves - 1) / std::max(1, qa.nwaves);
-                        const long long target = t.plan.fs == 9 ? 400 : 1024;
+                        const long long target = t.plan.fs == 9 ? Rules::kQuasiSplitTargetFs9 : Rules::kQuasiSplitTarget;
                         int split = wgs > 0 ? static_cast<int>((target + wgs - 1) / wgs) : 1;
                         qa.phase_split = std::max(1, std::min(split, per_wave));
                         if (quasi_split_knob() >= 0) qa.phase_split = std::max(1, std::min(quasi_split_knob(), per_wave));
@@ -257,7 +331,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
                     if (f.kernel_mode == 0 && (t.plan.fs == 7 || t.plan.fs == 9)) {
                         const int rows = t.plan.fs * (t.plan.fs == 7 ? 8 : 9);  // period-rows of a full tile
                         const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + rows - 1) / rows) * nframes;
-                        if (wgs < 6144) variant = 2;
+                        if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
                     }
                     return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);
                 });
@@ -271,6 +345,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
         hip_check(hipStreamWaitEvent(stream, f.ev_join, 0), "hipStreamWaitEvent(join)");
     }
 }
+}  // namespace
 
 }  // namespace host
 }  // namespace jinc

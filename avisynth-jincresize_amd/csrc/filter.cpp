@@ -107,36 +107,26 @@ int jinc_filter_get_frame(jinc_filter* f, const void* const src[4], const int sr
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        for (auto& s : f->slots)  // a synchronous frame must not overtake frames still in the pipeline
-            if (s.busy) {
-                hip_check(hipStreamSynchronize(s.stream), "stream sync");
-                s.busy = false;
-            }
-        DeviceFrameBuf& s = f->slots[0];
-        ensure_slot(*f, s, false);
-        submit_frame(*f, s, src, src_pitch, dst, dst_pitch);
-        hip_check(hipStreamSynchronize(s.stream), "stream sync");
+        drain_pipeline(*f);  // a synchronous frame must not overtake frames still in the pipeline
+        wait_frame(*f, submit_frame(*f, src, src_pitch, dst, dst_pitch));
+    });
+}
+
+int jinc_filter_set_pipeline_group(jinc_filter* f, int depth, int group, int register_host_buffers) {
+    if (!f || depth < 1 || depth > kMaxPipelineDepth) return fail(JINC_ERR_INVALID_ARG, "JincResize: pipeline depth must be 1..256.");
+    if (group < 0 || group > depth) return fail(JINC_ERR_INVALID_ARG, "JincResize: frames per launch must be 0 (automatic) .. depth.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        configure_pipeline(*f, depth, group, register_host_buffers != 0);
     });
 }
 
 int jinc_filter_set_pipeline(jinc_filter* f, int depth, int register_host_buffers) {
-    if (!f || depth < 1 || depth > 16) return fail(JINC_ERR_INVALID_ARG, "JincResize: pipeline depth must be 1..16.");
-    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
-    return guarded([&] {
-        hip_check(hipSetDevice(f->device), "hipSetDevice");
-        for (auto& s : f->slots)
-            if (s.busy) {
-                hip_check(hipStreamSynchronize(s.stream), "stream sync");
-                s.busy = false;
-            }
-        if (static_cast<size_t>(depth) > f->slots.size()) f->slots.resize(depth);
-        f->register_host = register_host_buffers != 0;
-        if (!f->register_host) {
-            for (auto& p : f->pinned) (void)hipHostUnregister(p.base);
-            f->pinned.clear();
-        }
-    });
+    return jinc_filter_set_pipeline_group(f, depth, 0, register_host_buffers);
 }
+
+int jinc_filter_pipeline_group(const jinc_filter* f) { return f ? f->group_frames : 0; }
 
 int jinc_filter_submit(jinc_filter* f, const void* const src[4], const int src_pitch[4], void* const dst[4],
                        const int dst_pitch[4], long long* ticket) {
@@ -144,19 +134,16 @@ int jinc_filter_submit(jinc_filter* f, const void* const src[4], const int src_p
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        const long long t = f->next_ticket;
-        const size_t k = static_cast<size_t>(t % static_cast<long long>(f->slots.size()));
-        DeviceFrameBuf& s = f->slots[k];
-        ensure_slot(*f, s, k != 0);
-        if (s.busy) {  // the slot's previous frame has to be finished before its buffers are reused
-            hip_check(hipStreamSynchronize(s.stream), "stream sync");
-            s.busy = false;
-        }
-        submit_frame(*f, s, src, src_pitch, dst, dst_pitch);
-        s.busy = true;
-        s.ticket = t;
-        *ticket = t;
-        ++f->next_ticket;
+        *ticket = submit_frame(*f, src, src_pitch, dst, dst_pitch);
+    });
+}
+
+int jinc_filter_flush(jinc_filter* f) {
+    if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        if (f->open_group >= 0) launch_open_group(*f);
     });
 }
 
@@ -165,13 +152,7 @@ int jinc_filter_wait(jinc_filter* f, long long ticket) {
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        for (auto& s : f->slots)
-            if (s.busy && s.ticket == ticket) {
-                hip_check(hipStreamSynchronize(s.stream), "stream sync");
-                s.busy = false;
-                return;
-            }
-        // unknown or already completed ticket: nothing to wait for (its slot has been reused or waited on)
+        wait_frame(*f, ticket);
     });
 }
 
@@ -195,6 +176,7 @@ int jinc_filter_sync(jinc_filter* f) {
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
+        drain_pipeline(*f);
         hip_check(hipStreamSynchronize(f->stream), "stream sync");
     });
 }
@@ -381,6 +363,11 @@ int jinc_debug_last_direct_shape(void) { return jinc::last_direct_shape(); }
 const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {
     if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return "";
     return f->tables[table].last_kernel;
+}
+
+const char* jinc_debug_last_call(int* nframes) {
+    if (nframes) *nframes = last_call_frames_in_process();
+    return last_interior_kernel_in_process();
 }
 
 int jinc_filter_set_border_strips(jinc_filter* f, int enable) {

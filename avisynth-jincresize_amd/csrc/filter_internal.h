@@ -68,25 +68,68 @@ struct EventPair {
     hipEvent_t start = nullptr, stop = nullptr;
 };
 
-struct DeviceFrameBuf {  // device staging planes of one in-flight frame (host-pointer entry points)
-    void* src[4] = {nullptr, nullptr, nullptr, nullptr};
+// Frames in flight (pipeline.cpp).  A group is a run of consecutively submitted frames that share ONE strided device
+// buffer per plane and ONE set of kernel launches (enqueue(..., nframes = frames.size(), ...)).  Three conveyor belts, each
+// a stream that carries one kind of work for ALL groups in submission order:
+//   h2d_stream   one DMA copy per plane and frame, queued at submit            -> event h2d_ready (per group)
+//   f.stream     the resampling kernels of a group behind its h2d_ready         -> event kernels_done (per group)
+//   d2h_stream   the group's results to the callers' planes behind kernels_done -> events done[] (per share / per frame)
+// so that group j's results travel while group j + 1 is computed and group j + 2 arrives.  Results travel by the shader
+// (kernel_blit.hip: one launch per share of the group, straight into the pinned host planes) when every destination plane
+// of the group is pinned, else by one DMA copy per plane and frame.  One belt per kind of work keeps the stages in order:
+// with a stream per group, the transports of two groups ran side by side, finished together, released two groups' worth
+// of submissions at once and the pipeline fell into a two-phase rhythm (profiles/round3/e2e_pipeline_*.log).
+// The two event hops between the belts cost ~0.2 ms of latency per group (measured: C2 at one frame per launch 5 600 ->
+// 2 700 frames/s), so groups of fewer than kBeltMinGroup frames keep the round-2 shape instead: a stream per group that
+// carries its copies, kernels and results in order, no events; consecutive groups overlap because their streams differ.
+constexpr int kBeltMinGroup = 8;
+constexpr int kGroupShares = 4;  // completion granularity of a group whose results travel by the shader
+
+struct GroupFrame {
+    void* dst[4] = {nullptr, nullptr, nullptr, nullptr};      // host destination planes
+    void* dst_dev[4] = {nullptr, nullptr, nullptr, nullptr};  // their device mapping (pinned), or nullptr
+    int dst_pitch[4] = {0, 0, 0, 0};
+    long long ticket = -1;
+    int done_event = -1;  // index into FrameGroup::done, set at launch
+};
+
+struct FrameGroup {
+    void* src[4] = {nullptr, nullptr, nullptr, nullptr};  // device planes of `capacity` frames, frame stride *_fs
     void* dst[4] = {nullptr, nullptr, nullptr, nullptr};
     int src_pitch[4] = {0, 0, 0, 0};
     int dst_pitch[4] = {0, 0, 0, 0};
-    hipStream_t stream = nullptr;  // slot 0 uses the filter's stream, further slots own theirs
-    bool ready = false;
-    bool busy = false;             // work enqueued and not yet waited for
-    long long ticket = -1;
+    size_t src_fs[4] = {0, 0, 0, 0};
+    size_t dst_fs[4] = {0, 0, 0, 0};
+    int capacity = 0;
+    hipStream_t own_stream = nullptr;  // small groups: everything of the group in order on this stream
+    hipEvent_t h2d_ready = nullptr, kernels_done = nullptr;
+    jinc::BlitEntry* table = nullptr;  // [capacity x planes], pinned host memory the device reads (hipHostMalloc)
+    std::vector<hipEvent_t> done;    // [capacity]
+    std::vector<GroupFrame> frames;  // frames of the current use of the buffer, in submission order
+    enum State { Idle, Filling, Launched, Failed } state = Idle;
+    std::string error;               // Failed: what the launch reported (handed to every wait on its frames)
 };
 
 struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-ahead pipeline, opt-in)
     char* base = nullptr;
     size_t bytes = 0;
+    char* dev = nullptr;    // the range's address in the device's address space (hipHostGetDevicePointer), or nullptr
     unsigned long long stamp = 0;
     long long ticket = -1;  // latest frame whose copies use this range (may still be in flight)
 };
 
+// Upper limits of the look-ahead pipeline: frames in flight per instance, and the device memory its staging may take.
+constexpr int kMaxPipelineDepth = 256;
+constexpr size_t kPipelineBudgetBytes = size_t(24) << 30;
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace host
+}  // namespace jinc
+struct jinc_filter;
+namespace jinc {
+namespace host {
+void release_pipeline(jinc_filter& f);  // pipeline.cpp: waits for the frames in flight, frees group buffers, events and copy lanes
 
 // Smallest batch the frame-lane kernel takes over from the gather kernel: its lanes are the frames of the batch, so a
 // batch of n < 64 frames fills n of 64 lanes.
@@ -114,7 +157,13 @@ struct jinc_filter {
     int device = -1;  // -1: host-only instance (plan inspection); frame calls fail
     hipStream_t stream = nullptr;
     std::vector<jinc::host::DeviceTable> tables;
-    std::vector<jinc::host::DeviceFrameBuf> slots = std::vector<jinc::host::DeviceFrameBuf>(1);  // frames in flight (pipeline depth)
+    int pipeline_depth = 1;   // frames the client keeps in flight (jinc_filter_set_pipeline)
+    int group_frames = 1;     // frames coalesced into one launch
+    std::vector<jinc::host::FrameGroup> groups = std::vector<jinc::host::FrameGroup>(1);  // ring of group buffers
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;  // belts for groups of >= kBeltMinGroup frames (else nullptr)
+    int transport = -1;       // results to the host: -1 automatic (shader when pinned), 0 DMA copies always (A/B, JINC_PIPELINE_DMA=1)
+    int open_group = -1;      // index of the group being filled, -1: none
+    int last_group = 0;       // most recently opened group (the ring advances from here)
     long long next_ticket = 0;
     bool register_host = false;
     std::vector<jinc::host::PinnedRange> pinned;
@@ -133,13 +182,7 @@ struct jinc_filter {
                 if (t.blob) (void)hipFree(t.blob);
                 for (void* b : t.lane_blobs) (void)hipFree(b);
             }
-            for (size_t s = 0; s < slots.size(); ++s) {
-                for (int i = 0; i < 4; ++i) {
-                    if (slots[s].src[i]) (void)hipFree(slots[s].src[i]);
-                    if (slots[s].dst[i]) (void)hipFree(slots[s].dst[i]);
-                }
-                if (s > 0 && slots[s].stream) (void)hipStreamDestroy(slots[s].stream);
-            }
+            jinc::host::release_pipeline(*this);
             for (auto& p : pinned) (void)hipHostUnregister(p.base);
             for (auto* v : {&ev_periodic, &ev_gather})
                 for (auto& e : *v) {
@@ -179,10 +222,14 @@ uint32_t direct_src_bytes(const void* base, uint64_t plane_bytes);
 // dispatch.cpp: kernel launches of one call (one plane loop) on `stream`
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4], void* const dst[4],
              const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream);
-// pipeline.cpp
-void ensure_slot(jinc_filter& f, DeviceFrameBuf& s, bool own_stream);
-void submit_frame(jinc_filter& f, DeviceFrameBuf& s, const void* const src[4], const int src_pitch[4], void* const dst[4],
-                  const int dst_pitch[4]);
+const char* last_interior_kernel_in_process();
+int last_call_frames_in_process();
+// pipeline.cpp: frames in flight on one instance
+void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host);  // drains first
+long long submit_frame(jinc_filter& f, const void* const src[4], const int src_pitch[4], void* const dst[4], const int dst_pitch[4]);
+void wait_frame(jinc_filter& f, long long ticket);  // flushes the open group if the frame is in it
+void launch_open_group(jinc_filter& f);             // the frames submitted so far leave now (a client that knows no more are coming)
+void drain_pipeline(jinc_filter& f);                // every submitted frame complete
 
 }  // namespace host
 }  // namespace jinc

@@ -227,6 +227,21 @@ int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* s
 // 2 = AVX2, 3 = AVX-512; min_val = lower clamp of float source samples of this plane.
 int launch_simd_order(const DevicePlan& plan, const PlaneIO& io, int order, float min_val, void* stream);
 
+// Frame transport by the shader (kernel_blit.hip): entry = one plane of one frame, `rows` rows of `row_bytes` bytes from
+// src (pitch src_pitch) to dst (pitch dst_pitch); either side may be host memory mapped into the device's address space.
+// unit = 16 / 4 / 1: widest access both pointers and pitches allow (blit_unit).  The table lives in memory the device can
+// read (the pipeline keeps it in pinned host memory); one launch moves entries [first, first + count).
+struct BlitEntry {
+    const void* src = nullptr;
+    void* dst = nullptr;
+    uint32_t src_pitch = 0, dst_pitch = 0, row_bytes = 0, rows = 0, unit = 1, pad = 0;
+};
+int blit_unit(const void* src, const void* dst, uint32_t src_pitch, uint32_t dst_pitch);
+// max_rows / max_row_bytes: the largest plane among the entries (work is cut into slices of ~64 KB of rows); workgroups:
+// how many run at once (the link bounds the kernel, the rest of the chip stays free for the resampling kernels).
+int launch_blit_rows(const BlitEntry* table_device, int first, int count, uint32_t max_rows, uint32_t max_row_bytes, int workgroups,
+                     void* stream);
+
 // Test hook: applies the kernels' float -> sample conversion (clamp, round-half-even, store) to n sums.
 int launch_debug_convert(const float* in, void* out, int n, int sample_bytes, float peak, void* stream);
 

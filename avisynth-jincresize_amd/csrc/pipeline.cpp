@@ -1,94 +1,403 @@
-// pipeline.cpp -- frames in flight on one filter instance: device staging slots, pinned host ranges, and the
-// H2D -> kernels -> D2H sequence of one frame (frame transport around GetFrame).
+// pipeline.cpp -- frames in flight on one filter instance (frame transport around GetFrame).
+//
+// The reference's surface is per frame (JincResize_GetFrame handles frame n only, ref /root/reference/src/JincResize.cpp:603-630)
+// and stays that way: jinc_filter_submit / _wait / _get_frame take and complete single frames.  What happens in between is
+// coalesced: consecutively submitted frames are staged into ONE strided device buffer per plane (a FrameGroup) and leave
+// as ONE enqueue(..., nframes = k, ...) -- so the batch kernels of dispatch.cpp (frame-lane / frame-pair forms, wide
+// tiles) serve the host-pointer entry points too.
+//   submit(frame)  H2D copy of the frame into slot k of the open group, queued at once; the group is launched when it
+//                  holds `group_frames` frames;
+//   launch         the kernels behind the group's copies, then the results to the callers' planes: by the shader straight
+//                  into the pinned host planes (kernel_blit.hip, kGroupShares launches + events per group) when every
+//                  destination plane is pinned, else one DMA copy per plane and frame with an event per frame;
+//   wait(ticket)   launches the open group early if the frame sits in it, then waits for that frame's event only;
+//   groups rotate through a ring of ceil(depth / group_frames) + 1 buffers; reusing a buffer waits for its previous use
+//   (back-pressure).  Streams: see FrameGroup in filter_internal.h (three belts: arrivals, kernels, departures).
+// Why the shader: one DMA copy per plane and frame costs ~17 us of engine turnaround besides the wire time (2 MB planes:
+// one every 60 us = 35 GB/s of the link's 52 GB/s); a single launch per share of the group has no per-frame cost.
+// Results do not depend on the grouping: frames are independent and every kernel computes a frame's samples the same way
+// whatever the batch size (tests/test_gpu_parity.py, tests/test_pipeline_groups.py).
+#include <cstdlib>
+
 #include "filter_internal.h"
 
 namespace jinc {
 namespace host {
 
-void ensure_slot(jinc_filter& f, DeviceFrameBuf& s, bool own_stream) {
-    if (s.ready) return;
+namespace {
+
+void release_group(FrameGroup& g) {  // (the belts are idle: callers drain first)
+    for (int i = 0; i < 4; ++i) {
+        if (g.src[i]) (void)hipFree(g.src[i]);
+        if (g.dst[i]) (void)hipFree(g.dst[i]);
+        g.src[i] = g.dst[i] = nullptr;
+    }
+    for (hipEvent_t e : g.done) (void)hipEventDestroy(e);
+    g.done.clear();
+    if (g.table) (void)hipHostFree(g.table);
+    g.table = nullptr;
+    if (g.own_stream) (void)hipStreamDestroy(g.own_stream);
+    g.own_stream = nullptr;
+    for (hipEvent_t* e : {&g.h2d_ready, &g.kernels_done}) {
+        if (*e) (void)hipEventDestroy(*e);
+        *e = nullptr;
+    }
+    g.capacity = 0;
+    g.frames.clear();
+    g.state = FrameGroup::Idle;
+}
+
+bool use_belts(const jinc_filter& f) { return f.group_frames >= kBeltMinGroup; }
+// Streams of a group's three kinds of work: the filter's belts, or the group's own stream for all three.
+hipStream_t h2d_of(const jinc_filter& f, const FrameGroup& g) { return g.own_stream ? g.own_stream : f.h2d_stream; }
+hipStream_t kernels_of(const jinc_filter& f, const FrameGroup& g) { return g.own_stream ? g.own_stream : f.stream; }
+hipStream_t d2h_of(const jinc_filter& f, const FrameGroup& g) { return g.own_stream ? g.own_stream : f.d2h_stream; }
+
+size_t staging_bytes_per_frame(const jinc_filter& f) {
     const int sb = f.vi_in.component_size;
+    size_t total = 0;
+    for (int i = 0; i < f.planecount; ++i) {
+        int sw, sh, dw, dh;
+        f.plane_dims(f.vi_in, i, sw, sh);
+        f.plane_dims(f.vi_out, i, dw, dh);
+        total += align_up(align_up(static_cast<size_t>(sw) * sb, 256) * sh, 256) + align_up(align_up(static_cast<size_t>(dw) * sb, 256) * dh, 256);
+    }
+    return total;
+}
+
+// Device buffers, stream, events and transport table of a group, for f.group_frames frames (allocated on first use).
+void ensure_group(jinc_filter& f, FrameGroup& g) {
+    if (g.capacity == f.group_frames) return;
+    release_group(g);
+    const int sb = f.vi_in.component_size;
+    const size_t cap = static_cast<size_t>(f.group_frames);
     try {
         for (int i = 0; i < f.planecount; ++i) {
             int sw, sh, dw, dh;
             f.plane_dims(f.vi_in, i, sw, sh);
             f.plane_dims(f.vi_out, i, dw, dh);
-            s.src_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(sw) * sb, 256));
-            s.dst_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(dw) * sb, 256));
-            hip_check(hipMalloc(&s.src[i], static_cast<size_t>(s.src_pitch[i]) * sh), "hipMalloc(src plane)");
-            hip_check(hipMalloc(&s.dst[i], static_cast<size_t>(s.dst_pitch[i]) * dh), "hipMalloc(dst plane)");
+            g.src_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(sw) * sb, 256));
+            g.dst_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(dw) * sb, 256));
+            g.src_fs[i] = align_up(static_cast<size_t>(g.src_pitch[i]) * sh, 256);
+            g.dst_fs[i] = align_up(static_cast<size_t>(g.dst_pitch[i]) * dh, 256);
+            hip_check(hipMalloc(&g.src[i], g.src_fs[i] * cap), "hipMalloc(src planes of a frame group)");
+            hip_check(hipMalloc(&g.dst[i], g.dst_fs[i] * cap), "hipMalloc(dst planes of a frame group)");
         }
-        if (own_stream)
-            hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
-        else
-            s.stream = f.stream;
+        if (use_belts(f)) {
+            hip_check(hipEventCreateWithFlags(&g.h2d_ready, hipEventDisableTiming), "hipEventCreate");
+            hip_check(hipEventCreateWithFlags(&g.kernels_done, hipEventDisableTiming), "hipEventCreate");
+        } else {
+            hip_check(hipStreamCreateWithFlags(&g.own_stream, hipStreamNonBlocking), "hipStreamCreate");
+        }
+        hip_check(hipHostMalloc(reinterpret_cast<void**>(&g.table), sizeof(jinc::BlitEntry) * cap * 4, hipHostMallocDefault),
+                  "hipHostMalloc(transport table)");
+        g.done.reserve(cap);
+        for (size_t k = 0; k < cap; ++k) {
+            hipEvent_t e = nullptr;
+            hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            g.done.push_back(e);
+        }
     } catch (...) {  // a later allocation failed: give back what this call allocated (the next call starts over)
-        for (int i = 0; i < 4; ++i) {
-            if (s.src[i]) (void)hipFree(s.src[i]);
-            if (s.dst[i]) (void)hipFree(s.dst[i]);
-            s.src[i] = s.dst[i] = nullptr;
-        }
+        release_group(g);
         throw;
     }
-    s.ready = true;
+    g.capacity = f.group_frames;
 }
 
-// Pins [p, p + bytes) once (cache keyed by address range, least recently used out) so that the async copies of the
-// pipeline really are asynchronous.  The cache holds at least every range the frames in flight can reference
-// (depth x planes x (src + dst)), and a range whose frame may still be in flight is never unregistered under its copy:
-// the owning slot's stream is drained first.  Failure to register is not an error: the copy takes the pageable path.
-namespace {
-void pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket) {
+// The group's previous use is over: every frame of it complete (or failed), the buffer free for the next run of frames.
+void finish_group(jinc_filter& f, FrameGroup& g) {
+    // Launched: the event of the group's last frame closes everything the group has queued (the departures belt is in
+    // order).  Filling / Failed: its arrivals may still be on the wire.
+    if (g.state == FrameGroup::Launched && !g.frames.empty())
+        hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames.back().done_event)]), "hipEventSynchronize(group done)");
+    else if (g.state != FrameGroup::Idle && h2d_of(f, g))
+        hip_check(hipStreamSynchronize(h2d_of(f, g)), "stream sync");
+}
+
+void retire_group(jinc_filter& f, FrameGroup& g) {
+    finish_group(f, g);
+    g.frames.clear();
+    g.error.clear();
+    g.state = FrameGroup::Idle;
+}
+
+int blit_workgroups() {  // A/B knob JINC_BLIT_WORKGROUPS (default 48)
+    static const int v = [] {
+        const char* e = std::getenv("JINC_BLIT_WORKGROUPS");
+        const int n = e ? std::atoi(e) : 0;
+        return n > 0 ? n : 48;
+    }();
+    return v;
+}
+
+int group_shares() {  // A/B knob JINC_GROUP_SHARES (default kGroupShares)
+    static const int v = [] {
+        const char* e = std::getenv("JINC_GROUP_SHARES");
+        const int n = e ? std::atoi(e) : 0;
+        return n > 0 ? n : kGroupShares;
+    }();
+    return v;
+}
+
+bool dma_forced() {
+    static const bool v = [] {
+        const char* e = std::getenv("JINC_PIPELINE_DMA");
+        return e && std::atoi(e) != 0;
+    }();
+    return v;
+}
+
+// Kernels of the group's frames in one call, then the results to the callers' planes and the events their waits block
+// on.  A failure marks the group Failed; every wait on one of its frames reports it.
+void launch_group(jinc_filter& f, FrameGroup& g) {
+    const int n = static_cast<int>(g.frames.size());
+    const int sb = f.vi_in.component_size;
+    const int planes = f.planecount;
+    if (f.open_group >= 0 && &g == &f.groups[static_cast<size_t>(f.open_group)]) f.open_group = -1;
+    try {
+        const bool belts = !g.own_stream;
+        hipStream_t d2h = d2h_of(f, g);
+        if (belts) {  // the kernels read what the arrivals belt has copied
+            hip_check(hipEventRecord(g.h2d_ready, f.h2d_stream), "hipEventRecord(arrivals)");
+            hip_check(hipStreamWaitEvent(f.stream, g.h2d_ready, 0), "hipStreamWaitEvent(arrivals)");
+        }
+        enqueue(f, g.src, g.src_pitch, g.src_fs, g.dst, g.dst_pitch, g.dst_fs, n, kernels_of(f, g));
+        if (belts) {  // the departures belt reads what the kernels have written
+            hip_check(hipEventRecord(g.kernels_done, f.stream), "hipEventRecord(kernels)");
+            hip_check(hipStreamWaitEvent(d2h, g.kernels_done, 0), "hipStreamWaitEvent(kernels)");
+        }
+        bool by_shader = f.transport != 0 && !dma_forced();
+        for (const GroupFrame& fr : g.frames)
+            for (int i = 0; i < planes; ++i) by_shader &= fr.dst_dev[i] != nullptr;
+        if (by_shader) {
+            uint32_t max_rows = 0, max_row_bytes = 0;
+            for (int k = 0; k < n; ++k)
+                for (int i = 0; i < planes; ++i) {
+                    int dw, dh;
+                    f.plane_dims(f.vi_out, i, dw, dh);
+                    const GroupFrame& fr = g.frames[static_cast<size_t>(k)];
+                    jinc::BlitEntry& e = g.table[static_cast<size_t>(k) * planes + i];
+                    e.src = static_cast<const char*>(g.dst[i]) + g.dst_fs[i] * k;
+                    e.dst = fr.dst_dev[i];
+                    e.src_pitch = static_cast<uint32_t>(g.dst_pitch[i]);
+                    e.dst_pitch = static_cast<uint32_t>(fr.dst_pitch[i]);
+                    e.row_bytes = static_cast<uint32_t>(dw) * sb;
+                    e.rows = static_cast<uint32_t>(dh);
+                    e.unit = static_cast<uint32_t>(jinc::blit_unit(e.src, e.dst, e.src_pitch, e.dst_pitch));
+                    max_rows = std::max(max_rows, e.rows);
+                    max_row_bytes = std::max(max_row_bytes, e.row_bytes);
+                }
+            // shares of the group, each one launch + one event: a client collecting frames in order gets the first ones
+            // while the later shares are still on the wire
+            const int shares = std::min(n, group_shares());
+            for (int s = 0; s < shares; ++s) {
+                const int k0 = n * s / shares, k1 = n * (s + 1) / shares;
+                hip_check(static_cast<hipError_t>(jinc::launch_blit_rows(g.table, k0 * planes, (k1 - k0) * planes, max_rows, max_row_bytes,
+                                                                         blit_workgroups(), d2h)),
+                          "transport kernel launch");
+                hip_check(hipEventRecord(g.done[static_cast<size_t>(s)], d2h), "hipEventRecord(share done)");
+                for (int k = k0; k < k1; ++k) g.frames[static_cast<size_t>(k)].done_event = s;
+            }
+        } else {
+            for (int k = 0; k < n; ++k) {
+                GroupFrame& fr = g.frames[static_cast<size_t>(k)];
+                for (int i = 0; i < planes; ++i) {
+                    int dw, dh;
+                    f.plane_dims(f.vi_out, i, dw, dh);
+                    hip_check(hipMemcpy2DAsync(fr.dst[i], fr.dst_pitch[i], static_cast<const char*>(g.dst[i]) + g.dst_fs[i] * k, g.dst_pitch[i],
+                                               static_cast<size_t>(dw) * sb, dh, hipMemcpyDeviceToHost, d2h),
+                              "D2H copy");
+                }
+                hip_check(hipEventRecord(g.done[static_cast<size_t>(k)], d2h), "hipEventRecord(frame done)");
+                fr.done_event = k;
+            }
+        }
+        g.state = FrameGroup::Launched;
+    } catch (const std::exception& e) {
+        // whatever was queued must not touch the caller's planes after the error is reported
+        (void)hipStreamSynchronize(kernels_of(f, g));
+        if (d2h_of(f, g)) (void)hipStreamSynchronize(d2h_of(f, g));
+        g.state = FrameGroup::Failed;
+        g.error = e.what();
+        throw;
+    }
+}
+
+// Pins [p, p + bytes) once (cache keyed by address range, least recently used out) so that the copies of the pipeline
+// really are asynchronous and the shader can reach the planes; returns p's address in the device's address space, or
+// nullptr if the range could not be pinned (the frame then takes the DMA / pageable path -- not an error).  The cache
+// holds at least every range the frames in flight can reference (frames x planes x (src + dst)), and a range whose frame
+// may still be in flight is never unregistered under its transfer: its group is finished first.
+char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket) {
     char* c = const_cast<char*>(static_cast<const char*>(p));
     for (auto& r : f.pinned)
         if (c >= r.base && c + bytes <= r.base + r.bytes) {
             r.stamp = ++f.pin_clock;
             r.ticket = ticket;
-            return;
+            return r.dev ? r.dev + (c - r.base) : nullptr;
         }
-    const size_t capacity = std::max<size_t>(64, f.slots.size() * 8 + 8);
+    const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
+    const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
     if (f.pinned.size() >= capacity) {
         size_t lru = 0;
         for (size_t i = 1; i < f.pinned.size(); ++i)
             if (f.pinned[i].stamp < f.pinned[lru].stamp) lru = i;
-        for (auto& s : f.slots)
-            if (s.busy && s.ticket == f.pinned[lru].ticket) (void)hipStreamSynchronize(s.stream);  // its copies may still run
+        for (auto& g : f.groups)  // its transfers may still run (a group being filled has its H2D copies queued already)
+            for (const GroupFrame& fr : g.frames)
+                if (fr.ticket == f.pinned[lru].ticket) {
+                    if (g.state == FrameGroup::Filling || g.state == FrameGroup::Launched) finish_group(f, g);
+                }
         (void)hipHostUnregister(f.pinned[lru].base);
-        f.pinned.erase(f.pinned.begin() + lru);
+        f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(lru));
     }
-    if (hipHostRegister(c, bytes, hipHostRegisterDefault) == hipSuccess) {
-        f.pinned.push_back({c, bytes, ++f.pin_clock, ticket});
-    } else {
+    if (hipHostRegister(c, bytes, hipHostRegisterDefault) != hipSuccess) {
         (void)hipGetLastError();  // clear; e.g. the range overlaps memory somebody else has registered
+        return nullptr;
     }
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, c, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = nullptr;
+    }
+    f.pinned.push_back({c, bytes, static_cast<char*>(dev), ++f.pin_clock, ticket});
+    return static_cast<char*>(dev);
 }
 
 }  // namespace
 
-void submit_frame(jinc_filter& f, DeviceFrameBuf& s, const void* const src[4], const int src_pitch[4], void* const dst[4],
-                  const int dst_pitch[4]) {
+namespace {
+void release_belts(jinc_filter& f) {
+    if (f.h2d_stream) (void)hipStreamDestroy(f.h2d_stream);
+    if (f.d2h_stream) (void)hipStreamDestroy(f.d2h_stream);
+    f.h2d_stream = f.d2h_stream = nullptr;
+}
+
+// The arrivals and departures belts exist while groups are large enough to use them.  The departures belt runs at the
+// highest priority: its kernel is bound by the link and needs few waves, but those must not queue behind the resampling
+// kernels of the next group (measured: JINC_D2H_PRIORITY, profiles/round3/).
+void ensure_belts(jinc_filter& f) {
+    if (!use_belts(f)) {
+        release_belts(f);
+        return;
+    }
+    if (f.h2d_stream) return;
+    hip_check(hipStreamCreateWithFlags(&f.h2d_stream, hipStreamNonBlocking), "hipStreamCreate(arrivals)");
+    int least = 0, greatest = 0;
+    hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    const char* e = std::getenv("JINC_D2H_PRIORITY");
+    const int prio = (e && std::atoi(e) == 0) ? least : greatest;
+    hip_check(hipStreamCreateWithPriority(&f.d2h_stream, hipStreamNonBlocking, prio), "hipStreamCreate(departures)");
+}
+}  // namespace
+
+void release_pipeline(jinc_filter& f) {
+    for (hipStream_t s : {f.h2d_stream, f.stream, f.d2h_stream})
+        if (s) (void)hipStreamSynchronize(s);
+    for (auto& g : f.groups) {
+        if (g.own_stream) (void)hipStreamSynchronize(g.own_stream);
+        release_group(g);
+    }
+    release_belts(f);
+}
+
+void launch_open_group(jinc_filter& f) {
+    if (f.open_group < 0) return;
+    FrameGroup& g = f.groups[static_cast<size_t>(f.open_group)];
+    f.open_group = -1;
+    if (g.state == FrameGroup::Filling && !g.frames.empty()) launch_group(f, g);
+}
+
+void drain_pipeline(jinc_filter& f) {
+    launch_open_group(f);
+    for (auto& g : f.groups) finish_group(f, g);
+}
+
+void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host) {
+    drain_pipeline(f);
+    for (auto& g : f.groups) retire_group(f, g);
+    depth = std::max(1, std::min(depth, kMaxPipelineDepth));
+    // Frames per launch: half the frames in flight unless the caller says otherwise, so that one group computes while the
+    // client still collects the previous one (depth 1..3: single frames, the round-2 behaviour).
+    if (group <= 0) group = depth >= 4 ? depth / 2 : 1;
+    group = std::min(group, depth);
+    const size_t per_frame = std::max<size_t>(1, staging_bytes_per_frame(f));
+    auto ring_of = [&](int g) { return (depth + g - 1) / g + 1; };
+    while (group > 1 && per_frame * static_cast<size_t>(group) * static_cast<size_t>(ring_of(group)) > kPipelineBudgetBytes) group /= 2;
+    if (group != f.group_frames)
+        for (auto& g : f.groups) release_group(g);
+    f.pipeline_depth = depth;
+    f.group_frames = group;
+    const size_t ring = static_cast<size_t>(ring_of(group));
+    while (f.groups.size() > ring) {
+        release_group(f.groups.back());
+        f.groups.pop_back();
+    }
+    f.groups.resize(ring);
+    f.open_group = -1;
+    f.last_group = 0;
+    f.register_host = register_host;
+    if (!f.register_host) {
+        for (auto& p : f.pinned) (void)hipHostUnregister(p.base);
+        f.pinned.clear();
+    }
+    ensure_belts(f);
+}
+
+long long submit_frame(jinc_filter& f, const void* const src[4], const int src_pitch[4], void* const dst[4], const int dst_pitch[4]) {
     const int sb = f.vi_in.component_size;
     for (int i = 0; i < f.planecount; ++i) {
         if (!src[i] || !dst[i]) throw ArgError("JincResize: null plane pointer.");
+        int sw, dw, h;
+        f.plane_dims(f.vi_in, i, sw, h);
+        f.plane_dims(f.vi_out, i, dw, h);
+        if (static_cast<size_t>(src_pitch[i]) < static_cast<size_t>(sw) * sb || static_cast<size_t>(dst_pitch[i]) < static_cast<size_t>(dw) * sb)
+            throw ArgError("JincResize: plane pitch is smaller than the row size.");
+    }
+    if (f.open_group < 0) {  // open the next buffer of the ring; its previous frames have to be finished first
+        const int next = (f.last_group + 1) % static_cast<int>(f.groups.size());
+        FrameGroup& g = f.groups[static_cast<size_t>(next)];
+        retire_group(f, g);
+        ensure_belts(f);
+        ensure_group(f, g);
+        g.state = FrameGroup::Filling;
+        f.open_group = f.last_group = next;
+    }
+    FrameGroup& g = f.groups[static_cast<size_t>(f.open_group)];
+    const size_t k = g.frames.size();
+    const long long ticket = f.next_ticket;
+    GroupFrame fr;
+    fr.ticket = ticket;
+    for (int i = 0; i < f.planecount; ++i) {
         int sw, sh, dw, dh;
         f.plane_dims(f.vi_in, i, sw, sh);
         f.plane_dims(f.vi_out, i, dw, dh);
         if (f.register_host) {
-            pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, f.next_ticket);
-            pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, f.next_ticket);
+            (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket);
+            fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket);
         }
-        hip_check(hipMemcpy2DAsync(s.src[i], s.src_pitch[i], src[i], src_pitch[i], static_cast<size_t>(sw) * sb, sh,
-                                   hipMemcpyHostToDevice, s.stream),
+        hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
+                                   static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
                   "H2D copy");
+        fr.dst[i] = dst[i];
+        fr.dst_pitch[i] = dst_pitch[i];
     }
-    enqueue(f, s.src, s.src_pitch, nullptr, s.dst, s.dst_pitch, nullptr, 1, s.stream);
-    for (int i = 0; i < f.planecount; ++i) {
-        int dw, dh;
-        f.plane_dims(f.vi_out, i, dw, dh);
-        hip_check(hipMemcpy2DAsync(dst[i], dst_pitch[i], s.dst[i], s.dst_pitch[i], static_cast<size_t>(dw) * sb, dh,
-                                   hipMemcpyDeviceToHost, s.stream),
-                  "D2H copy");
+    g.frames.push_back(fr);
+    ++f.next_ticket;
+    if (static_cast<int>(g.frames.size()) >= g.capacity) launch_group(f, g);
+    return ticket;
+}
+
+void wait_frame(jinc_filter& f, long long ticket) {
+    for (auto& g : f.groups) {
+        for (size_t k = 0; k < g.frames.size(); ++k) {
+            if (g.frames[k].ticket != ticket) continue;
+            if (g.state == FrameGroup::Filling) launch_group(f, g);  // the client wants this frame now: no more company
+            if (g.state == FrameGroup::Failed) throw HipError(g.error);
+            hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames[k].done_event)]), "hipEventSynchronize(frame done)");
+            return;
+        }
     }
+    // unknown or long completed ticket: nothing to wait for (its group buffer has been reused, which waited for it)
 }
 
 }  // namespace host

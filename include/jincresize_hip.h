@@ -153,18 +153,26 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
 
 /* ---- Look-ahead pipeline around GetFrame (frame transport) -------------------------
  * A host that knows which frames come next (a plugin that prefetches fi->child frames n+1..n+k, a batch tool)
- * keeps up to `depth` frames in flight per instance: jinc_filter_submit enqueues H2D -> kernels -> D2H of one
- * frame on its own stream and returns a ticket at once; jinc_filter_wait blocks until that frame's destination
- * planes are complete.  src and dst must stay valid and untouched until the wait returns.  Frames are
- * independent, so completion order does not matter for results.
+ * keeps up to `depth` (1..256) frames in flight per instance.  The surface stays per frame, as the reference's
+ * GetFrame is (ref :603-630): jinc_filter_submit takes ONE frame (its H2D copy is queued at once) and returns a
+ * ticket; jinc_filter_wait blocks until THAT frame's destination planes are complete.  In between the library
+ * coalesces: `group` consecutively submitted frames share one strided device buffer and ONE set of kernel
+ * launches (the batch kernels -- lanes = frames, wide tiles -- that single-frame calls cannot use), followed by one
+ * D2H copy per frame.  A group leaves when it is full, when a wait asks for one of its frames, or on
+ * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 4; else 1): one group computes while the client collects
+ * the previous one.  src and dst must stay valid and untouched until the frame's wait returns.  Frames are
+ * independent, so neither grouping nor completion order changes results.
  * register_host_buffers != 0: every plane buffer seen is pinned with hipHostRegister (cached by address range,
- * LRU of 64) so that the copies really are asynchronous and overlap; the caller then guarantees that such
- * buffers stay allocated until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0).  With pageable
+ * least recently used out) so that the copies really are asynchronous and overlap; the caller then guarantees
+ * that such buffers stay allocated until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0).  With pageable
  * buffers the pipeline still works but the copies serialise on the host.
- * jinc_filter_get_frame == submit + wait on slot 0 (after draining frames still in flight). */
+ * A failed launch is reported by the submit that triggered it and by every wait on a frame of that group.
+ * jinc_filter_get_frame == submit + wait (after draining frames still in flight). */
 JINC_API int jinc_filter_set_pipeline(jinc_filter *f, int depth, int register_host_buffers);
+JINC_API int jinc_filter_set_pipeline_group(jinc_filter *f, int depth, int group, int register_host_buffers);
 JINC_API int jinc_filter_submit(jinc_filter *f, const void *const src[4], const int src_pitch[4], void *const dst[4],
                                 const int dst_pitch[4], long long *ticket);
+JINC_API int jinc_filter_flush(jinc_filter *f); /* launch the frames submitted so far (no more are coming) */
 JINC_API int jinc_filter_wait(jinc_filter *f, long long ticket);
 
 /* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t; NULL is
@@ -184,8 +192,9 @@ JINC_API int jinc_filter_sync(jinc_filter *f);
 /* ---- Frames of a clip sharded over the HIP devices of the node (BASELINE.json configs[4]) --------
  * Frames are independent units (JincResize_GetFrame touches frame n only, ref :603-630) and the plan is read-only, so
  * the shard needs no exchange between devices: frame n is computed on device jinc_shard_device(n, G) = n mod G, every
- * device holds a replica of the plan (one filter instance) and keeps `streams_per_device` frames in flight (per-frame
- * device buffers and hipStreams, H2D -> kernels -> D2H), driven by one host thread per device.  No collective.
+ * device holds a replica of the plan (one filter instance) and keeps `streams_per_device` (1..256) frames in flight
+ * through the look-ahead pipeline above (frames coalesced into groups of streams_per_device / 2 per launch), driven by
+ * one host thread per device.  No collective.
  * ndevices <= 0: all visible devices.  register_host_buffers: as for jinc_filter_set_pipeline.
  * jinc_batch_process: src_planes / dst_planes hold 4 pointers per frame ([frame][plane], planes in the reference's
  * processing order, unused planes NULL), HOST buffers with the given pitches (bytes); returns when every frame is

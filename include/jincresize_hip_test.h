@@ -59,6 +59,12 @@ JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table
 /* Name of the kernel that computed the interior of `table` in the most recent frame call (the choice depends on the
  * batch size: the frame-lane kernel needs a batch). "" before the first call. */
 JINC_API const char *jinc_filter_last_kernel(const jinc_filter *f, int table);
+/* Frames the look-ahead pipeline coalesces into one launch (what jinc_filter_set_pipeline[_group] settled on after its
+ * automatic rule and the device-memory budget). */
+JINC_API int jinc_filter_pipeline_group(const jinc_filter *f);
+/* Interior kernel (of table 0) and frame count of the most recent kernel call of ANY filter instance in this process:
+ * for tests that drive the plugin shell and cannot reach its jinc_filter handles. */
+JINC_API const char *jinc_debug_last_call(int *nframes);
 /* Border frame of exactly periodic plans: 1 (default) = rows and columns on the strip kernels, corners on the
  * gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel; 0 = everything on the
  * gather kernel (A/B measurements, tests). */

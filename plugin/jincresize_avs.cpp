@@ -37,6 +37,7 @@ struct Instance {
     jinc_filter* filter = nullptr;
     int chroma_location = -1;     // value written to _ChromaLocation, -1: format without sub-sampled chroma
     int lookahead = 1;            // frames in flight (JINCRESIZE_LOOKAHEAD, default 1 = the reference's synchronous GetFrame)
+    int group = 0;                // of them coalesced into one launch (JINCRESIZE_GROUP, default 0 = lookahead / 2)
     std::vector<Pending> ring;
     int next_submit = 0;          // next frame number to submit when access is sequential
     std::string error;            // storage for fi->error
@@ -91,7 +92,8 @@ AVS_VideoFrame* get_frame_sync(AVS_FilterInfo* fi, Instance* inst, int n) {
 }
 
 // Look-ahead form: frames n .. n+depth-1 are in flight on the filter's
-// pipeline slots; sequential access is assumed, anything else drains the ring first.
+// pipeline, which coalesces consecutive frames into groups that share one set of kernel launches (batch kernels);
+// each GetFrame still returns exactly frame n.  Sequential access is assumed, anything else drains the ring first.
 AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
     const int depth = inst->lookahead;
     const int last = fi->vi.num_frames - 1;
@@ -130,6 +132,7 @@ AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
         p.frame = k;
         inst->next_submit = k + 1;
     }
+    if (inst->next_submit > last) jinc_filter_flush(inst->filter);  // end of the clip: the last frames leave without company
     if (want.frame != n) return nullptr;  // the child had no frame n
     if (jinc_filter_wait(inst->filter, want.ticket) != JINC_OK) {
         AVS_VideoFrame* dst = want.dst;
@@ -242,10 +245,11 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
     Instance* inst = new Instance;
     inst->filter = filter;
     inst->chroma_location = jinc_filter_chroma_location(filter);
-    if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(8, std::atoi(e)));
+    if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(256, std::atoi(e)));
+    if (const char* e = std::getenv("JINCRESIZE_GROUP")) inst->group = std::max(0, std::min(inst->lookahead, std::atoi(e)));
     if (inst->lookahead > 1) {
         const char* reg = std::getenv("JINCRESIZE_PIN_FRAMES");
-        if (jinc_filter_set_pipeline(filter, inst->lookahead, reg && std::atoi(reg) != 0) != JINC_OK) inst->lookahead = 1;
+        if (jinc_filter_set_pipeline_group(filter, inst->lookahead, inst->group, reg && std::atoi(reg) != 0) != JINC_OK) inst->lookahead = 1;
         inst->ring.resize(static_cast<size_t>(inst->lookahead));
     }
 

@@ -20,7 +20,7 @@ import __graft_entry__ as entry  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=512)
-    ap.add_argument("--streams", type=int, nargs="+", default=[2, 3, 4])
+    ap.add_argument("--streams", type=int, nargs="+", default=[4, 16, 64], help="frames in flight per device")
     ap.add_argument("--register", type=int, nargs="+", default=[0, 1])
     a = ap.parse_args()
     pkg = entry.load_package()

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--threads", type=int, nargs="+", default=[1, 2, 4, 8])
     ap.add_argument("--seconds", type=float, default=3.0)
     ap.add_argument("--pipeline", type=int, nargs="*", default=[], help="also time ONE host thread with these pipeline depths")
+    ap.add_argument("--group", type=int, default=0, help="frames coalesced per launch (0: automatic = depth / 2)")
+    ap.add_argument("--registered-only", action="store_true")
     a = ap.parse_args()
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, _ = bench.CONFIGS[a.config]
@@ -59,13 +61,13 @@ def main():
                           "Mpix_per_s": round(fps * dw * dh / 1e6, 1),
                           "host_GB_per_s": round(fps * bench.algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh) / 1e9, 2)}))
     for depth in a.pipeline:
-        for register in (False, True):
-            pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, a.seconds, a.config)
+        for register in ((True,) if a.registered_only else (False, True)):
+            pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, a.seconds, a.config, min(a.group, depth))
 
 
-def pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, seconds, config):
+def pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, seconds, config, group=0):
     f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
-    f.set_pipeline(depth, register)
+    f.set_pipeline(depth, register, group)
     rng = np.random.default_rng(2)
     nbuf = depth + 1
     srcs, dsts = [], []
@@ -94,7 +96,8 @@ def pipeline_run(pkg, fmt, sw, sh, dw, dh, kw, depth, register, seconds, config)
         f.wait(tickets.pop(0))
     el = time.perf_counter() - t0
     fps = n / el
-    print(json.dumps({"config": config, "threads": 1, "pipeline_depth": depth, "registered_host_buffers": register,
+    print(json.dumps({"config": config, "threads": 1, "pipeline_depth": depth, "frames_per_launch": f.pipeline_group,
+                      "kernel": f.last_kernel(0), "registered_host_buffers": register,
                       "frames_per_s": round(fps, 1), "Mpix_per_s": round(fps * dw * dh / 1e6, 1),
                       "host_GB_per_s": round(fps * bench.algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh) / 1e9, 2)}))
     f.close()

@@ -363,3 +363,47 @@ def test_lookahead_ring_sequential_and_seek(host, O, depth, monkeypatch):
     host.mock_source_release(src)
     assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,group,kernel", [
+    (("Y8", 1280, 720, 1754, 986, "JincResize", {}), None, "ewa_framelane_win"),          # no phase structure, fs 7: groups of 16
+    (("Y8", 1280, 720, 1920, 1080, "Jinc256Resize", {}), 32, "ewa_framelane_kernel"),     # 1.5x tap 8 (fs 17): needs >= 24 frames
+], ids=["A137_lookahead32", "N15T8_lookahead32_group32"])
+def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, case, group, kernel, monkeypatch):
+    """with JINCRESIZE_LOOKAHEAD=32 the plugin's per-frame GetFrame (ref :603-630) is served by coalesced
+    launches -- the frame-lane kernels -- and every frame is still exactly that frame's result."""
+    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "32")
+    monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
+    if group:
+        monkeypatch.setenv("JINCRESIZE_GROUP", str(group))
+    fmt_name, sw, sh, tw, th, fn, named = case
+    fmt = O.FORMATS[fmt_name]
+    nframes = 64
+    frames = [O.lcg_frame(fmt, sw, sh, seed=31000 + n) for n in range(nframes)]
+    kw = dict(named)
+    kw.update({"Jinc256Resize": dict(tap=8)}.get(fn, {}))
+    single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **kw)   # the same frames, one synchronous call each
+    want = [single.get_frame(fr) for fr in frames]
+    single.close()
+    of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(kw))
+    h = Host(host)
+    src = h.source(fmt, sw, sh, frames)
+    clip, err = h.invoke(fn, src, tw, th, **named)
+    assert err is None, err
+    seen = set()
+    for n in range(nframes):
+        fr = host.mock_clip_get_frame(clip, n)
+        assert host.mock_clip_error(clip) is None
+        seen.add(pkg.last_call())
+        got = [h.read_plane(fr, 0, np.uint8)]
+        assert_planes_equal(got, want[n], fmt.plane_dims(tw, th), what=f"{fn} frame {n} grouped vs single")
+        if n in (0, 41):
+            assert_planes_equal(got, of.get_frame(frames[n], threads=8), fmt.plane_dims(tw, th), what=f"{fn} frame {n} vs oracle")
+        host.mock_frame_release(fr)
+    assert host.mock_source_get_frame_calls(src) == nframes + 1   # each child frame once (+ the frame-0 property probe)
+    assert all(name.startswith(kernel) and k == (group or 16) for name, k in seen), seen
+    host.mock_clip_release(clip)
+    host.mock_source_release(src)
+    assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
+    h.close()
