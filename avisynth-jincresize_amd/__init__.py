@@ -81,7 +81,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
-           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_debug_last_call",
+           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
 
@@ -114,6 +114,7 @@ def lib():
         L.jinc_filter_set_pipeline_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.jinc_filter_pipeline_group.argtypes = [C.c_void_p]
         L.jinc_filter_flush.argtypes = [C.c_void_p]
+        L.jinc_filter_adopt_host_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.jinc_debug_last_call.argtypes = [C.POINTER(C.c_int)]
         L.jinc_debug_last_call.restype = C.c_char_p
         L.jinc_filter_submit.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4, C.POINTER(C.c_longlong)]
@@ -412,6 +413,10 @@ class Filter:
     @property
     def pipeline_group(self) -> int:
         return int(lib().jinc_filter_pipeline_group(self._h))
+
+    def adopt_host_range(self, base: int, nbytes: int) -> None:
+        """[base, base + nbytes) is pinned by the caller (hipHostMalloc / hipHostRegister) and stays so until close()."""
+        self._check(lib().jinc_filter_adopt_host_range(self._h, C.c_void_p(base), C.c_size_t(nbytes)))
 
     def flush(self) -> None:
         """Launch the frames submitted so far (a client that knows no more are coming)."""

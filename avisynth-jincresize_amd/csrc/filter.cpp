@@ -138,6 +138,15 @@ int jinc_filter_submit(jinc_filter* f, const void* const src[4], const int src_p
     });
 }
 
+int jinc_filter_adopt_host_range(jinc_filter* f, void* base, size_t bytes) {
+    if (!f || !base || !bytes) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        adopt_host_range(*f, base, bytes);
+    });
+}
+
 int jinc_filter_flush(jinc_filter* f) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");

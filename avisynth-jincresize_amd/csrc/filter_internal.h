@@ -114,6 +114,7 @@ struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-a
     char* base = nullptr;
     size_t bytes = 0;
     char* dev = nullptr;    // the range's address in the device's address space (hipHostGetDevicePointer), or nullptr
+    bool adopted = false;   // pinned by the caller (jinc_filter_adopt_host_range): never unregistered or evicted here
     unsigned long long stamp = 0;
     long long ticket = -1;  // latest frame whose copies use this range (may still be in flight)
 };
@@ -183,7 +184,8 @@ struct jinc_filter {
                 for (void* b : t.lane_blobs) (void)hipFree(b);
             }
             jinc::host::release_pipeline(*this);
-            for (auto& p : pinned) (void)hipHostUnregister(p.base);
+            for (auto& p : pinned)
+                if (!p.adopted) (void)hipHostUnregister(p.base);
             for (auto* v : {&ev_periodic, &ev_gather})
                 for (auto& e : *v) {
                     (void)hipEventDestroy(e.start);
@@ -228,6 +230,7 @@ int last_call_frames_in_process();
 void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host);  // drains first
 long long submit_frame(jinc_filter& f, const void* const src[4], const int src_pitch[4], void* const dst[4], const int dst_pitch[4]);
 void wait_frame(jinc_filter& f, long long ticket);  // flushes the open group if the frame is in it
+void adopt_host_range(jinc_filter& f, void* base, size_t bytes);  // caller-pinned memory: usable for async copies and shader transport
 void launch_open_group(jinc_filter& f);             // the frames submitted so far leave now (a client that knows no more are coming)
 void drain_pipeline(jinc_filter& f);                // every submitted frame complete
 

@@ -5,45 +5,37 @@
 // Not part of the hot path's arithmetic: bytes in, the same bytes out.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace jinc {
 namespace {
 
-// Rows [r0, r1) of entry e, by the whole workgroup.
+// Rows [r0, r1) of entry e, by the whole workgroup: a wave takes every 4th group of 4 rows, its lanes walk along the rows
+// in 64 x sizeof(V) byte steps.  No divisions, a handful of integer instructions per 16 bytes: the kernel runs beside
+// VALU-bound resampling kernels and must not queue for the vector unit (a first form that cut the plane into units with
+// q / units_per_row, q % units_per_row per access lost a third of its rate next to the frame-lane kernel).
 template <typename V>
 __device__ __forceinline__ void move_rows(const BlitEntry& e, uint32_t r0, uint32_t r1) {
     constexpr uint32_t U = sizeof(V);
-    const uint32_t ppr = e.row_bytes / U;  // whole units per row
-    const uint32_t total = ppr * (r1 - r0);
-    const uint32_t stride = blockDim.x;
-    const char* __restrict__ src = static_cast<const char*>(e.src) + static_cast<size_t>(r0) * e.src_pitch;
-    char* __restrict__ dst = static_cast<char*>(e.dst) + static_cast<size_t>(r0) * e.dst_pitch;
-    uint32_t p = threadIdx.x;
-    // four independent units per lane and pass: loads first, then stores (the link wants many requests in flight)
-    for (; p + 3 * stride < total; p += 4 * stride) {
-        V v[4];
-        uint32_t off[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const char* __restrict__ src = static_cast<const char*>(e.src);
+    char* __restrict__ dst = static_cast<char*>(e.dst);
+    const uint32_t whole = e.row_bytes / U * U;  // bytes of a row in whole units
+    for (uint32_t r = r0 + 4 * wave; r < r1; r += 4 * waves) {
+        for (uint32_t c = lane * U; c < whole; c += 64 * U) {
+            V v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t q = p + k * stride, row = q / ppr, col = q - row * ppr;
-            v[k] = *reinterpret_cast<const V*>(src + static_cast<size_t>(row) * e.src_pitch + col * U);
-            off[k] = row * e.dst_pitch + col * U;
-        }
+            for (uint32_t k = 0; k < 4; ++k)  // four rows in flight per lane: loads first, then stores
+                if (r + k < r1) v[k] = *reinterpret_cast<const V*>(src + static_cast<size_t>(r + k) * e.src_pitch + c);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<V*>(dst + off[k]) = v[k];
-    }
-    for (; p < total; p += stride) {
-        const uint32_t row = p / ppr, col = p - row * ppr;
-        *reinterpret_cast<V*>(dst + static_cast<size_t>(row) * e.dst_pitch + col * U) =
-            *reinterpret_cast<const V*>(src + static_cast<size_t>(row) * e.src_pitch + col * U);
-    }
-    const uint32_t tail = e.row_bytes - ppr * U;  // bytes of a row beyond its whole units
-    if (tail) {
-        for (uint32_t q = threadIdx.x; q < tail * (r1 - r0); q += stride) {
-            const uint32_t row = q / tail, b = ppr * U + (q - row * tail);
-            dst[static_cast<size_t>(row) * e.dst_pitch + b] = src[static_cast<size_t>(row) * e.src_pitch + b];
+            for (uint32_t k = 0; k < 4; ++k)
+                if (r + k < r1) *reinterpret_cast<V*>(dst + static_cast<size_t>(r + k) * e.dst_pitch + c) = v[k];
         }
+        if (whole + lane < e.row_bytes)  // bytes of a row beyond its whole units (fewer than sizeof(V) <= 64)
+            for (uint32_t k = 0; k < 4 && r + k < r1; ++k)
+                dst[static_cast<size_t>(r + k) * e.dst_pitch + whole + lane] = src[static_cast<size_t>(r + k) * e.src_pitch + whole + lane];
     }
 }
 
@@ -51,7 +43,8 @@ __device__ __forceinline__ void move_rows(const BlitEntry& e, uint32_t r0, uint3
 // kernels of the next group of frames run beside it on the other compute units) walk over work items = (entry, slice of
 // `rows_per_item` rows), item = blockIdx.x, blockIdx.x + gridDim.x, ...
 __global__ __launch_bounds__(256) void blit_rows_kernel(const BlitEntry* __restrict__ table, uint32_t entries, uint32_t rows_per_item,
-                                                        uint32_t items_per_entry) {
+                                                        uint32_t items_per_entry, int wave_priority) {
+    if (wave_priority) __builtin_amdgcn_s_setprio(3);
     for (uint32_t item = blockIdx.x; item < entries * items_per_entry; item += gridDim.x) {
         const uint32_t ei = item / items_per_entry, slice = item - ei * items_per_entry;
         const BlitEntry e = table[ei];
@@ -64,6 +57,16 @@ __global__ __launch_bounds__(256) void blit_rows_kernel(const BlitEntry* __restr
     }
 }
 
+}  // namespace
+
+namespace {
+int blit_wave_priority() {  // A/B knob JINC_BLIT_SETPRIO (default 1)
+    static const int v = [] {
+        const char* e = getenv("JINC_BLIT_SETPRIO");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
 }  // namespace
 
 int blit_unit(const void* src, const void* dst, uint32_t src_pitch, uint32_t dst_pitch) {
@@ -81,7 +84,7 @@ int launch_blit_rows(const BlitEntry* table_device, int first, int count, uint32
     const uint32_t items = static_cast<uint32_t>(count) * items_per_entry;
     const uint32_t grid = items < static_cast<uint32_t>(workgroups) ? items : static_cast<uint32_t>(workgroups);
     hipLaunchKernelGGL(blit_rows_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), table_device + first,
-                       static_cast<uint32_t>(count), rows_per_item, items_per_entry);
+                       static_cast<uint32_t>(count), rows_per_item, items_per_entry, blit_wave_priority());
     return hipGetLastError();
 }
 

@@ -121,13 +121,19 @@ void retire_group(jinc_filter& f, FrameGroup& g) {
     g.state = FrameGroup::Idle;
 }
 
-int blit_workgroups() {  // A/B knob JINC_BLIT_WORKGROUPS (default 48)
-    static const int v = [] {
+// Workgroups of the transport kernel.  The link bounds it, and next to a transport-bound plan 48 workgroups keep the link
+// full (C2, 1.37x: 24 workgroups lose 6 %); next to a kernel-bound plan (many taps per output byte: 1.5x with tap 8)
+// every transport wave takes issue slots from the resampling kernel and 24 are the better trade (17.8 against 16.5
+// thousand frames/s; profiles/round3/blit_workgroups.log).  A/B knob: JINC_BLIT_WORKGROUPS.
+int blit_workgroups(const jinc_filter& f) {
+    static const int knob = [] {
         const char* e = std::getenv("JINC_BLIT_WORKGROUPS");
-        const int n = e ? std::atoi(e) : 0;
-        return n > 0 ? n : 48;
+        return e ? std::atoi(e) : 0;
     }();
-    return v;
+    if (knob > 0) return knob;
+    int taps_per_byte = 0;
+    for (const auto& p : f.plans) taps_per_byte = std::max(taps_per_byte, p.fs * p.fs / f.vi_in.component_size);
+    return taps_per_byte >= 100 ? 24 : 48;
 }
 
 int group_shares() {  // A/B knob JINC_GROUP_SHARES (default kGroupShares)
@@ -135,6 +141,15 @@ int group_shares() {  // A/B knob JINC_GROUP_SHARES (default kGroupShares)
         const char* e = std::getenv("JINC_GROUP_SHARES");
         const int n = e ? std::atoi(e) : 0;
         return n > 0 ? n : kGroupShares;
+    }();
+    return v;
+}
+
+// Diagnosis only (JINC_PIPELINE_SKIP=h2d / kernels: wrong results, same transport otherwise): which stage slows which.
+int debug_skip() {
+    static const int v = [] {
+        const char* e = std::getenv("JINC_PIPELINE_SKIP");
+        return !e ? 0 : std::string(e) == "h2d" ? 1 : std::string(e) == "kernels" ? 2 : 0;
     }();
     return v;
 }
@@ -161,7 +176,7 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
             hip_check(hipEventRecord(g.h2d_ready, f.h2d_stream), "hipEventRecord(arrivals)");
             hip_check(hipStreamWaitEvent(f.stream, g.h2d_ready, 0), "hipStreamWaitEvent(arrivals)");
         }
-        enqueue(f, g.src, g.src_pitch, g.src_fs, g.dst, g.dst_pitch, g.dst_fs, n, kernels_of(f, g));
+        if (debug_skip() != 2) enqueue(f, g.src, g.src_pitch, g.src_fs, g.dst, g.dst_pitch, g.dst_fs, n, kernels_of(f, g));
         if (belts) {  // the departures belt reads what the kernels have written
             hip_check(hipEventRecord(g.kernels_done, f.stream), "hipEventRecord(kernels)");
             hip_check(hipStreamWaitEvent(d2h, g.kernels_done, 0), "hipStreamWaitEvent(kernels)");
@@ -193,7 +208,7 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
             for (int s = 0; s < shares; ++s) {
                 const int k0 = n * s / shares, k1 = n * (s + 1) / shares;
                 hip_check(static_cast<hipError_t>(jinc::launch_blit_rows(g.table, k0 * planes, (k1 - k0) * planes, max_rows, max_row_bytes,
-                                                                         blit_workgroups(), d2h)),
+                                                                         blit_workgroups(f), d2h)),
                           "transport kernel launch");
                 hip_check(hipEventRecord(g.done[static_cast<size_t>(s)], d2h), "hipEventRecord(share done)");
                 for (int k = k0; k < k1; ++k) g.frames[static_cast<size_t>(k)].done_event = s;
@@ -236,12 +251,15 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
             r.ticket = ticket;
             return r.dev ? r.dev + (c - r.base) : nullptr;
         }
+    if (!f.register_host) return nullptr;  // only ranges the caller pinned are known: this one is pageable
     const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
     const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
-    if (f.pinned.size() >= capacity) {
-        size_t lru = 0;
-        for (size_t i = 1; i < f.pinned.size(); ++i)
-            if (f.pinned[i].stamp < f.pinned[lru].stamp) lru = i;
+    size_t own = 0;
+    for (const auto& r : f.pinned) own += r.adopted ? 0 : 1;
+    if (own >= capacity) {
+        size_t lru = f.pinned.size();
+        for (size_t i = 0; i < f.pinned.size(); ++i)
+            if (!f.pinned[i].adopted && (lru == f.pinned.size() || f.pinned[i].stamp < f.pinned[lru].stamp)) lru = i;
         for (auto& g : f.groups)  // its transfers may still run (a group being filled has its H2D copies queued already)
             for (const GroupFrame& fr : g.frames)
                 if (fr.ticket == f.pinned[lru].ticket) {
@@ -259,7 +277,7 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
         (void)hipGetLastError();
         dev = nullptr;
     }
-    f.pinned.push_back({c, bytes, static_cast<char*>(dev), ++f.pin_clock, ticket});
+    f.pinned.push_back({c, bytes, static_cast<char*>(dev), false, ++f.pin_clock, ticket});
     return static_cast<char*>(dev);
 }
 
@@ -290,6 +308,18 @@ void ensure_belts(jinc_filter& f) {
 }
 }  // namespace
 
+void adopt_host_range(jinc_filter& f, void* base, size_t bytes) {
+    char* c = static_cast<char*>(base);
+    for (const auto& r : f.pinned)
+        if (c >= r.base && c + bytes <= r.base + r.bytes) return;  // known already
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, c, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        throw ArgError("JincResize: the host range is not pinned for this device (hipHostRegister / hipHostMalloc it first).");
+    }
+    f.pinned.push_back({c, bytes, static_cast<char*>(dev), true, ++f.pin_clock, -1});
+}
+
 void release_pipeline(jinc_filter& f) {
     for (hipStream_t s : {f.h2d_stream, f.stream, f.d2h_stream})
         if (s) (void)hipStreamSynchronize(s);
@@ -316,9 +346,10 @@ void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host
     drain_pipeline(f);
     for (auto& g : f.groups) retire_group(f, g);
     depth = std::max(1, std::min(depth, kMaxPipelineDepth));
-    // Frames per launch: half the frames in flight unless the caller says otherwise, so that one group computes while the
-    // client still collects the previous one (depth 1..3: single frames, the round-2 behaviour).
-    if (group <= 0) group = depth >= 4 ? depth / 2 : 1;
+    // Frames per launch unless the caller says otherwise: half the frames in flight, so that one group computes while the
+    // client still collects the previous one -- from 16 frames in flight on; below that single frames on a stream each
+    // (the round-2 shape) overlap better than groups of 2..7 (C2 at depth 4: 5 550 frames/s against 4 400 in pairs).
+    if (group <= 0) group = depth >= 16 ? depth / 2 : 1;
     group = std::min(group, depth);
     const size_t per_frame = std::max<size_t>(1, staging_bytes_per_frame(f));
     auto ring_of = [&](int g) { return (depth + g - 1) / g + 1; };
@@ -336,9 +367,10 @@ void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host
     f.open_group = -1;
     f.last_group = 0;
     f.register_host = register_host;
-    if (!f.register_host) {
-        for (auto& p : f.pinned) (void)hipHostUnregister(p.base);
-        f.pinned.clear();
+    if (!f.register_host) {  // ranges this instance pinned go; ranges the caller pinned stay known
+        for (auto& p : f.pinned)
+            if (!p.adopted) (void)hipHostUnregister(p.base);
+        f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(), [](const PinnedRange& r) { return !r.adopted; }), f.pinned.end());
     }
     ensure_belts(f);
 }
@@ -371,13 +403,14 @@ long long submit_frame(jinc_filter& f, const void* const src[4], const int src_p
         int sw, sh, dw, dh;
         f.plane_dims(f.vi_in, i, sw, sh);
         f.plane_dims(f.vi_out, i, dw, dh);
-        if (f.register_host) {
+        if (f.register_host || !f.pinned.empty()) {
             (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket);
             fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket);
         }
-        hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
-                                   static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
-                  "H2D copy");
+        if (debug_skip() != 1)
+            hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
+                                       static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
+                      "H2D copy");
         fr.dst[i] = dst[i];
         fr.dst_pitch[i] = dst_pitch[i];
     }

@@ -159,7 +159,7 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  * coalesces: `group` consecutively submitted frames share one strided device buffer and ONE set of kernel
  * launches (the batch kernels -- lanes = frames, wide tiles -- that single-frame calls cannot use), followed by one
  * D2H copy per frame.  A group leaves when it is full, when a wait asks for one of its frames, or on
- * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 4; else 1): one group computes while the client collects
+ * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 16; else 1): one group computes while the client collects
  * the previous one.  src and dst must stay valid and untouched until the frame's wait returns.  Frames are
  * independent, so neither grouping nor completion order changes results.
  * register_host_buffers != 0: every plane buffer seen is pinned with hipHostRegister (cached by address range,
@@ -173,6 +173,12 @@ JINC_API int jinc_filter_set_pipeline_group(jinc_filter *f, int depth, int group
 JINC_API int jinc_filter_submit(jinc_filter *f, const void *const src[4], const int src_pitch[4], void *const dst[4],
                                 const int dst_pitch[4], long long *ticket);
 JINC_API int jinc_filter_flush(jinc_filter *f); /* launch the frames submitted so far (no more are coming) */
+/* For hosts that pin their frame memory themselves (a frame pool allocated with hipHostMalloc, or pinned once with
+ * hipHostRegister(..., hipHostRegisterPortable)): tells the instance that [base, base + bytes) is pinned and stays so
+ * until jinc_filter_free.  Planes inside such a range travel like planes the instance pinned itself (asynchronous
+ * copies, results written by the shader), with no registration cost per frame and whatever register_host_buffers
+ * says; the instance never unregisters them. */
+JINC_API int jinc_filter_adopt_host_range(jinc_filter *f, void *base, size_t bytes);
 JINC_API int jinc_filter_wait(jinc_filter *f, long long ticket);
 
 /* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t; NULL is
