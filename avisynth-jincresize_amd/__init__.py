@@ -81,7 +81,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
-           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call",
+           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
 
@@ -114,7 +114,11 @@ def lib():
         L.jinc_filter_set_pipeline_group.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.jinc_filter_pipeline_group.argtypes = [C.c_void_p]
         L.jinc_filter_flush.argtypes = [C.c_void_p]
+        L.jinc_filter_direct_premise.argtypes = [C.c_void_p]
         L.jinc_filter_adopt_host_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jinc_debug_clock_sampler_start.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_void_p)]
+        L.jinc_debug_clock_sampler_stop.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.jinc_debug_valu_pair_probe.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.jinc_debug_last_call.argtypes = [C.POINTER(C.c_int)]
         L.jinc_debug_last_call.restype = C.c_char_p
         L.jinc_filter_submit.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4, C.POINTER(C.c_longlong)]
@@ -156,6 +160,43 @@ def lib():
 
 def device_count() -> int:
     return int(lib().jinc_device_count())
+
+
+class ClockSampler:
+    """Shader clock while other kernels run (jinc_debug_clock_sampler_*): `with ClockSampler(0) as c: ...; c.ghz` = (min, median, max)."""
+
+    def __init__(self, device: int = 0, max_seconds: float = 60.0):
+        self._h = C.c_void_p()
+        rc = lib().jinc_debug_clock_sampler_start(int(device), float(max_seconds), C.byref(self._h))
+        if rc != 0:
+            raise JincError(rc, lib().jinc_last_error().decode())
+        self.ghz = None
+
+    def stop(self):
+        if self._h.value:
+            a, b, c = C.c_double(), C.c_double(), C.c_double()
+            rc = lib().jinc_debug_clock_sampler_stop(self._h, C.byref(a), C.byref(b), C.byref(c))
+            self._h = C.c_void_p()
+            if rc != 0:
+                raise JincError(rc, lib().jinc_last_error().decode())
+            self.ghz = (a.value, b.value, c.value)
+        return self.ghz
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.stop()
+        return False
+
+
+def valu_pair_probe(device: int = 0, waves_per_simd: int = 8) -> Tuple[float, float]:
+    """(Tops, shader clock GHz) that plain v_mul_f32 + v_add_f32 sustain on this part at the given occupancy (measurement hook)."""
+    t, g = C.c_double(), C.c_double()
+    rc = lib().jinc_debug_valu_pair_probe(int(device), int(waves_per_simd), C.byref(t), C.byref(g))
+    if rc != 0:
+        raise JincError(rc, lib().jinc_last_error().decode())
+    return t.value, g.value
 
 
 def last_call() -> Tuple[str, int]:
@@ -417,6 +458,10 @@ class Filter:
     def adopt_host_range(self, base: int, nbytes: int) -> None:
         """[base, base + nbytes) is pinned by the caller (hipHostMalloc / hipHostRegister) and stays so until close()."""
         self._check(lib().jinc_filter_adopt_host_range(self._h, C.c_void_p(base), C.c_size_t(nbytes)))
+
+    @property
+    def direct_premise(self) -> int:
+        return int(lib().jinc_filter_direct_premise(self._h))
 
     def flush(self) -> None:
         """Launch the frames submitted so far (a client that knows no more are coming)."""

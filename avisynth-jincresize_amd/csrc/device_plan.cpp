@@ -430,7 +430,12 @@ void init_device(jinc_filter& f, int device) {
     }
     hip_check(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming), "hipEventCreate");
-    f.direct_premise = buffer_range_check_covers_soffset(device) == 1;
+    {   // a probe that could not run (-1) is a broken device, not "the premise does not hold": the latter silently moves every
+        // exactly periodic down-scale and tap > 8 plan to the gather kernel at a fraction of the rate
+        const int probe = buffer_range_check_covers_soffset(device);
+        if (probe < 0) throw HipError("JincResize: the buffer range-check probe could not run on the HIP device.");
+        f.direct_premise = probe == 1;
+    }
     f.tables.resize(f.plans.size());
     for (size_t i = 0; i < f.plans.size(); ++i) {
         upload_table(f.plans[i], f.tables[i], f.stream);

@@ -374,10 +374,105 @@ const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {
     return f->tables[table].last_kernel;
 }
 
+// Shader-clock sampler beside the kernels being timed (kernel_probe.hip).
+struct jinc_clock_sampler {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int* stop = nullptr;                 // pinned host memory
+    unsigned long long* out = nullptr;   // pinned host memory, 2 x kSamplers
+    static constexpr int kSamplers = 8;
+};
+
+int jinc_debug_clock_sampler_start(int device, double max_seconds, jinc_clock_sampler** out) {
+    if (!out || max_seconds <= 0.0 || max_seconds > 120.0) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad argument.");
+    *out = nullptr;
+    std::unique_ptr<jinc_clock_sampler> s(new jinc_clock_sampler());
+    s->device = device;
+    const int rc = guarded([&] {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        int least = 0, greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        hip_check(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
+        hip_check(hipHostMalloc(reinterpret_cast<void**>(&s->stop), sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+        hip_check(hipHostMalloc(reinterpret_cast<void**>(&s->out), sizeof(unsigned long long) * 2 * jinc_clock_sampler::kSamplers, hipHostMallocDefault),
+                  "hipHostMalloc");
+        *s->stop = 0;
+        std::memset(s->out, 0, sizeof(unsigned long long) * 2 * jinc_clock_sampler::kSamplers);
+        hip_check(static_cast<hipError_t>(jinc::launch_clock_sampler(s->stop, s->out, jinc_clock_sampler::kSamplers, max_seconds, s->stream)),
+                  "clock sampler launch");
+    });
+    if (rc != JINC_OK) {
+        if (s->stop) (void)hipHostFree(s->stop);
+        if (s->out) (void)hipHostFree(s->out);
+        if (s->stream) (void)hipStreamDestroy(s->stream);
+        return rc;
+    }
+    *out = s.release();
+    return JINC_OK;
+}
+
+int jinc_debug_clock_sampler_stop(jinc_clock_sampler* s, double* ghz_min, double* ghz_median, double* ghz_max) {
+    if (!s) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    const int rc = guarded([&] {
+        hip_check(hipSetDevice(s->device), "hipSetDevice");
+        __atomic_store_n(s->stop, 1, __ATOMIC_SEQ_CST);
+        hip_check(hipStreamSynchronize(s->stream), "stream sync");
+        std::vector<double> ghz;
+        for (int k = 0; k < jinc_clock_sampler::kSamplers; ++k)
+            if (s->out[2 * k + 1] > 0) ghz.push_back(static_cast<double>(s->out[2 * k]) / static_cast<double>(s->out[2 * k + 1]) * 0.1);
+        std::sort(ghz.begin(), ghz.end());
+        if (ghz.empty()) throw HipError("JincResize: the clock samplers did not run.");
+        if (ghz_min) *ghz_min = ghz.front();
+        if (ghz_max) *ghz_max = ghz.back();
+        if (ghz_median) *ghz_median = 0.5 * (ghz[(ghz.size() - 1) / 2] + ghz[ghz.size() / 2]);
+    });
+    (void)hipHostFree(s->stop);
+    (void)hipHostFree(s->out);
+    (void)hipStreamDestroy(s->stream);
+    delete s;
+    return rc;
+}
+
+int jinc_debug_valu_pair_probe(int device, int waves_per_simd, double* tops, double* shader_clock_ghz) {
+    if (waves_per_simd < 1 || waves_per_simd > 8 || !tops) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad argument.");
+    return guarded([&] {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        hipDeviceProp_t prop;
+        hip_check(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+        const int blocks = prop.multiProcessorCount * waves_per_simd;  // 256 threads = one wave per SIMD of a CU
+        const int iters = 100000;                                     // ~15 ms at 8 waves per SIMD
+        float* out = nullptr;
+        hip_check(hipMalloc(&out, sizeof(float) * 256 * blocks), "hipMalloc");
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hip_check(hipEventCreate(&e0), "hipEventCreate");
+        hip_check(hipEventCreate(&e1), "hipEventCreate");
+        jinc_clock_sampler* cs = nullptr;
+        double best = 1e30, ghz = 0.0;
+        for (int rep = 0; rep < 4; ++rep) {  // the first launch ramps the clock; the last one is sampled
+            if (rep == 3 && shader_clock_ghz) (void)jinc_debug_clock_sampler_start(device, 5.0, &cs);
+            hip_check(hipEventRecord(e0, nullptr), "hipEventRecord");
+            hip_check(static_cast<hipError_t>(jinc::launch_valu_pair_probe(out, blocks, iters, nullptr)), "probe launch");
+            hip_check(hipEventRecord(e1, nullptr), "hipEventRecord");
+            hip_check(hipEventSynchronize(e1), "hipEventSynchronize");
+            float ms = 0.f;
+            hip_check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+            if (rep > 0) best = std::min(best, static_cast<double>(ms));
+        }
+        if (cs) (void)jinc_debug_clock_sampler_stop(cs, nullptr, &ghz, nullptr);
+        *tops = 16.0 * iters * 256.0 * blocks / (best * 1e-3) / 1e12;
+        if (shader_clock_ghz) *shader_clock_ghz = ghz;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(out);
+    });
+}
+
 const char* jinc_debug_last_call(int* nframes) {
     if (nframes) *nframes = last_call_frames_in_process();
     return last_interior_kernel_in_process();
 }
+
+int jinc_filter_direct_premise(const jinc_filter* f) { return (f && f->device >= 0) ? (f->direct_premise ? 1 : 0) : -1; }
 
 int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");

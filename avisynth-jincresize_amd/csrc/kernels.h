@@ -242,6 +242,15 @@ int blit_unit(const void* src, const void* dst, uint32_t src_pitch, uint32_t dst
 int launch_blit_rows(const BlitEntry* table_device, int first, int count, uint32_t max_rows, uint32_t max_row_bytes, int workgroups,
                      void* stream);
 
+// Measurement hook (kernel_probe.hip): `samplers` single-lane workgroups stamp the shader clock counter and the 100 MHz
+// real-time counter until *stop_flag (pinned host memory) becomes non-zero or max_seconds pass; out[2 k] = shader ticks,
+// out[2 k + 1] = real-time ticks of sampler k.
+int launch_clock_sampler(const int* stop_flag, unsigned long long* out, int samplers, double max_seconds, void* stream);
+
+// Measurement hook: `blocks` x 256 lanes run iters x 8 (v_mul_f32 with an SGPR coefficient, v_add_f32 onto one chain);
+// out holds blocks x 256 floats.
+int launch_valu_pair_probe(float* out, int blocks, int iters, void* stream);
+
 // Test hook: applies the kernels' float -> sample conversion (clamp, round-half-even, store) to n sums.
 int launch_debug_convert(const float* in, void* out, int n, int sample_bytes, float peak, void* stream);
 

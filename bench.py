@@ -166,15 +166,135 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     o1, on1, oel1 = run(1, 2.0)     # ... and on one core
     path = ("own AVX2+FMA code in the reference's opt=2 summation order (not bit-equal to opt=0)" if have_avx2
             else "oracle (opt=0 port)")
-    return {"value": round(v, 2), "unit": "Mpix/s", "cores": best, "kind": "port",
-            "sample": f"{n} frames of {cfg_name} in {el:.1f}s; {path}, rows over {best} OpenMP threads, the fastest "
-                      f"of {cands} at {scan_s:.0f}s each, on a host with {avail} usable cores ({cpu_model()})",
+    # SURVEY 8(d)'s method next to it: whole frames in parallel, one single-thread instance per worker (how the reference is
+    # deployed: Prefetch(P), MT_MULTI_INSTANCE).  `value` = the better of the two methods, named in `method`.
+    fp_counts = sorted({p for p in (16, 64, 128, avail) if p <= avail} or {avail})
+    fp = cpu_frame_parallel(cfg_name, fp_counts)
+    fp_key = "avx2_order_Mpix_s" if have_avx2 else "opt0_port_Mpix_s"
+    fp_best = max(fp[fp_key], key=lambda k: fp[fp_key][k])
+    row_value, row_cores = v, best
+    method = "rows of one frame over OpenMP threads"
+    if fp[fp_key][fp_best] > v:
+        v, best = fp[fp_key][fp_best], int(fp_best)
+        method = "whole frames in parallel, one single-thread filter instance per worker (MT_MULTI_INSTANCE)"
+    return {"value": round(v, 2), "unit": "Mpix/s", "cores": best, "kind": "port", "method": method,
+            "sample": f"{path}; best of two methods on a host with {avail} usable cores ({cpu_model()}): (a) frame-parallel, "
+                      f"P single-thread instances for P in {fp_counts}, {fp['seconds_per_point']:.0f}s each; (b) {n} frames of {cfg_name} "
+                      f"in {el:.1f}s with rows over {row_cores} OpenMP threads, the fastest of {cands} at {scan_s:.0f}s each",
             "path": "avx2_order" if have_avx2 else "opt0_port",
+            "frame_parallel": fp, "row_parallel_value": round(row_value, 2), "row_parallel_cores": row_cores,
             "cpu_model": cpu_model(), "host_cores": avail,
             "single_core_value": round(v1, 2), "single_core_sample": f"{n1} frames in {el1:.1f}s",
             "runs_at_chosen_count_Mpix_s": [round(x, 1) for x in vals],
             "opt0_port_value": round(o_best, 2), "opt0_port_single_core_value": round(o1, 2),
             "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in scan.items()}}
+
+
+def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
+    """SURVEY 8(d)'s method: P single-thread workers, each with its OWN filter instance (tables of its own, like the P instances
+    AviSynth creates under Prefetch(P) for an MT_MULTI_INSTANCE filter, ref JincResize.cpp:649-652) and its own frames, all
+    running whole frames at once; aggregate Mpix/s for each P in `counts`, for the AVX2-order code and the opt=0 port."""
+    import threading
+    O = entry.load_oracle()
+    fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[cfg_name]
+    fmt = O.FORMATS[fmt_name]
+    have_avx2 = bool(O.lib().oracle_avx2_available())
+    pmax = max(counts)
+    workers = [None] * pmax
+
+    def build(k):  # instance k: plan build included here, untimed (the reference pays it per instance at script load)
+        flt = O.OracleFilter(fmt, sw, sh, dw, dh, **kw)
+        src = O.lcg_frame(fmt, sw, sh, seed=12345 + k)
+        dst = [O.alloc_plane(w, h, fmt.dtype) for (w, h) in flt.out_dims()]
+        workers[k] = (flt, src, dst)
+
+    t_build = time.perf_counter()
+    ts = [threading.Thread(target=build, args=(k,)) for k in range(pmax)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    t_build = time.perf_counter() - t_build
+
+    def run(p, avx2):
+        done = [0] * p
+        go, stop = threading.Event(), threading.Event()
+
+        def work(k):
+            flt, src, dst = workers[k]
+            go.wait()
+            while not stop.is_set():
+                for i, d in enumerate(dst):   # one frame = every plane, one thread (the library call releases the GIL)
+                    t = flt.table_for_plane(i)
+                    if avx2:
+                        t.resize_simd(2, src[i], d, -0.5 if (i and not fmt.rgb) else 0.0, 1, True)
+                    else:
+                        t.resize(src[i], d, flt.peak, 1)
+                done[k] += 1
+
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(p)]
+        [t.start() for t in ts]
+        t0 = time.perf_counter()
+        go.set()
+        time.sleep(seconds)
+        stop.set()
+        [t.join() for t in ts]   # frames in progress are finished and counted: elapsed includes them
+        el = time.perf_counter() - t0
+        return sum(done) * dw * dh / el / 1e6
+
+    out = {"instances_built_in_s": round(t_build, 2), "seconds_per_point": seconds, "avx2_order_Mpix_s": {}, "opt0_port_Mpix_s": {}}
+    for p in counts:
+        if have_avx2:
+            out["avx2_order_Mpix_s"][str(p)] = round(run(p, True), 1)
+        out["opt0_port_Mpix_s"][str(p)] = round(run(p, False), 1)
+    return out
+
+
+def e2e_record(pkg, config, depth=64, seconds=1.5):
+    """Host planes in, host planes out through the look-ahead pipeline (jinc_filter_submit / _wait, one host thread,
+    caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it."""
+    import numpy as np
+    fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
+    fmt = pkg.FORMATS[fmt_name]
+    frame_bytes = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
+    depth = max(2, min(depth, int((2 << 30) // max(1, frame_bytes))))   # at most ~2 GiB of host frames
+    f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
+    f.set_pipeline(depth, True)
+    rng = np.random.default_rng(3)
+    nbuf = depth + 1
+    srcs, dsts = [], []
+    for _ in range(nbuf):
+        planes = []
+        for (w, h) in fmt.plane_dims(sw, sh):
+            p = pkg.alloc_plane(w, h, fmt.dtype)
+            p[:] = (rng.random(p.shape) * (((1 << fmt.bits) - 1) if fmt.sample_bytes < 4 else 1)).astype(fmt.dtype)
+            planes.append(p)
+        srcs.append(planes)
+        dsts.append([pkg.alloc_plane(w, h, fmt.dtype) for (w, h) in fmt.plane_dims(dw, dh)])
+    tickets = []
+
+    def pump(n):
+        tickets.append(f.submit(srcs[n % nbuf], dsts[n % nbuf]))
+        if len(tickets) >= depth:
+            f.wait(tickets.pop(0))
+
+    for k in range(2 * nbuf):  # warm-up: allocations, registration
+        pump(k)
+    while tickets:
+        f.wait(tickets.pop(0))
+    n, t0, kernel = 0, time.perf_counter(), ""
+    while time.perf_counter() - t0 < seconds:
+        pump(n)
+        n += 1
+        if n == 2 * depth:
+            kernel = f.last_kernel(0)   # steady state, not the final partial group
+    while tickets:
+        f.wait(tickets.pop(0))
+    el = time.perf_counter() - t0
+    rec = {"what": "host planes -> jinc_filter_submit/_wait -> host planes, one host thread, buffers pinned in place; not `value`",
+           "frames_per_s": round(n / el, 1), "Mpix_per_s": round(n / el * dw * dh / 1e6, 1),
+           "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2), "frames_in_flight": depth, "frames_per_launch": f.pipeline_group,
+           "kernel": kernel, "seconds": round(el, 2)}
+    f.close()
+    return rec
 
 
 def make_workload(pkg, torch, config, frames, device, seed):
@@ -231,6 +351,8 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default per config)")
     ap.add_argument("--config", default="C2", help="one of CONFIGS (scripts may add entries before calling main())")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host record (untimed, after the timed region)")
+    ap.add_argument("--no-clock-sampler", action="store_true")
     ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
     args = ap.parse_args()
@@ -285,6 +407,8 @@ def main():
     torch.cuda.synchronize()
     flt.set_profiling(True)
     flt.kernel_times()  # reset
+    # shader clock WHILE the timed steps run: eight single-lane samplers (one per XCD) beside the kernels (kernel_probe.hip)
+    sampler = pkg.ClockSampler(local_rank, 60.0) if rank == 0 and not args.no_clock_sampler else None
     if use_dist:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
@@ -295,8 +419,16 @@ def main():
     if use_dist:
         dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
+    clock_ghz = sampler.stop() if sampler else None
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
+    # untimed, right after the timed region (clocks warm): what the kernels' instruction pair sustains on THIS part
+    pair_probe = None
+    if rank == 0 and not args.no_clock_sampler:
+        try:
+            pair_probe = {str(w): pkg.valu_pair_probe(local_rank, w) for w in (4, 6, 8)}
+        except Exception:  # noqa: BLE001
+            pair_probe = None
 
     frames_done = float(B * args.steps)
     elapsed_max, frames_all = aggregate(elapsed, frames_done, dist if use_dist else None)
@@ -319,10 +451,14 @@ def main():
         achieved_gbs = bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9
         valu_ops = 2.0 * fs * fs * samples_frame * B / (kernel_ms_per_step * 1e-3)
         traffic = traffic_raw = None
+        pmc_clock = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath)).get(args.config, {})
+                if "effective_clock_ghz" in rec:   # GRBM_GUI_ACTIVE / 8 / kernel time of the committed PMC pass
+                    pmc_clock = {"ghz": rec["effective_clock_ghz"], "kernel_ms_in_that_pass": rec.get("clock_pass_kernel_ms"),
+                                 "source": "profiles/traffic.json (rocprofv3 --pmc GRBM_GUI_ACTIVE pass of this command)"}
                 if "hbm_bytes_per_launch" in rec:  # PMC figure (2 x FETCH_SIZE + WRITE_SIZE), scaled to this run's frames per launch
                     scale = B / (rec.get("frames_per_launch") or B)
                     traffic = int(rec["hbm_bytes_per_launch"] * scale)
@@ -340,7 +476,7 @@ def main():
                        "sample_type": {1: "u8", 2: "u16", 4: "f32"}[sb], "frames_per_step_per_gpu": B,
                        "timed_region_s": round(elapsed_max, 4), "resident_bytes_per_gpu": (bytes_frame * B),
                        "untimed_spinup_ms_before_warmup": spin_ms, "parallelism": f"frames sharded over {world} GPU(s), no collective",
-                       "kernel": dom_name, "filter_size": fs, "plan_sets": info.num_sets,
+                       "kernel": dom_name, "direct_kernel_premise": flt.direct_premise, "filter_size": fs, "plan_sets": info.num_sets,
                        "plan_bytes": int(info.plan_bytes)},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -352,10 +488,27 @@ def main():
                          "binding_roof": "un-fused fp32 VALU (v_mul_f32+v_add_f32 per tap; FMA/MFMA would break bit-exactness)",
                          "valu_achieved_Tops": round(valu_ops / 1e12, 2), "valu_peak_Tops": VALU_UNFUSED_PEAK / 1e12,
                          "valu_frac": round(valu_ops / VALU_UNFUSED_PEAK, 4),
+                         # what the part sustained in THIS run: shader clock sampled beside the timed kernels (median / min / max
+                         # over 8 samplers = XCDs), the VALU peak at that clock and the fraction of it
+                         "shader_clock_ghz": round(clock_ghz[1], 3) if clock_ghz else None,
+                         "shader_clock_ghz_min_max": [round(clock_ghz[0], 3), round(clock_ghz[2], 3)] if clock_ghz else None,
+                         "valu_peak_at_clock_Tops": round(256 * 128 * clock_ghz[1] * 1e9 / 1e12, 2) if clock_ghz else None,
+                         "valu_frac_at_clock": round(valu_ops / (256 * 128 * clock_ghz[1] * 1e9), 4) if clock_ghz else None,
+                         "effective_clock_ghz": pmc_clock["ghz"] if pmc_clock else None, "effective_clock_pmc": pmc_clock,
+                         # plain v_mul_f32 (SGPR coefficient) + v_add_f32 with nothing else in the loop, chip filled at 4 / 6 / 8
+                         # waves per SIMD, measured on this device right after the timed region: [Tops, shader clock GHz]
+                         "valu_pair_sustained_Tops": {w: [round(t, 2), round(g, 3)] for w, (t, g) in pair_probe.items()} if pair_probe else None,
+                         "valu_frac_of_pair_sustained": round(valu_ops / 1e12 / max(t for t, _ in pair_probe.values()), 4) if pair_probe else None,
                          # the north_star's "HBM-read" reading: source bytes only (each source sample once)
                          "hbm_read_frac": round(src_bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "border_kernel_ms_per_step": round(gat_ms / args.steps, 4) if per_n > 0 else None},
         }
+        line["e2e"] = None
+        if world == 1 and not args.no_e2e:
+            try:
+                line["e2e"] = e2e_record(pkg, args.config)
+            except Exception as exc:  # noqa: BLE001  (a record next to the value, never a reason to lose the line)
+                line["e2e"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config)
         else:

@@ -59,9 +59,24 @@ JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table
 /* Name of the kernel that computed the interior of `table` in the most recent frame call (the choice depends on the
  * batch size: the frame-lane kernel needs a batch). "" before the first call. */
 JINC_API const char *jinc_filter_last_kernel(const jinc_filter *f, int table);
+/* 1: the device's buffer range check covers the scalar offset, so ewa_direct_kernel and the strip border kernels are in
+ * use; 0: it does not, and their plans run on the gather kernel (bench.py reports it: a silent fallback would show);
+ * -1: host-only instance. */
+JINC_API int jinc_filter_direct_premise(const jinc_filter *f);
 /* Frames the look-ahead pipeline coalesces into one launch (what jinc_filter_set_pipeline[_group] settled on after its
  * automatic rule and the device-memory budget). */
 JINC_API int jinc_filter_pipeline_group(const jinc_filter *f);
+/* Shader clock WHILE other kernels run (bench.py: roofline.shader_clock_ghz): start launches eight single-lane samplers on
+ * a stream of their own (one per XCD; they stamp the shader-clock and the 100 MHz real-time counters and sleep in between),
+ * stop raises their flag, waits for them and reports min / median / max over the samplers of
+ * d(shader ticks) / d(real-time ticks) x 0.1 GHz.  max_seconds (<= 120) bounds their life if stop is never called. */
+typedef struct jinc_clock_sampler jinc_clock_sampler;
+JINC_API int jinc_debug_clock_sampler_start(int device, double max_seconds, jinc_clock_sampler **out);
+JINC_API int jinc_debug_clock_sampler_stop(jinc_clock_sampler *s, double *ghz_min, double *ghz_median, double *ghz_max);
+/* What the hot kernels' instruction pair sustains on this part (bench.py: roofline.valu_pair_sustained_Tops): v_mul_f32 with
+ * an SGPR coefficient + v_add_f32 onto one chain per lane, nothing else in the loop, the chip filled with waves_per_simd
+ * waves per SIMD; Tops = multiplies + adds per second / 1e12, and the shader clock sampled beside the last launch. */
+JINC_API int jinc_debug_valu_pair_probe(int device, int waves_per_simd, double *tops, double *shader_clock_ghz);
 /* Interior kernel (of table 0) and frame count of the most recent kernel call of ANY filter instance in this process:
  * for tests that drive the plugin shell and cannot reach its jinc_filter handles. */
 JINC_API const char *jinc_debug_last_call(int *nframes);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rebuilds profiles/traffic.json (what bench.py copies into roofline.traffic) from the PMC summaries of a round.
 
-usage: make_traffic.py <round-dir> <tag>     e.g.  make_traffic.py round2 r2t  -> reads profiles/round2/r2u_c{2,3,4}.json
+usage: make_traffic.py <round-dir> <tag>     e.g.  make_traffic.py round3 r3v  -> reads profiles/round3/r3v_c{2,3,4}.json
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024, separate --pmc passes).  The x2 on the read side is the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the requests are 128 B); round 1
@@ -32,5 +32,8 @@ for cfg in ("C2", "C3", "C4", "A137", "N15"):
                 "frames_per_launch": d.get("frames_per_launch"),
                 "kernel": name, "fetch_bytes_raw": int(round(e["FETCH_SIZE_bytes_mean"])), "write_bytes": int(round(e["WRITE_SIZE_bytes_mean"])),
                 "avg_ns_under_rocprof": e["avg_ns"], "calls": e["calls"]}
+    if "effective_clock_ghz" in e:   # GRBM_GUI_ACTIVE / 8 / dispatch duration, mean over the launches of that pass
+        out[cfg]["effective_clock_ghz"] = round(e["effective_clock_ghz"], 4)
+        out[cfg]["clock_pass_kernel_ms"] = round(e["clock_pass_kernel_ns"] / 1e6, 4)
 json.dump(out, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -54,6 +54,29 @@ def main():
                 e[c + "_bytes_mean"] = sum(v) / len(v) * 1024
                 e[c + "_launches"] = len(v)
                 e.update(meta[k])
+    # GRBM_GUI_ACTIVE pass (third pmc directory, optional): effective clock of a dispatch = counter / 8 XCDs / its duration
+    # (MI355X_MICROARCH.md, DVFS give-back); durations from the same pass's kernel trace, joined by dispatch id
+    for d in sys.argv[3:]:
+        dur = {}
+        for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                dur[r.get("Dispatch_Id")] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            clk = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                k = short(r["Kernel_Name"])
+                if not k or r["Counter_Name"] != "GRBM_GUI_ACTIVE":
+                    continue
+                ns = dur.get(r.get("Dispatch_Id"))
+                if ns is None and "Start_Timestamp" in r:
+                    ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                if ns:
+                    clk[k].append((float(r["Counter_Value"]) / 8.0 / ns, ns))
+            for k, v in clk.items():
+                e = out["kernels"].setdefault(k, {})
+                e["effective_clock_ghz"] = sum(c for c, _ in v) / len(v)
+                e["clock_pass_kernel_ns"] = sum(n for _, n in v) / len(v)
+                e["clock_pass_launches"] = len(v)
     for k, e in out["kernels"].items():
         if "FETCH_SIZE_bytes_mean" in e and "WRITE_SIZE_bytes_mean" in e:
             e["hbm_bytes_per_launch_raw"] = e["FETCH_SIZE_bytes_mean"] + e["WRITE_SIZE_bytes_mean"]
