@@ -79,7 +79,10 @@ def test_batches_of_frames(gpu_pkg, O, case):
                          [t.data_ptr() for t in dst_t], [t.stride(1) * sb for t in dst_t], [t.stride(0) * sb for t in dst_t],
                          n, stream=stream.cuda_stream)
         stream.synchronize()
-        assert f.last_kernel(0).startswith("ewa_framelane"), f.last_kernel(0)
+        # (last_kernel names the kernel of the batch's last part: beyond whole groups of 128 frames a remainder of fewer than 16
+        # frames is a call of its own under the normal rules -- for these plans the gather kernel)
+        small_rest = n > 128 and 0 < n % 128 < 16   # (automatic mode: n >= 24)
+        assert f.last_kernel(0).startswith("ewa_gather" if small_rest else "ewa_framelane"), (n, f.last_kernel(0))
         for k in range(n):
             got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
             assert_planes_equal(got, wants[k], ddims, what=f"batch {n} frame {k}")

@@ -675,7 +675,16 @@ def test_randomised_arguments(gpu_pkg, O, seed, gen):
     src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=seed)
     want = of.get_frame(src, threads=4)
     got = f.get_frame(src)
-    assert_planes_equal(got, want, f.out_dims(), what=f"gen {gen} seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}")
+    what = f"gen {gen} seed {seed}: {fmt} {sw}x{sh}->{tw}x{th} {kw}"
+    assert_planes_equal(got, want, f.out_dims(), what=what)
+    # Plans with affine window origins: the quasi-periodic kernel in each of its forms, whatever the automatic choice was
+    # (calls of fewer than 3e6 samples -- every frame of this sweep -- go to the gather kernel since round 2): 7 = per-lane
+    # coefficient registers / exact, 8 = waterfall over sets in SGPRs, 10 = per-row look-up + per-lane registers; each also
+    # with a tile's phases split over several workgroups (what small calls do in automatic mode).
+    if any(f.plan_info(t).quasi for t in range(f.num_tables)):
+        for mode in (7, 8, 10):
+            f.set_kernel_mode(mode)
+            assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + f" kernel mode {mode}")
     f.close()
 
 

@@ -407,3 +407,40 @@ def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, 
     host.mock_source_release(src)
     assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
     h.close()
+
+
+@pytest.mark.gpu
+def test_script_floats_arrive_as_32_bit_values(host, O, pkg):
+    """AviSynth hands script floats over as 32-bit values (AVS_Value.d.floating_pt; the reference reads them with avs_as_float,
+    ref :762-774): JincResize(blur=0.98) computes with (double)(float)0.98 = 0.98000001907..., not with 0.98.  On float planes
+    the two differ in a large share of the output samples, so the plugin path must match the oracle fed the float32-rounded
+    arguments -- and an ABI caller that passes the double 0.98 gets the double's result."""
+    fmt_name, sw, sh, tw, th = "RGBPS", 96, 64, 150, 100
+    fmt = O.FORMATS[fmt_name]
+    frames = [O.lcg_frame(fmt, sw, sh, seed=77)]
+    named = dict(blur=0.98, src_left=0.1, src_top=0.3, src_width=90.7, src_height=60.1, tap=4)
+    as_f32 = {k: (float(np.float32(v)) if isinstance(v, float) else v) for k, v in named.items()}
+    assert as_f32["blur"] != named["blur"]
+    want32 = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(as_f32)).get_frame(frames[0], threads=4)
+    want64 = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(named)).get_frame(frames[0], threads=4)
+    differing = sum(int(np.count_nonzero(a[:th, :tw].view(np.uint32) != b[:th, :tw].view(np.uint32))) for a, b in zip(want32, want64))
+    assert differing > 0.05 * 3 * tw * th, "the case does not tell float32 arguments from doubles"
+    h = Host(host)
+    src = h.source(fmt, sw, sh, frames)
+    clip, err = h.invoke("JincResize", src, tw, th, **named)
+    assert err is None, err
+    fr = host.mock_clip_get_frame(clip, 0)
+    assert host.mock_clip_error(clip) is None
+    got = [h.read_plane(fr, i, np.float32) for i in range(3)]
+    assert_planes_equal(got, want32, fmt.plane_dims(tw, th), what="plugin path: float32-rounded script arguments")
+    host.mock_frame_release(fr)
+    host.mock_clip_release(clip)
+    host.mock_source_release(src)
+    h.close()
+    # the C ABI takes doubles as they are
+    f = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **named)
+    assert_planes_equal(f.get_frame(frames[0]), want64, f.out_dims(), what="C ABI: double arguments")
+    f.close()
+    f = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **as_f32)
+    assert_planes_equal(f.get_frame(frames[0]), want32, f.out_dims(), what="C ABI: float32-rounded arguments")
+    f.close()
