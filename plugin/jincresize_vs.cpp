@@ -1,0 +1,203 @@
+// jincresize_vs.cpp -- VapourSynth (API 4) front-end around libjincresize_hip.so ("a VapourSynth front-end
+// -- the upstream lineage named in README.md:5 -- reusing the same HIP library").
+//
+// Registers jinc.JincResize and jinc.Jinc36Resize / Jinc64Resize / Jinc144Resize / Jinc256Resize with the AviSynth
+// plugin's argument names (/root/reference/README.md:17-111, registration /root/reference/src/JincResize.cpp:1044-1108), hands
+// them to the same C ABI (include/jincresize_hip.h) the AviSynth shell uses -- same defaults, same checks, same messages
+// (jinc_filter_create) -- and implements the filter's getFrame on jinc_filter_get_frame.  All resampling happens behind that
+// ABI on the GPU; there is no CPU path in this file.
+//
+// What differs from the AviSynth shell, by the host's nature:
+//   * arguments are named map entries; floats arrive as doubles (no float32 rounding as in AVS_Value);
+//   * planar RGB planes are ordered R, G, B (AviSynth: G, B, R) -- all three use the same table, so the order is immaterial;
+//   * there is no alpha plane inside a VapourSynth format;
+//   * one filter instance serves the whole graph: fmUnordered = one getFrame at a time, in any order (the instance is not
+//     re-entrant, like the reference's MT_MULTI_INSTANCE instances).
+//
+// Build against a VapourSynth installation (its SDK header first on the include path):
+//   g++ -std=c++17 -shared -fPIC plugin/jincresize_vs.cpp -Iinclude -I<vapoursynth sdk>/include
+//       -Lavisynth-jincresize_amd/lib -ljincresize_hip -o libjincresize_vs.so
+// In this repository it is compiled against plugin/compat/VapourSynth4.h (self-written declaration, see its verify-list)
+// and tested with the mock host of tests/mock_vs/ (tests/test_plugin_vs_mock_host.py).
+#include "VapourSynth4.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "jincresize_hip.h"
+
+namespace {
+
+struct Instance {
+    VSNode* node = nullptr;
+    VSVideoInfo vi{};            // output
+    jinc_filter* filter = nullptr;
+    int chroma_location = -1;    // value written to _ChromaLocation, -1: format without sub-sampled chroma
+    int planes = 0;
+};
+
+const VSFrame* VS_CC jinc_vs_get_frame(int n, int activationReason, void* instanceData, void**, VSFrameContext* frameCtx, VSCore* core,
+                                       const VSAPI* vsapi) {
+    Instance* d = static_cast<Instance*>(instanceData);
+    if (activationReason == arInitial) {
+        vsapi->requestFrameFilter(n, d->node, frameCtx);
+        return nullptr;
+    }
+    if (activationReason != arAllFramesReady) return nullptr;
+    const VSFrame* src = vsapi->getFrameFilter(n, d->node, frameCtx);
+    VSFrame* dst = vsapi->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);  // inherits the frame properties (ref :613)
+    const void* sp[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* dp[4] = {nullptr, nullptr, nullptr, nullptr};
+    int spitch[4] = {0, 0, 0, 0}, dpitch[4] = {0, 0, 0, 0};
+    for (int i = 0; i < d->planes; ++i) {
+        sp[i] = vsapi->getReadPtr(src, i);
+        spitch[i] = static_cast<int>(vsapi->getStride(src, i));
+        dp[i] = vsapi->getWritePtr(dst, i);
+        dpitch[i] = static_cast<int>(vsapi->getStride(dst, i));
+    }
+    if (jinc_filter_get_frame(d->filter, sp, spitch, dp, dpitch) != JINC_OK) {  // no CPU fallback: the failure goes to the host
+        vsapi->setFilterError(jinc_last_error(), frameCtx);
+        vsapi->freeFrame(src);
+        vsapi->freeFrame(dst);
+        return nullptr;
+    }
+    if (d->chroma_location >= 0)  // ref :617-625
+        vsapi->mapSetInt(vsapi->getFramePropertiesRW(dst), "_ChromaLocation", d->chroma_location, maReplace);
+    vsapi->freeFrame(src);  // ref :627
+    return dst;
+}
+
+void VS_CC jinc_vs_free(void* instanceData, VSCore*, const VSAPI* vsapi) {  // ref :632-647
+    Instance* d = static_cast<Instance*>(instanceData);
+    jinc_filter_free(d->filter);
+    vsapi->freeNode(d->node);
+    delete d;
+}
+
+// userData = 0: JincResize; 3 / 4 / 6 / 8: the alias with that tap count (ref :1007-1040: the alias forwards src_*, quant_*,
+// cplace, threads and adds tap).
+void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* core, const VSAPI* vsapi) {
+    const int alias_taps = static_cast<int>(reinterpret_cast<intptr_t>(userData));
+    int err = 0;
+    VSNode* node = vsapi->mapGetNode(in, "clip", 0, &err);
+    if (err || !node) {
+        vsapi->mapSetError(out, "JincResize: clip is required.");
+        return;
+    }
+    auto fail = [&](const char* msg) {
+        vsapi->mapSetError(out, msg);
+        vsapi->freeNode(node);
+    };
+    const VSVideoInfo* vi = vsapi->getVideoInfo(node);
+    if (vi->format.colorFamily == cfUndefined || vi->width <= 0 || vi->height <= 0)
+        return fail("JincResize: clip must have a constant format and size.");
+
+    jinc_video_info jvi;
+    std::memset(&jvi, 0, sizeof jvi);
+    jvi.width = vi->width;
+    jvi.height = vi->height;
+    jvi.bits_per_component = vi->format.bitsPerSample;
+    jvi.component_size = vi->format.bytesPerSample;
+    jvi.num_components = vi->format.numPlanes;
+    jvi.is_planar = 1;  // every VapourSynth video format is planar
+    jvi.is_rgb = vi->format.colorFamily == cfRGB;
+    jvi.sub_w = vi->format.subSamplingW;
+    jvi.sub_h = vi->format.subSamplingH;
+    if (vi->format.sampleType == stFloat && vi->format.bitsPerSample != 32) return fail("JincResize: half-precision float clips are not supported.");
+
+    jinc_args a;
+    std::memset(&a, 0, sizeof a);
+    auto has = [&](const char* key) { return vsapi->mapNumElements(in, key) > 0; };
+    auto get_int = [&](const char* key, unsigned bit, int& field) {
+        if (!has(key)) return;
+        field = static_cast<int>(vsapi->mapGetInt(in, key, 0, &err));
+        a.defined |= bit;
+    };
+    auto get_float = [&](const char* key, unsigned bit, double& field) {
+        if (!has(key)) return;
+        field = vsapi->mapGetFloat(in, key, 0, &err);
+        a.defined |= bit;
+    };
+    a.target_width = static_cast<int>(vsapi->mapGetInt(in, "target_width", 0, &err));
+    a.target_height = static_cast<int>(vsapi->mapGetInt(in, "target_height", 0, &err));
+    get_float("src_left", JINC_ARG_SRC_LEFT, a.src_left);
+    get_float("src_top", JINC_ARG_SRC_TOP, a.src_top);
+    get_float("src_width", JINC_ARG_SRC_WIDTH, a.src_width);
+    get_float("src_height", JINC_ARG_SRC_HEIGHT, a.src_height);
+    get_int("quant_x", JINC_ARG_QUANT_X, a.quant_x);
+    get_int("quant_y", JINC_ARG_QUANT_Y, a.quant_y);
+    get_int("threads", JINC_ARG_THREADS, a.threads);
+    std::string cplace;
+    if (has("cplace")) {
+        const char* s = vsapi->mapGetData(in, "cplace", 0, &err);
+        cplace.assign(s ? s : "", static_cast<size_t>(std::max(0, vsapi->mapGetDataSize(in, "cplace", 0, &err))));
+        a.cplace = cplace.c_str();
+        a.defined |= JINC_ARG_CPLACE;
+    }
+    if (alias_taps == 0) {  // JincResize only
+        get_int("tap", JINC_ARG_TAP, a.tap);
+        get_float("blur", JINC_ARG_BLUR, a.blur);
+        get_int("opt", JINC_ARG_OPT, a.opt);
+        get_int("initial_capacity", JINC_ARG_INITIAL_CAPACITY, a.initial_capacity);
+        get_float("initial_factor", JINC_ARG_INITIAL_FACTOR, a.initial_factor);
+    }
+    // cplace not given: the first frame's _ChromaLocation decides (ref :727-742); the ABI applies the rules
+    a.frame0_chroma_location = -1;
+    if (!(a.defined & JINC_ARG_CPLACE)) {
+        char msg[256];
+        if (const VSFrame* frame0 = vsapi->getFrame(0, node, msg, sizeof msg)) {
+            const VSMap* props = vsapi->getFramePropertiesRO(frame0);
+            if (vsapi->mapGetType(props, "_ChromaLocation") == ptInt)
+                a.frame0_chroma_location = static_cast<int>(vsapi->mapGetInt(props, "_ChromaLocation", 0, &err));
+            vsapi->freeFrame(frame0);
+        }
+    }
+    __builtin_cpu_init();  // ref :748-756: opt = 1 / 2 / 3 are validated against the host CPU as in the reference
+    a.cpu_has_sse41 = __builtin_cpu_supports("sse4.1") != 0;
+    a.cpu_has_avx2 = __builtin_cpu_supports("avx2") != 0;
+    a.cpu_has_avx512f = __builtin_cpu_supports("avx512f") != 0;
+
+    jinc_args final_args = a;
+    if (alias_taps != 0 && jinc_alias_args(alias_taps, &a, &final_args) != JINC_OK) return fail(jinc_last_error());
+    if (alias_taps != 0) final_args.cplace = a.cplace;
+
+    char msg[512];
+    jinc_filter* filter = nullptr;
+    if (jinc_filter_create(&jvi, &final_args, jinc_pick_device(), &filter, msg, sizeof msg) != JINC_OK) return fail(msg);
+
+    Instance* d = new Instance;
+    d->node = node;
+    d->filter = filter;
+    d->chroma_location = jinc_filter_chroma_location(filter);
+    d->planes = vi->format.numPlanes;
+    d->vi = *vi;
+    jinc_video_info out_vi;
+    jinc_filter_output_info(filter, &out_vi);  // ref :791-792
+    d->vi.width = out_vi.width;
+    d->vi.height = out_vi.height;
+    VSFilterDependency deps[1] = {{node, rpStrictSpatial}};  // frame n of the output needs frame n of the input, nothing else
+    vsapi->createVideoFilter(out, alias_taps ? "JincAliasResize" : "JincResize", &d->vi, jinc_vs_get_frame, jinc_vs_free, fmUnordered, deps, 1, d,
+                             core);
+}
+
+}  // namespace
+
+VS_EXTERNAL_API(void) VapourSynthPluginInit2(VSPlugin* plugin, const VSPLUGINAPI* vspapi) {
+    vspapi->configPlugin("com.jincresize.mi355x", "jinc", "EWA Jinc resampler (JincResize) on MI355X", VS_MAKE_VERSION(2, 1), VAPOURSYNTH_API_VERSION, 0,
+                         plugin);
+    // the reference's parameter list (ref :1044-1060), as named map entries
+    vspapi->registerFunction("JincResize",
+                             "clip:vnode;target_width:int;target_height:int;src_left:float:opt;src_top:float:opt;src_width:float:opt;"
+                             "src_height:float:opt;quant_x:int:opt;quant_y:int:opt;tap:int:opt;blur:float:opt;cplace:data:opt;threads:int:opt;"
+                             "opt:int:opt;initial_capacity:int:opt;initial_factor:float:opt;",
+                             "clip:vnode;", jinc_vs_create, nullptr, plugin);
+    static const char kAliasArgs[] =
+        "clip:vnode;target_width:int;target_height:int;src_left:float:opt;src_top:float:opt;src_width:float:opt;src_height:float:opt;"
+        "quant_x:int:opt;quant_y:int:opt;cplace:data:opt;threads:int:opt;";  // ref :1061-1108
+    static const struct { const char* name; intptr_t taps; } kAliases[] = {
+        {"Jinc36Resize", 3}, {"Jinc64Resize", 4}, {"Jinc144Resize", 6}, {"Jinc256Resize", 8}};
+    for (const auto& al : kAliases) vspapi->registerFunction(al.name, kAliasArgs, "clip:vnode;", jinc_vs_create, reinterpret_cast<void*>(al.taps), plugin);
+}
