@@ -390,9 +390,10 @@ int jinc_debug_clock_sampler_start(int device, double max_seconds, jinc_clock_sa
     s->device = device;
     const int rc = guarded([&] {
         hip_check(hipSetDevice(device), "hipSetDevice");
-        int least = 0, greatest = 0;
-        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-        hip_check(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, greatest), "hipStreamCreate");
+        // default priority: a dispatch that stays active on a HIGH-priority stream throttles the wave launch of every other
+        // queue for as long as it lives (measured: eight sleeping sampler waves at the highest priority cost the direct
+        // kernels 10-15 %: 1080p -> 720p 256 -> 223 Gpix/s; profiles/round3/clock_sampler_priority.log)
+        hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipHostMalloc(reinterpret_cast<void**>(&s->stop), sizeof(int), hipHostMallocDefault), "hipHostMalloc");
         hip_check(hipHostMalloc(reinterpret_cast<void**>(&s->out), sizeof(unsigned long long) * 2 * jinc_clock_sampler::kSamplers, hipHostMallocDefault),
                   "hipHostMalloc");

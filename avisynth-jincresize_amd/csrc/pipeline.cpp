@@ -302,9 +302,12 @@ void ensure_belts(jinc_filter& f) {
     hip_check(hipStreamCreateWithFlags(&f.h2d_stream, hipStreamNonBlocking), "hipStreamCreate(arrivals)");
     int least = 0, greatest = 0;
     hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    const char* e = std::getenv("JINC_D2H_PRIORITY");
-    const int prio = (e && std::atoi(e) == 0) ? least : greatest;
-    hip_check(hipStreamCreateWithPriority(&f.d2h_stream, hipStreamNonBlocking, prio), "hipStreamCreate(departures)");
+    const char* e = std::getenv("JINC_D2H_PRIORITY");  // A/B knob: 0 lowest, 1 highest (default), 2 normal
+    const int mode = e ? std::atoi(e) : 1;
+    if (mode == 2)
+        hip_check(hipStreamCreateWithFlags(&f.d2h_stream, hipStreamNonBlocking), "hipStreamCreate(departures)");
+    else
+        hip_check(hipStreamCreateWithPriority(&f.d2h_stream, hipStreamNonBlocking, mode == 0 ? least : greatest), "hipStreamCreate(departures)");
 }
 }  // namespace
 

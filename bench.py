@@ -407,8 +407,6 @@ def main():
     torch.cuda.synchronize()
     flt.set_profiling(True)
     flt.kernel_times()  # reset
-    # shader clock WHILE the timed steps run: eight single-lane samplers (one per XCD) beside the kernels (kernel_probe.hip)
-    sampler = pkg.ClockSampler(local_rank, 60.0) if rank == 0 and not args.no_clock_sampler else None
     if use_dist:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
@@ -419,9 +417,19 @@ def main():
     if use_dist:
         dist.barrier(device_ids=[local_rank])
     elapsed = time.perf_counter() - t0
-    clock_ghz = sampler.stop() if sampler else None
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
+    # Shader clock under this load, in a SECOND, untimed pass of the same steps with eight single-lane samplers (one per XCD)
+    # beside the kernels (kernel_probe.hip).  Not during the timed region: any second dispatch that stays active, however
+    # small, costs kernels with short-lived workgroups 10-15 % (1080p -> 720p 253 -> 222 Gpix/s, C2 1 %;
+    # profiles/round3/clock_sampler_priority.log), so the value is taken without it and the clock right after.
+    clock_ghz = None
+    if rank == 0 and not args.no_clock_sampler:
+        sampler = pkg.ClockSampler(local_rank, 60.0)
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        clock_ghz = sampler.stop()
     # untimed, right after the timed region (clocks warm): what the kernels' instruction pair sustains on THIS part
     pair_probe = None
     if rank == 0 and not args.no_clock_sampler:
@@ -488,13 +496,17 @@ def main():
                          "binding_roof": "un-fused fp32 VALU (v_mul_f32+v_add_f32 per tap; FMA/MFMA would break bit-exactness)",
                          "valu_achieved_Tops": round(valu_ops / 1e12, 2), "valu_peak_Tops": VALU_UNFUSED_PEAK / 1e12,
                          "valu_frac": round(valu_ops / VALU_UNFUSED_PEAK, 4),
-                         # what the part sustained in THIS run: shader clock sampled beside the timed kernels (median / min / max
-                         # over 8 samplers = XCDs), the VALU peak at that clock and the fraction of it
+                         # what the part sustains under this load: shader clock sampled beside the same steps in a second, untimed pass
+                         # right after the timed one (median / min / max over 8 samplers = XCDs), the VALU peak at that clock and
+                         # the fraction of it
                          "shader_clock_ghz": round(clock_ghz[1], 3) if clock_ghz else None,
                          "shader_clock_ghz_min_max": [round(clock_ghz[0], 3), round(clock_ghz[2], 3)] if clock_ghz else None,
-                         "valu_peak_at_clock_Tops": round(256 * 128 * clock_ghz[1] * 1e9 / 1e12, 2) if clock_ghz else None,
-                         "valu_frac_at_clock": round(valu_ops / (256 * 128 * clock_ghz[1] * 1e9), 4) if clock_ghz else None,
+                         "valu_frac_at_sampled_clock": round(valu_ops / (256 * 128 * clock_ghz[1] * 1e9), 4) if clock_ghz else None,
+                         # the micro-architecture guide's recipe: GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the committed PMC pass of
+                         # this command (profiles/traffic.json); it reads ~12 % below the sampled shader clock
                          "effective_clock_ghz": pmc_clock["ghz"] if pmc_clock else None, "effective_clock_pmc": pmc_clock,
+                         "valu_peak_at_clock_Tops": round(256 * 128 * pmc_clock["ghz"] * 1e9 / 1e12, 2) if pmc_clock else None,
+                         "valu_frac_at_clock": round(valu_ops / (256 * 128 * pmc_clock["ghz"] * 1e9), 4) if pmc_clock else None,
                          # plain v_mul_f32 (SGPR coefficient) + v_add_f32 with nothing else in the loop, chip filled at 4 / 6 / 8
                          # waves per SIMD, measured on this device right after the timed region: [Tops, shader clock GHz]
                          "valu_pair_sustained_Tops": {w: [round(t, 2), round(g, 3)] for w, (t, g) in pair_probe.items()} if pair_probe else None,

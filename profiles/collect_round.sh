@@ -6,9 +6,11 @@
 # gpurun_out/<tag>_*; profiles/summarize.py condenses it into profiles/<round-dir>/ (copied to gpurun_out/ as well).
 tag=${1:-r3x}
 export JINC_PROFILE_DIR=${2:-round3}
+part=${3:-all}   # profiles | lines | all  (one gpurun call may run 1200 s at most: the two halves fit, the whole does not)
 ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/$JINC_PROFILE_DIR
+if [ "$part" != lines ]; then
 for c in C2 C3 C4 A137 N15; do
   export JINC_FRAMES_PER_LAUNCH=$(python -c "import bench; print(bench.CONFIGS['$c'][6])")
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$c -- python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/${tag}_stats_$c.log 2>&1
@@ -19,6 +21,8 @@ for c in C2 C3 C4 A137 N15; do
   grep "^{" gpurun_out/${tag}_stats_$c.log | tail -1 > profiles/$JINC_PROFILE_DIR/${tag}_stats_bench_$c.json
 done
 cp profiles/$JINC_PROFILE_DIR/${tag}_* gpurun_out/$JINC_PROFILE_DIR/ 2>/dev/null
+fi
+[ "$part" = profiles ] && exit 0
 for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875; do
   timeout 120 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
   python profiles/bench_line.py < gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
