@@ -164,6 +164,11 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
             return;
         }
     }
+    auto quad_chosen = [&](const DeviceTable& t) {   // (the same rule as at the launch below)
+        if (!t.periodic.quad) return false;
+        const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 55) / 56) * nframes;
+        return f.kernel_mode == 13 || (f.kernel_mode == 0 && wgs >= Rules::kHalfTileMaxWorkgroups);
+    };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
@@ -265,7 +270,8 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         const bool periodic = !direct && !quasi && wants_periodic(t);
         t.last_kernel = direct     ? "ewa_direct_kernel"
                         : quasi    ? "ewa_quasi_kernel"
-                        : periodic ? ((f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
+                        : periodic ? (quad_chosen(t) ? "ewa_periodic_quad_kernel"
+                                      : (f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
                                       : (f.kernel_mode == 3 || (t.plan.fs != 7 && t.plan.fs != 9)) ? "ewa_periodic_rows_kernel"
                                                                                                     : "ewa_periodic_kernel")
                                    : "ewa_gather_kernel";
@@ -324,7 +330,15 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                 });
             else
                 timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
-                    int variant = f.kernel_mode >= 3 ? f.kernel_mode - 2 : 0;
+                    int variant = (f.kernel_mode >= 3 && f.kernel_mode <= 6) ? f.kernel_mode - 2 : 0;
+                    // quad form (2x up-scales whose phases share their window origin: a lane computes a period's 2 x 2 pixels from
+                    // one window on packed multiplies / adds): +2.5 .. 6 % on calls that fill the chip (C2 at 16 / 1024 frames
+                    // 544 -> 560 / 591 -> 606 Gpix/s, 16-bit 4:2:0 356 -> 365, float RGB 165 -> 175), -5 % on a 4-frame call
+                    // (profiles/round3/quad_ab.log): automatic for full-tile launches, kernel mode 13 forces it, 2 excludes it
+                    const long long quad_wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 55) / 56) * nframes;
+                    const bool quad = t.periodic.quad != nullptr &&
+                                      (f.kernel_mode == 13 || (f.kernel_mode == 0 && quad_wgs >= Rules::kHalfTileMaxWorkgroups));
+                    if (quad) variant = 5;
                     // Small calls (single frames, short batches) take the window kernels' half-height tiles: twice the
                     // workgroups for a launch that does not fill the chip (C2, one frame: 600 workgroups on 1536 slots,
                     // kernel 27.2 -> 22.3 us; 4 frames: 323 -> 354 Gpix/s); long batches keep the full tiles (+2 %).
@@ -332,6 +346,9 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                         const int rows = t.plan.fs * (t.plan.fs == 7 ? 8 : 9);  // period-rows of a full tile
                         const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + rows - 1) / rows) * nframes;
                         if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
+                    }
+                    if (quad) {
+                        if (quad_wgs < Rules::kHalfTileMaxWorkgroups) variant = 6;
                     }
                     return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);
                 });

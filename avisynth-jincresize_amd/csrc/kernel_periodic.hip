@@ -148,6 +148,21 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 // exactly the scalar chain).  The coefficient stays in an SGPR and is broadcast to both halves by op_sel.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Two horizontally adjacent samples of a lane through the buffer resource: one 2-sample store.
+template <typename T>
+__device__ __forceinline__ void store_pair_buf(BufferRsrc rsrc, uint32_t voffset, uint32_t soffset, f32x2 r, float peak) {
+    if constexpr (std::is_same_v<T, float>) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, r), rsrc, voffset, soffset, 0);
+    } else if constexpr (std::is_same_v<T, uint8_t>) {
+        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(r.x, 0u, 0u);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(r.y, 1u, w);
+        __builtin_amdgcn_raw_buffer_store_b16(static_cast<uint16_t>(w), rsrc, voffset, soffset, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(round_sample(r.x, peak) | (round_sample(r.y, peak) << 16), rsrc, voffset, soffset, 0);
+    }
+}
+
 // acc-independent product of a 2-vector with ONE coefficient taken from the low (HI = false) or high half of
 // an aligned SGPR pair, broadcast to both halves by op_sel -- written as asm because the compiler otherwise
 // materialises every (c, c) splat as its own SGPR pair (98 SGPRs for fs = 7 -> spills).  Register-only VALU.
@@ -287,6 +302,210 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
                 }
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, quad form: 2x up-scales whose two phases per axis share their window origin
+// ------------------------------------------------------------------------------------------------
+// For a 2x up-scale the output pixels (2i, 2i+1) x (2j, 2j+1) of a period read the SAME fs x fs source window (plan:
+// start_x[0] == start_x[1], start_y[0] == start_y[1]) with four different coefficient sets.  A lane owns one period
+// column and keeps ONE register window for all four chains; the chains of the two horizontally adjacent pixels travel
+// as the two halves of a register pair, so every tap of both is one v_pk_mul_f32 (sample broadcast to both halves by
+// op_sel, coefficient pair = (phase 0, phase 1) from an aligned SGPR pair) and one v_pk_add_f32 -- two exact IEEE
+// products / sums per instruction, each half the reference's sequential chain bit for bit, nothing fused or reassociated.
+// Against ewa_periodic_kernel: half the VALU instructions per output sample on the faster packed pair (70 against 58
+// Tops/s in the probe), a quarter of the LDS reads and stores, the same 8 waves per SIMD (one window per lane) -- but the
+// 4 x fs x fs coefficients no longer fit the SGPR file: the pairs of one kernel row (2 x 16 dwords) are re-read from the
+// scalar cache per kernel row and output row pair (always hits: 4 sets).
+// Coefficient layout (host: attach_quad): quad[ly][q][8 pairs][p], the pair lx = (set(p=0,q), set(p=1,q))[ly][lx].
+template <int FS>
+struct QuadTaps;  // packed taps of one kernel row, window row held as pairs of a flat register array
+
+// 7 taps starting at an EVEN flat index: pairs w0..w3 hold taps (0,1) (2,3) (4,5) (6,-)
+__device__ __forceinline__ void quad_row7_even(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c0, f32x2 c1, f32x2 c2, f32x2 c3,
+                                               f32x2 c4, f32x2 c5, f32x2 c6) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %6 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %2, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+}
+// 7 taps starting at an ODD flat index: pairs w0..w3 hold taps (-,0) (1,2) (3,4) (5,6)
+__device__ __forceinline__ void quad_row7_odd(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c0, f32x2 c1, f32x2 c2, f32x2 c3,
+                                              f32x2 c4, f32x2 c5, f32x2 c6) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %6 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %8 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %11 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %12 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+}
+
+// Window slot `slot` (7 samples at flat indices 7 * slot ..) times the seven coefficient pairs c[0..6] onto acc.
+template <int SLOT>
+__device__ __forceinline__ void quad_row7(f32x2& acc, const f32x2 (&w)[25], const f32x2 (&c)[8]) {
+    constexpr int K0 = 7 * SLOT, P = K0 / 2;
+    if constexpr (K0 % 2 == 0)
+        quad_row7_even(acc, w[P], w[P + 1], w[P + 2], w[P + 3], c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+    else
+        quad_row7_odd(acc, w[P], w[P + 1], w[P + 2], w[P + 3], c[0], c[1], c[2], c[3], c[4], c[5], c[6]);
+}
+
+template <int SLOT>
+__device__ __forceinline__ void quad_load_row7(f32x2 (&w)[25], const float* p) {
+#pragma unroll
+    for (int lx = 0; lx < 7; ++lx) {
+        constexpr int K0 = 7 * SLOT;
+        const float v = p[lx];
+        if ((K0 + lx) % 2 == 0) w[(K0 + lx) / 2].x = v;
+        else w[(K0 + lx) / 2].y = v;
+    }
+}
+
+// The 16 coefficient pairs of kernel row LY (q = 0: pairs 0..7, q = 1: pairs 8..15): two s_load_dwordx16.
+__device__ __forceinline__ void quad_fetch(f32x2 (&c)[16], const JINC_CONSTANT f32x2* quad, int ly) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) c[k] = quad[ly * 16 + k];
+}
+__device__ __forceinline__ void quad_arrived(f32x2 (&c)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+s"(c[k]));
+}
+
+// One output row pair: window slots (U + ly) % 7 hold kernel rows ly = 0..6; acc0 = (q = 0: phases p = 0, 1), acc1 = (q = 1).
+// The coefficient pairs of kernel row ly + 1 are requested before the taps of row ly are issued (two sets of 32 SGPRs
+// taken alternately); `quad` must not be loop-invariant in the caller, or the compiler hoists all 224 loads out of the row
+// loop and spills them (measured: 264 spilled SGPRs).
+template <int U>
+__device__ __forceinline__ void quad_pixel7(f32x2& acc0, f32x2& acc1, const f32x2 (&w)[25], const JINC_CONSTANT f32x2* quad) {
+    f32x2 ca[16], cb[16];
+    quad_fetch(ca, quad, 0);
+#define JINC_QUAD_STEP(LY, CUR, NEXT)                                         \
+    if constexpr (LY < 6) quad_fetch(NEXT, quad, LY + 1);                      \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    quad_arrived(CUR);                                                         \
+    quad_row7<(U + LY) % 7>(acc0, w, reinterpret_cast<const f32x2(&)[8]>(CUR[0])); \
+    quad_row7<(U + LY) % 7>(acc1, w, reinterpret_cast<const f32x2(&)[8]>(CUR[8])); \
+    __builtin_amdgcn_sched_barrier(0);
+    JINC_QUAD_STEP(0, ca, cb)
+    JINC_QUAD_STEP(1, cb, ca)
+    JINC_QUAD_STEP(2, ca, cb)
+    JINC_QUAD_STEP(3, cb, ca)
+    JINC_QUAD_STEP(4, ca, cb)
+    JINC_QUAD_STEP(5, cb, ca)
+    JINC_QUAD_STEP(6, ca, cb)
+#undef JINC_QUAD_STEP
+}
+
+template <typename T, int RG>
+__global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const PeriodicArgs a, const PlaneIO io) {
+    constexpr int FS = 7;
+    using Cfg = PeriodicCfg<FS, RG>;
+    static_assert(RG % 4 == 0, "the four waves of a workgroup take RG / 4 row groups each");
+    __shared__ float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + 4 * i;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+            }
+        }
+    }
+    __syncthreads();
+    if ((i0 + lane) >= a.ni) return;  // no barrier below
+
+    const JINC_CONSTANT f32x2* quad = (const JINC_CONSTANT f32x2*)(a.quad);
+    // both phases of an axis share the window origin (host: quad != nullptr only then)
+    const float* base = tile + (a.start_y[0] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[0] - a.min_sx) + lane;
+    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+    const uint32_t xoff = static_cast<uint32_t>(a.ix0 + 2 * (i0 + lane)) * static_cast<uint32_t>(sizeof(T));
+
+    constexpr int kGroupsPerWave = RG / 4;
+    const int g_first = wave * kGroupsPerWave;
+    if (j0 + g_first * FS >= a.nj) return;  // wave-uniform: bottom tiles
+    f32x2 win[25];
+    {
+        const float* wb = base + (g_first * FS) * Cfg::kLdsPitch;
+        quad_load_row7<0>(win, wb + 0 * Cfg::kLdsPitch);
+        quad_load_row7<1>(win, wb + 1 * Cfg::kLdsPitch);
+        quad_load_row7<2>(win, wb + 2 * Cfg::kLdsPitch);
+        quad_load_row7<3>(win, wb + 3 * Cfg::kLdsPitch);
+        quad_load_row7<4>(win, wb + 4 * Cfg::kLdsPitch);
+        quad_load_row7<5>(win, wb + 5 * Cfg::kLdsPitch);
+    }
+    for (int g = g_first; g < g_first + kGroupsPerWave; ++g) {
+        if (j0 + g * FS >= a.nj) break;  // wave-uniform
+        const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#define JINC_QUAD_ROW(U)                                                                                          \
+    {                                                                                                             \
+        quad_load_row7<(U + FS - 1) % FS>(win, gbase + (U + FS - 1) * Cfg::kLdsPitch);                             \
+        f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};                                                                \
+        uint32_t zero;                                                                                             \
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
+        quad_pixel7<U>(acc0, acc1, win, quad + zero);                                                              \
+        const int j = j0 + g * FS + U;                                                                             \
+        if (j < a.nj) {                                                                                            \
+            const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                               \
+            store_pair_buf<T>(drsrc, xoff, so, acc0, io.peak);                                                     \
+            store_pair_buf<T>(drsrc, xoff, so + static_cast<uint32_t>(io.dst_pitch), acc1, io.peak);               \
+        }                                                                                                          \
+    }
+        JINC_QUAD_ROW(0) JINC_QUAD_ROW(1) JINC_QUAD_ROW(2) JINC_QUAD_ROW(3) JINC_QUAD_ROW(4) JINC_QUAD_ROW(5) JINC_QUAD_ROW(6)
+#undef JINC_QUAD_ROW
     }
 }
 
@@ -460,6 +679,14 @@ int launch_periodic_pk_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t 
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int RG>
+int launch_periodic_quad_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicCfg<7, RG>;
+    dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_quad_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T, int FS, int KC>
 int launch_rows_k(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = RowsCfg<FS, KC>;
@@ -479,6 +706,8 @@ int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream)
 
 template <typename T>
 int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
+    if ((variant == 5 || variant == 6) && fs == 7 && pa.quad)  // quad form: 5 = tiles of 8 row groups, 6 = of 4 (small calls)
+        return variant == 5 ? launch_periodic_quad_t<T, 8>(pa, io, stream) : launch_periodic_quad_t<T, 4>(pa, io, stream);
     if (variant == 3 && fs == 7) return launch_periodic_pk_t<T, 7, 4>(pa, io, stream);
     if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
     if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);

@@ -82,6 +82,9 @@ struct PeriodicArgs {
     int set[64] = {0};
     int src_w = 0, src_h = 0;
     int dst_h = 0;  // rows of the destination plane (bounds of the store descriptor)
+    // 2x up-scales whose phases share their window origin (ewa_periodic_quad_kernel): coefficient pairs
+    // quad[ly][q][8 pairs][p] = (set(p=0,q), set(p=1,q))[ly][lx], or nullptr when the plan has no such form
+    const float* quad = nullptr;
 };
 
 // Quasi-periodic interior: the window origins are affine per residue (output pixel (ix0 + px*i + p,

@@ -64,6 +64,8 @@ CONFIGS = {
     "D12T8": ("Y8", 3840, 2160, 1920, 1080, dict(tap=8), 32),    # Jinc256 at 1/2: fs = 33 (3 x 11)
     "T6": ("Y8", 1920, 1080, 3840, 2160, dict(tap=6), 64),    # Jinc144: fs = 13
     "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 16),  # tap 16: fs = 33 (1089 taps)
+    "C2H": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=3), 128),  # C2's geometry on 16-bit 4:2:0 (luma and chroma both 2x, fs 7)
+    "C2F": ("RGBPS", 1920, 1080, 3840, 2160, dict(tap=3), 64),       # ... and on float RGB
 }
 
 

@@ -734,9 +734,9 @@ def test_device_entry_rejects_bad_layouts(gpu_pkg):
     f.close()
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4, 5, 6, 7, 8, 9, 10],
-                         ids=["gather", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_waterfall", "direct",
-                              "quasi_lane_coefficients"])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13],
+                         ids=["gather", "window", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_waterfall", "direct",
+                              "quasi_lane_coefficients", "quad"])
 def test_every_kernel_reproduces_the_reference_crc_at_full_size(gpu_pkg, O, mode):
     """C2 at full size through every kernel family: the crc32 of the reference's own opt=0 output."""
     k = next(x for x in KAT["outputs"] if x["name"] == "C2")
@@ -773,3 +773,39 @@ def test_create_free_cycles_do_not_leak_device_memory(gpu_pkg, O):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 60 cycles"
+
+
+QUAD_CASES = [
+    ("Y8", 192, 108, 384, 216, dict(tap=3)),
+    ("Y8", 1000, 300, 2000, 600, dict(tap=3)),          # several tiles in x, partial last tile
+    ("Y16", 320, 180, 640, 360, dict(tap=3)),
+    ("Y10", 320, 180, 640, 360, dict(tap=3)),
+    ("Y32", 320, 180, 640, 360, dict(tap=3)),
+    ("YUV420P8", 256, 144, 512, 288, dict(tap=3, cplace="mpeg1")),   # luma and chroma tables both 2x
+    ("RGBPS", 160, 100, 320, 200, dict(tap=3, blur=0.95)),
+]
+
+
+@pytest.mark.parametrize("case", QUAD_CASES, ids=_id)
+@pytest.mark.parametrize("frames", [1, 5])
+def test_quad_form_of_the_periodic_kernel(gpu_pkg, O, case, frames):
+    """ewa_periodic_quad_kernel (kernel mode 13): 2x up-scales, a lane computes the 2 x 2 pixels of a period from one window
+    with packed multiplies / adds; bit-exact against the oracle, single frames (half-height tiles) and batches."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th, kw = case
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    of = O.OracleFilter(ofmt, sw, sh, tw, th, **oracle_kwargs(kw))
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, **kw)
+    f.set_kernel_mode(13)
+    srcs = [O.lcg_frame(ofmt, sw, sh, seed=6100 + k) for k in range(frames)]
+    if frames == 1:
+        got = f.get_frame(srcs[0])
+        assert f.last_kernel(0) == "ewa_periodic_quad_kernel", f.last_kernel(0)
+        assert_planes_equal(got, of.get_frame(srcs[0], threads=4), f.out_dims(), what=_id(case))
+    else:
+        from test_framelane_pair import _run_batch
+        got = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 13)
+        assert f.last_kernel(0) == "ewa_periodic_quad_kernel", f.last_kernel(0)
+        for k in range(frames):
+            assert_planes_equal(got[k], of.get_frame(srcs[k], threads=4), f.out_dims(), what=_id(case) + f" frame {k}")
+    f.close()
