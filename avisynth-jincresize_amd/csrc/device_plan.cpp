@@ -87,18 +87,20 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
 jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end);
 
 // ewa_periodic_quad_kernel's coefficient pairs for 2x up-scales whose two phases per axis share their window origin
-// (filter size 7): quad[ly][q][8 pairs][p] = (set(p = 0, q), set(p = 1, q))[ly][lx]; a kernel row of one q is 16 dwords =
-// one s_load_dwordx16 (the eighth pair is padding), the two q of a kernel row are adjacent.
+// (filter sizes 7 and 9): quad[ly][q][8 or 10 pairs][p] = (set(p = 0, q), set(p = 1, q))[ly][lx]; a kernel row of one q is 16
+// dwords (fs 7: one s_load_dwordx16, the eighth pair is padding) or 20 (fs 9), the two q of a kernel row are adjacent.
 void attach_quad(const jinc::PlanePlan& p, DeviceTable& t) {
     jinc::PeriodicArgs& pa = t.periodic;
-    if (!t.use_periodic || p.fs != 7 || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] || pa.start_y[0] != pa.start_y[1]) return;
-    constexpr int FS = 7;
-    std::vector<float> q(2 * FS * 8 * 2, 0.f);
+    if (!t.use_periodic || (p.fs != 7 && p.fs != 9) || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] ||
+        pa.start_y[0] != pa.start_y[1])
+        return;
+    const int FS = p.fs, PR = FS == 7 ? 8 : 10;  // pairs per (kernel row, q), padded: 16 / 20 dwords
+    std::vector<float> q(static_cast<size_t>(2) * FS * PR * 2, 0.f);
     for (int qy = 0; qy < 2; ++qy)
         for (int ly = 0; ly < FS; ++ly)
             for (int lx = 0; lx < FS; ++lx)
                 for (int px = 0; px < 2; ++px)
-                    q[((static_cast<size_t>(ly) * 2 + qy) * 8 + lx) * 2 + px] = p.set_ptr(pa.set[qy * 2 + px])[ly * FS + lx];
+                    q[((static_cast<size_t>(ly) * 2 + qy) * PR + lx) * 2 + px] = p.set_ptr(pa.set[qy * 2 + px])[ly * FS + lx];
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, q.size() * sizeof(float)), "hipMalloc(quad coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table

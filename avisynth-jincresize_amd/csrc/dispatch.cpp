@@ -25,6 +25,8 @@ struct Rules {
     static constexpr int kFrameLaneMinFramesStep2Fs7 = 64;
     // window kernels take half-height tiles below this many workgroups per launch (round2 small-call rules)
     static constexpr long long kHalfTileMaxWorkgroups = 6144;
+    // fs-9 quad form (ewa_periodic_quad9_kernel) below this many full-tile workgroups per launch (C4: one frame per call)
+    static constexpr long long kQuad9MaxWorkgroups = 4096;
     // workgroups a quasi-periodic launch aims for when it splits a tile's phases (fs 9 tiles cost more to stage)
     static constexpr long long kQuasiSplitTarget = 1024, kQuasiSplitTargetFs9 = 400;
 };
@@ -164,10 +166,12 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
             return;
         }
     }
-    auto quad_chosen = [&](const DeviceTable& t) {   // (the same rule as at the launch below)
+    auto quad_chosen = [&](const DeviceTable& t) {
         if (!t.periodic.quad) return false;
-        const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 55) / 56) * nframes;
-        return f.kernel_mode == 13 || (f.kernel_mode == 0 && wgs >= Rules::kHalfTileMaxWorkgroups);
+        if (f.kernel_mode == 13) return true;
+        if (f.kernel_mode != 0) return false;
+        const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
+        return t.plan.fs == 7 ? wgs >= Rules::kHalfTileMaxWorkgroups : wgs < Rules::kQuad9MaxWorkgroups;
     };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
@@ -332,12 +336,11 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                 timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
                     int variant = (f.kernel_mode >= 3 && f.kernel_mode <= 6) ? f.kernel_mode - 2 : 0;
                     // quad form (2x up-scales whose phases share their window origin: a lane computes a period's 2 x 2 pixels from
-                    // one window on packed multiplies / adds): +2.5 .. 6 % on calls that fill the chip (C2 at 16 / 1024 frames
-                    // 544 -> 560 / 591 -> 606 Gpix/s, 16-bit 4:2:0 356 -> 365, float RGB 165 -> 175), -5 % on a 4-frame call
-                    // (profiles/round3/quad_ab.log): automatic for full-tile launches, kernel mode 13 forces it, 2 excludes it
-                    const long long quad_wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 55) / 56) * nframes;
-                    const bool quad = t.periodic.quad != nullptr &&
-                                      (f.kernel_mode == 13 || (f.kernel_mode == 0 && quad_wgs >= Rules::kHalfTileMaxWorkgroups));
+                    // one window on packed multiplies / adds), chosen where it measured ahead (profiles/round3/quad_ab.log):
+                    // fs 7 on calls that fill the chip (C2 at 16 / 1024 frames 544 -> 560 / 591 -> 606 Gpix/s, 16-bit 4:2:0 356 ->
+                    // 365, float RGB 165 -> 175; a 4-frame call loses 5 %), fs 9 on calls that do not (C4, one frame per call: 80
+                    // -> 94 Gpix/s; 4 / 16 frames: equal).  Kernel mode 13 forces it, 2 excludes it.
+                    const bool quad = quad_chosen(t);
                     if (quad) variant = 5;
                     // Small calls (single frames, short batches) take the window kernels' half-height tiles: twice the
                     // workgroups for a launch that does not fill the chip (C2, one frame: 600 workgroups on 1536 slots,
@@ -348,6 +351,8 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                         if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
                     }
                     if (quad) {
+                        const long long quad_wgs = static_cast<long long>((t.periodic.ni + 63) / 64) *
+                                                   ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
                         if (quad_wgs < Rules::kHalfTileMaxWorkgroups) variant = 6;
                     }
                     return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);

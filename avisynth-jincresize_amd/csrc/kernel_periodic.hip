@@ -365,6 +365,105 @@ __device__ __forceinline__ void quad_row7_odd(f32x2& acc, f32x2 w0, f32x2 w1, f3
         : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
 }
 
+// fs 9: nine taps starting at an EVEN flat index: pairs w0..w4 hold taps (0,1) (2,3) (4,5) (6,7) (8,-)
+__device__ __forceinline__ void quad_row9_even(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 w4, f32x2 c0, f32x2 c1, f32x2 c2,
+                                               f32x2 c3, f32x2 c4, f32x2 c5, f32x2 c6, f32x2 c7, f32x2 c8) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %2, %8 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %11 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %12 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %13 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %14 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %6, %15 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8));
+}
+// ... at an ODD flat index: pairs w0..w4 hold taps (-,0) (1,2) (3,4) (5,6) (7,8)
+__device__ __forceinline__ void quad_row9_odd(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 w4, f32x2 c0, f32x2 c1, f32x2 c2,
+                                              f32x2 c3, f32x2 c4, f32x2 c5, f32x2 c6, f32x2 c7, f32x2 c8) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %13 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %6, %14 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %6, %15 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7), "s"(c8));
+}
+template <int SLOT>
+__device__ __forceinline__ void quad_row9(f32x2& acc, const f32x2 (&w)[41], const f32x2 (&c)[10]) {
+    constexpr int K0 = 9 * SLOT, P = K0 / 2;
+    if constexpr (K0 % 2 == 0)
+        quad_row9_even(acc, w[P], w[P + 1], w[P + 2], w[P + 3], w[P + 4], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
+    else
+        quad_row9_odd(acc, w[P], w[P + 1], w[P + 2], w[P + 3], w[P + 4], c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]);
+}
+template <int SLOT>
+__device__ __forceinline__ void quad_load_row9(f32x2 (&w)[41], const float* p) {
+#pragma unroll
+    for (int lx = 0; lx < 9; ++lx) {
+        constexpr int K0 = 9 * SLOT;
+        const float v = p[lx];
+        if ((K0 + lx) % 2 == 0) w[(K0 + lx) / 2].x = v;
+        else w[(K0 + lx) / 2].y = v;
+    }
+}
+// fs 9: the 2 x 10 coefficient pairs of a kernel row do not fit twice next to everything else (2 x 40 SGPRs), so the two
+// phase rows q alternate through two sets of 20 SGPRs: the pairs of (ly, q = 1) are requested before the taps of (ly, q = 0)
+// are issued, those of (ly + 1, q = 0) before the taps of (ly, q = 1).  Layout: quad[ly][q][10 pairs][p].
+__device__ __forceinline__ void quad_fetch10(f32x2 (&c)[10], const JINC_CONSTANT f32x2* quad, int row) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) c[k] = quad[row * 10 + k];
+}
+__device__ __forceinline__ void quad_arrived10(f32x2 (&c)[10]) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) asm volatile("" : "+s"(c[k]));
+}
+template <int U>
+__device__ __forceinline__ void quad_pixel9(f32x2& acc0, f32x2& acc1, const f32x2 (&w)[41], const JINC_CONSTANT f32x2* quad) {
+    f32x2 ca[10], cb[10];
+    quad_fetch10(ca, quad, 0);
+#define JINC_QUAD9_STEP(LY)                                                   \
+    quad_fetch10(cb, quad, 2 * LY + 1);                                        \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    quad_arrived10(ca);                                                        \
+    quad_row9<(U + LY) % 9>(acc0, w, ca);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    if constexpr (LY < 8) quad_fetch10(ca, quad, 2 * LY + 2);                  \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    quad_arrived10(cb);                                                        \
+    quad_row9<(U + LY) % 9>(acc1, w, cb);                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    JINC_QUAD9_STEP(0) JINC_QUAD9_STEP(1) JINC_QUAD9_STEP(2) JINC_QUAD9_STEP(3) JINC_QUAD9_STEP(4) JINC_QUAD9_STEP(5)
+    JINC_QUAD9_STEP(6) JINC_QUAD9_STEP(7) JINC_QUAD9_STEP(8)
+#undef JINC_QUAD9_STEP
+}
+
 // Window slot `slot` (7 samples at flat indices 7 * slot ..) times the seven coefficient pairs c[0..6] onto acc.
 template <int SLOT>
 __device__ __forceinline__ void quad_row7(f32x2& acc, const f32x2 (&w)[25], const f32x2 (&c)[8]) {
@@ -505,6 +604,98 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const Periodi
         }                                                                                                          \
     }
         JINC_QUAD_ROW(0) JINC_QUAD_ROW(1) JINC_QUAD_ROW(2) JINC_QUAD_ROW(3) JINC_QUAD_ROW(4) JINC_QUAD_ROW(5) JINC_QUAD_ROW(6)
+#undef JINC_QUAD_ROW
+    }
+}
+
+// fs 9 (tap 4 at 2x: C4): the same kernel with a 9 x 9 window (41 register pairs: 5 waves per SIMD, as the window kernel of
+// fs 9) and the coefficient pairs of the two phase rows taken alternately (quad_pixel9).
+template <typename T, int RG>
+__global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const PeriodicArgs a, const PlaneIO io) {
+    constexpr int FS = 9;
+    using Cfg = PeriodicCfg<FS, RG>;
+    static_assert(RG % 4 == 0, "the four waves of a workgroup take RG / 4 row groups each");
+    __shared__ float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + 4 * i;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+            }
+        }
+    }
+    __syncthreads();
+    if ((i0 + lane) >= a.ni) return;  // no barrier below
+
+    const JINC_CONSTANT f32x2* quad = (const JINC_CONSTANT f32x2*)(a.quad);
+    // both phases of an axis share the window origin (host: quad != nullptr only then)
+    const float* base = tile + (a.start_y[0] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[0] - a.min_sx) + lane;
+    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+    const uint32_t xoff = static_cast<uint32_t>(a.ix0 + 2 * (i0 + lane)) * static_cast<uint32_t>(sizeof(T));
+
+    constexpr int kGroupsPerWave = RG / 4;
+    const int g_first = wave * kGroupsPerWave;
+    if (j0 + g_first * FS >= a.nj) return;  // wave-uniform: bottom tiles
+    f32x2 win[41];
+    {
+        const float* wb = base + (g_first * FS) * Cfg::kLdsPitch;
+        quad_load_row9<0>(win, wb + 0 * Cfg::kLdsPitch);
+        quad_load_row9<1>(win, wb + 1 * Cfg::kLdsPitch);
+        quad_load_row9<2>(win, wb + 2 * Cfg::kLdsPitch);
+        quad_load_row9<3>(win, wb + 3 * Cfg::kLdsPitch);
+        quad_load_row9<4>(win, wb + 4 * Cfg::kLdsPitch);
+        quad_load_row9<5>(win, wb + 5 * Cfg::kLdsPitch);
+        quad_load_row9<6>(win, wb + 6 * Cfg::kLdsPitch);
+        quad_load_row9<7>(win, wb + 7 * Cfg::kLdsPitch);
+    }
+    for (int g = g_first; g < g_first + kGroupsPerWave; ++g) {
+        if (j0 + g * FS >= a.nj) break;  // wave-uniform
+        const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#define JINC_QUAD_ROW(U)                                                                                          \
+    {                                                                                                             \
+        quad_load_row9<(U + FS - 1) % FS>(win, gbase + (U + FS - 1) * Cfg::kLdsPitch);                             \
+        f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};                                                                \
+        uint32_t zero;                                                                                             \
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
+        quad_pixel9<U>(acc0, acc1, win, quad + zero);                                                              \
+        const int j = j0 + g * FS + U;                                                                             \
+        if (j < a.nj) {                                                                                            \
+            const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                               \
+            store_pair_buf<T>(drsrc, xoff, so, acc0, io.peak);                                                     \
+            store_pair_buf<T>(drsrc, xoff, so + static_cast<uint32_t>(io.dst_pitch), acc1, io.peak);               \
+        }                                                                                                          \
+    }
+        JINC_QUAD_ROW(0) JINC_QUAD_ROW(1) JINC_QUAD_ROW(2) JINC_QUAD_ROW(3) JINC_QUAD_ROW(4) JINC_QUAD_ROW(5) JINC_QUAD_ROW(6) JINC_QUAD_ROW(7) JINC_QUAD_ROW(8)
 #undef JINC_QUAD_ROW
     }
 }
@@ -687,6 +878,14 @@ int launch_periodic_quad_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int RG>
+int launch_periodic_quad9_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicCfg<9, RG>;
+    dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_quad9_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T, int FS, int KC>
 int launch_rows_k(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = RowsCfg<FS, KC>;
@@ -708,6 +907,8 @@ template <typename T>
 int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
     if ((variant == 5 || variant == 6) && fs == 7 && pa.quad)  // quad form: 5 = tiles of 8 row groups, 6 = of 4 (small calls)
         return variant == 5 ? launch_periodic_quad_t<T, 8>(pa, io, stream) : launch_periodic_quad_t<T, 4>(pa, io, stream);
+    if ((variant == 5 || variant == 6) && fs == 9 && pa.quad)
+        return launch_periodic_quad9_t<T, 4>(pa, io, stream);  // (8 row groups per tile: the staging's registers spill, no gain over the window kernel)
     if (variant == 3 && fs == 7) return launch_periodic_pk_t<T, 7, 4>(pa, io, stream);
     if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
     if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);

@@ -783,6 +783,11 @@ QUAD_CASES = [
     ("Y32", 320, 180, 640, 360, dict(tap=3)),
     ("YUV420P8", 256, 144, 512, 288, dict(tap=3, cplace="mpeg1")),   # luma and chroma tables both 2x
     ("RGBPS", 160, 100, 320, 200, dict(tap=3, blur=0.95)),
+    # fs 9 (tap 4): ewa_periodic_quad9_kernel
+    ("Y8", 192, 108, 384, 216, dict(tap=4)),
+    ("Y16", 700, 200, 1400, 400, dict(tap=4)),
+    ("RGBPS", 320, 180, 640, 360, dict(tap=4, blur=0.98)),       # C4's arguments
+    ("YUV420P10", 256, 144, 512, 288, dict(tap=4, cplace="topleft")),
 ]
 
 
