@@ -377,8 +377,9 @@ const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {
 // Shader-clock sampler beside the kernels being timed (kernel_probe.hip).
 struct jinc_clock_sampler {
     int device = 0;
-    hipStream_t stream = nullptr;
-    int* stop = nullptr;                 // pinned host memory
+    hipStream_t stream = nullptr, control = nullptr;
+    int* stop = nullptr;                 // DEVICE memory, raised by a memset on the control stream (a flag in pinned host
+                                         // memory is not seen by a running kernel here: the samplers ran to their time limit)
     unsigned long long* out = nullptr;   // pinned host memory, 2 x kSamplers
     static constexpr int kSamplers = 8;
 };
@@ -394,18 +395,22 @@ int jinc_debug_clock_sampler_start(int device, double max_seconds, jinc_clock_sa
         // queue for as long as it lives (measured: eight sleeping sampler waves at the highest priority cost the direct
         // kernels 10-15 %: 1080p -> 720p 256 -> 223 Gpix/s; profiles/round3/clock_sampler_priority.log)
         hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
-        hip_check(hipHostMalloc(reinterpret_cast<void**>(&s->stop), sizeof(int), hipHostMallocDefault), "hipHostMalloc");
+        hip_check(hipStreamCreateWithFlags(&s->control, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipMalloc(reinterpret_cast<void**>(&s->stop), 256), "hipMalloc");
+        hip_check(hipMemsetAsync(s->stop, 0, 256, s->control), "hipMemsetAsync");
+        hip_check(hipStreamSynchronize(s->control), "stream sync");
         hip_check(hipHostMalloc(reinterpret_cast<void**>(&s->out), sizeof(unsigned long long) * 2 * jinc_clock_sampler::kSamplers, hipHostMallocDefault),
                   "hipHostMalloc");
-        *s->stop = 0;
         std::memset(s->out, 0, sizeof(unsigned long long) * 2 * jinc_clock_sampler::kSamplers);
         hip_check(static_cast<hipError_t>(jinc::launch_clock_sampler(s->stop, s->out, jinc_clock_sampler::kSamplers, max_seconds, s->stream)),
                   "clock sampler launch");
     });
     if (rc != JINC_OK) {
-        if (s->stop) (void)hipHostFree(s->stop);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        if (s->stop) (void)hipFree(s->stop);
         if (s->out) (void)hipHostFree(s->out);
         if (s->stream) (void)hipStreamDestroy(s->stream);
+        if (s->control) (void)hipStreamDestroy(s->control);
         return rc;
     }
     *out = s.release();
@@ -416,7 +421,8 @@ int jinc_debug_clock_sampler_stop(jinc_clock_sampler* s, double* ghz_min, double
     if (!s) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
     const int rc = guarded([&] {
         hip_check(hipSetDevice(s->device), "hipSetDevice");
-        __atomic_store_n(s->stop, 1, __ATOMIC_SEQ_CST);
+        hip_check(hipMemsetAsync(s->stop, 1, 4, s->control), "hipMemsetAsync(stop flag)");  // any non-zero value stops the samplers
+        hip_check(hipStreamSynchronize(s->control), "stream sync");
         hip_check(hipStreamSynchronize(s->stream), "stream sync");
         std::vector<double> ghz;
         for (int k = 0; k < jinc_clock_sampler::kSamplers; ++k)
@@ -427,9 +433,10 @@ int jinc_debug_clock_sampler_stop(jinc_clock_sampler* s, double* ghz_min, double
         if (ghz_max) *ghz_max = ghz.back();
         if (ghz_median) *ghz_median = 0.5 * (ghz[(ghz.size() - 1) / 2] + ghz[ghz.size() / 2]);
     });
-    (void)hipHostFree(s->stop);
+    (void)hipFree(s->stop);
     (void)hipHostFree(s->out);
     (void)hipStreamDestroy(s->stream);
+    (void)hipStreamDestroy(s->control);
     delete s;
     return rc;
 }

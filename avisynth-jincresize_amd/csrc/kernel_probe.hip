@@ -1,7 +1,7 @@
 // kernel_probe.hip -- measurement hooks, not part of the hot path: a shader-clock sampler that runs BESIDE the kernels
 // being timed (bench.py: roofline.shader_clock_ghz).  One lane per workgroup, eight workgroups (consecutive workgroups go to
 // consecutive XCDs), each stamps s_memtime (shader clock ticks) and s_memrealtime (constant 100 MHz) when it starts and
-// when the host raises the stop flag; clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
+// when the host raises the stop flag (device memory, set by a memset on another stream); clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
 // The samplers sleep between looks at the flag: a few dozen scalar instructions per microsecond on 8 of 1024 SIMDs.
 #include <hip/hip_runtime.h>
 
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(64) void clock_sampler_kernel(const volatile int* s
         __builtin_amdgcn_s_sleep(127);
         c1 = __builtin_amdgcn_s_memtime();
         r1 = __builtin_amdgcn_s_memrealtime();
-        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+        if (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // device memory, served by the L2
     }
     out[2 * blockIdx.x] = c1 - c0;
     out[2 * blockIdx.x + 1] = r1 - r0;

@@ -246,7 +246,7 @@ int launch_blit_rows(const BlitEntry* table_device, int first, int count, uint32
                      void* stream);
 
 // Measurement hook (kernel_probe.hip): `samplers` single-lane workgroups stamp the shader clock counter and the 100 MHz
-// real-time counter until *stop_flag (pinned host memory) becomes non-zero or max_seconds pass; out[2 k] = shader ticks,
+// real-time counter until *stop_flag (device memory) becomes non-zero or max_seconds pass; out[2 k] = shader ticks,
 // out[2 k + 1] = real-time ticks of sampler k.
 int launch_clock_sampler(const int* stop_flag, unsigned long long* out, int samplers, double max_seconds, void* stream);
 

@@ -250,14 +250,14 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
     return out
 
 
-def e2e_record(pkg, config, depth=64, seconds=1.5):
+def e2e_record(pkg, config, depth=128, seconds=1.5):
     """Host planes in, host planes out through the look-ahead pipeline (jinc_filter_submit / _wait, one host thread,
     caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it."""
     import numpy as np
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
     fmt = pkg.FORMATS[fmt_name]
     frame_bytes = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
-    depth = max(2, min(depth, int((2 << 30) // max(1, frame_bytes))))   # at most ~2 GiB of host frames
+    depth = max(2, min(depth, int((2 << 30) // max(1, frame_bytes))))   # at most ~2 GiB of host frames (C2: 128, C4: 4)
     f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
     f.set_pipeline(depth, True)
     rng = np.random.default_rng(3)
@@ -430,7 +430,7 @@ def main():
         sampler = pkg.ClockSampler(local_rank, 60.0)
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize()
+        stream.synchronize()   # the steps' stream only: a device-wide synchronize would wait for the samplers themselves
         clock_ghz = sampler.stop()
     # untimed, right after the timed region (clocks warm): what the kernels' instruction pair sustains on THIS part
     pair_probe = None
