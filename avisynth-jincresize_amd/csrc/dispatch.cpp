@@ -27,6 +27,8 @@ struct Rules {
     static constexpr long long kHalfTileMaxWorkgroups = 6144;
     // fs-9 quad form (ewa_periodic_quad9_kernel) below this many full-tile workgroups per launch (C4: one frame per call)
     static constexpr long long kQuad9MaxWorkgroups = 4096;
+    // fs-7 quad form from this many periods (2 x 2 pixels each) per plane on: 1080p -> 4K has 2.05 M, 360p -> 720p 0.22 M
+    static constexpr long long kQuadMinPeriods = 1000000;
     // workgroups a quasi-periodic launch aims for when it splits a tile's phases (fs 9 tiles cost more to stage)
     static constexpr long long kQuasiSplitTarget = 1024, kQuasiSplitTargetFs9 = 400;
 };
@@ -171,7 +173,10 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         if (f.kernel_mode == 13) return true;
         if (f.kernel_mode != 0) return false;
         const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
-        return t.plan.fs == 7 ? wgs >= Rules::kHalfTileMaxWorkgroups : wgs < Rules::kQuad9MaxWorkgroups;
+        // (fs 7: large planes only -- on 1280 x 720 the border kernels beside the denser interior become the step's tail:
+        // C1 at 256 frames 492 -> 465 Gpix/s)
+        const long long periods = static_cast<long long>(t.periodic.ni) * t.periodic.nj;
+        return t.plan.fs == 7 ? (wgs >= Rules::kHalfTileMaxWorkgroups && periods >= Rules::kQuadMinPeriods) : wgs < Rules::kQuad9MaxWorkgroups;
     };
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
