@@ -356,6 +356,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host record (untimed, after the timed region)")
     ap.add_argument("--no-clock-sampler", action="store_true")
     ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
+    ap.add_argument("--simd-order", type=int, default=0, help="1 / 2 / 3: the compatibility kernel in the reference's SSE4.1 / AVX2 / AVX-512 summation order")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
     args = ap.parse_args()
     if args.config not in CONFIGS:
@@ -391,6 +392,8 @@ def main():
             raise SystemExit("C5: more ranks than frames")
     flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, local_rank, 12345 + rank * B)
     flt.set_kernel_mode(args.kernel_mode)
+    if args.simd_order:
+        flt.set_simd_order(args.simd_order)
     if args.border_overlap >= 0:
         flt.set_border_overlap(bool(args.border_overlap))
     info = flt.plan_info(0)
@@ -452,8 +455,8 @@ def main():
         n_planes = fmt.planes
         if per_n > 0:
             dom_name, dom_ms, dom_n = flt.last_kernel(0), per_ms, per_n
-        else:
-            dom_name, dom_ms, dom_n = "ewa_gather_kernel", gat_ms, gat_n
+        else:   # whole planes on the gather kernel (or, with --simd-order, on the compatibility kernel)
+            dom_name, dom_ms, dom_n = (flt.last_kernel(0) or "ewa_gather_kernel"), gat_ms, gat_n
         # one launch per plane per step; algorithmic bytes of a launch = the batch's bytes for that plane,
         # so summed over the planes of a step it is bytes_frame * B
         launches_per_step = max(1, dom_n // max(1, args.steps))
