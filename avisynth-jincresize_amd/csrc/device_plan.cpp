@@ -234,6 +234,89 @@ void plan_quasi(const jinc::PlanePlan& p, DeviceTable& t) {
     }
 }
 
+// Drifting plans (window origins affine per residue, phase classes changing now and then along an axis: 1.5x, 3x, 8/3 x 9/4 ...)
+// with filter sizes the direct kernel's row walk covers: along each axis the periods of a phase fall into a few runs of constant
+// class (1280 x 720 -> 1920 x 1080: 9..14 runs per column phase, 4..7 per row phase; 120 distinct interior sets), and a
+// (column run) x (row run) rectangle of one phase pair has ONE coefficient set and exactly periodic windows -- the direct
+// kernel's premise, per rectangle.  kernels.h DirectRun; the rectangles of a plane are one launch.
+void plan_runs(const jinc::PlanePlan& p, DeviceTable& t) {
+    t.use_runs = false;
+    if (p.periodic || !p.quasi) return;
+    const int px = p.qpx, py = p.qpy, sx = p.qsx, sy = p.qsy;
+    if (!jinc::direct_runs_supported(p.fs, px, py, sx, sy)) return;
+    const int ni = (p.ix1 - p.ix0) / px, nj = (p.iy1 - p.iy0) / py;
+    if (ni < 1 || nj < 1) return;
+    struct AxisRun {
+        int first, count, cls;
+    };
+    bool ok = true;
+    auto axis_runs = [&](const std::vector<int32_t>& cls, const std::vector<int32_t>& start, int o0, int period, int step, int n, int phase) {
+        std::vector<AxisRun> r;
+        for (int i = 0; i < n; ++i) {
+            const int x = o0 + period * i + phase;
+            if (cls[x] < 0 || start[x] != start[o0 + phase] + step * i) ok = false;  // not what PlanePlan::quasi promises
+            if (r.empty() || r.back().cls != cls[x])
+                r.push_back({i, 1, cls[x]});
+            else
+                ++r.back().count;
+        }
+        return r;
+    };
+    std::vector<jinc::DirectRun> runs;
+    for (int q = 0; q < py; ++q) {
+        const std::vector<AxisRun> ry = axis_runs(p.row_class, p.row_start, p.iy0, py, sy, nj, q);
+        for (int r = 0; r < px; ++r) {
+            const std::vector<AxisRun> rx = axis_runs(p.col_class, p.col_start, p.ix0, px, sx, ni, r);
+            if (!ok) return;
+            for (const AxisRun& b : ry)
+                for (const AxisRun& a : rx) {
+                    jinc::DirectRun d;
+                    d.set = p.interior_set[static_cast<size_t>(b.cls) * p.n_col_classes + a.cls];
+                    d.x0 = p.ix0 + px * a.first + r;
+                    d.y0 = p.iy0 + py * b.first + q;
+                    d.sx0 = p.col_start[d.x0];
+                    d.sy0 = p.row_start[d.y0];
+                    d.ni = a.count;
+                    d.nj = b.count;
+                    runs.push_back(d);
+                }
+        }
+    }
+    // rectangles of the same neighbourhood next to each other: consecutive items then read the same source rows
+    std::sort(runs.begin(), runs.end(), [](const jinc::DirectRun& a, const jinc::DirectRun& b) { return a.y0 != b.y0 ? a.y0 < b.y0 : a.x0 < b.x0; });
+    std::vector<int32_t> item_run;
+    for (size_t k = 0; k < runs.size(); ++k) {
+        const long long lanes = static_cast<long long>((runs[k].ni + 3) / 4) * ((runs[k].nj + 3) / 4);  // 4 x 4 periods per lane
+        runs[k].first_wave = static_cast<int32_t>(item_run.size());
+        item_run.insert(item_run.end(), static_cast<size_t>((lanes + 63) / 64), static_cast<int32_t>(k));
+    }
+    if (item_run.empty() || item_run.size() > 0x3fffffffu) return;
+    const size_t run_bytes = runs.size() * sizeof(jinc::DirectRun), item_bytes = item_run.size() * sizeof(int32_t);
+    char* dev = nullptr;
+    hip_check(hipMalloc(reinterpret_cast<void**>(&dev), run_bytes + item_bytes), "hipMalloc(direct runs)");
+    t.lane_blobs.push_back(dev);  // freed with the table
+    hip_check(hipMemcpy(dev, runs.data(), run_bytes, hipMemcpyHostToDevice), "direct runs upload");
+    hip_check(hipMemcpy(dev + run_bytes, item_run.data(), item_bytes, hipMemcpyHostToDevice), "direct runs upload");
+    jinc::DirectArgs da;
+    da.coeffs = t.plan.coeffs;
+    da.fs = p.fs;
+    da.coeff_row = (p.fs + 3) & ~3;
+    da.px = px, da.py = py, da.sx = sx, da.sy = sy;
+    da.ix0 = p.ix0, da.iy0 = p.iy0, da.ni = ni, da.nj = nj;
+    da.dst_h = p.g.dst_h;
+    da.plan = t.plan;
+    da.runs = reinterpret_cast<const jinc::DirectRun*>(dev);
+    da.item_run = reinterpret_cast<const int32_t*>(dev + run_bytes);
+    da.n_items = static_cast<int>(item_run.size());
+    t.runs = da;
+    t.use_runs = true;
+    if (!t.use_quasi) {  // (plan_quasi lays out the same border frame for the filter sizes it covers)
+        t.border_rects = border_frame(p, p.ix0 + px * ni, p.iy0 + py * nj);
+        t.border_rects.private_sets = true;
+        t.border_rects.unit_stride = true;
+    }
+}
+
 // Exactly periodic plans: kernel_direct.hip can take the interior (it is the choice for down-scales and taps > 8,
 // which the register/LDS kernels do not cover) and, for every interior kernel, the border rows and columns.
 void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
@@ -465,6 +548,7 @@ void init_device(jinc_filter& f, int device) {
         attach_quad(f.plans[i], f.tables[i]);
         plan_quasi(f.plans[i], f.tables[i]);
         plan_direct(f.plans[i], f.tables[i]);
+        plan_runs(f.plans[i], f.tables[i]);
         {   // every interior variant of a table must cover the same extent: the border frame is laid out once
             const DeviceTable& t = f.tables[i];
             int ex = -1, ey = -1;
@@ -475,6 +559,7 @@ void init_device(jinc_filter& f, int device) {
             if (t.use_periodic) same(t.periodic.ix0 + t.periodic.px * t.periodic.ni, t.periodic.iy0 + t.periodic.py * t.periodic.nj);
             if (t.use_quasi) same(t.quasi.ix0 + t.quasi.px * t.quasi.ni, t.quasi.iy0 + t.quasi.py * t.quasi.nj);
             if (t.use_direct) same(t.direct.ix0 + t.direct.px * t.direct.ni, t.direct.iy0 + t.direct.py * t.direct.nj);
+            if (t.use_runs) same(t.runs.ix0 + t.runs.px * t.runs.ni, t.runs.iy0 + t.runs.py * t.runs.nj);
         }
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].border_rects, f.stream);
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].corner_rects, f.stream);

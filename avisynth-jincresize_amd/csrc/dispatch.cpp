@@ -20,6 +20,17 @@ struct Rules {
     // kFrameLaneMinFrames (16) frames, filter sizes above 9 from 24, drifting plans with more than 16 phases from 36,
     // drifting fs-9 / fs-7 plans with a source step of 2 from 48 / 64
     static constexpr int kFrameLaneMinFramesBigFs = 24;
+    // ... against the runs form of the direct kernel (drifting plans with fs >= 9), plans with more than 16 phases only
+    // (round3/runs_vs_auto.txt: DVD -> 1080p with tap 4, 72 phases: 16 frames 118 (runs) against 82 Gpix/s, 128 frames 151 against
+    // 159; 5/2 with tap 6: 128 frames 120.5 against 124.7; with 9 phases the runs form is ahead at every batch size)
+    static constexpr int kFrameLaneMinFramesRuns = 48;
+    static constexpr int kRunsMaxPhasesInBatches = 16;
+    // calls (per plane) below this many taps stay with the gather kernel
+    static constexpr double kRunsMinTaps = 1.0e8;
+    // border kernels also move to the side stream when the border frame alone holds this many taps per call (drifting plans
+    // with large taps: every border pixel owns a set; 1.5x with tap 8, one frame: 20.5e6 border taps, 24.8 -> 29.0 Gpix/s;
+    // with tap 4: 2.9e6, 55.6 -> 44.3 when forked)
+    static constexpr double kOverlapMinBorderTaps = 1.0e7;
     static constexpr int kFrameLaneMinFramesManyPhases = 36;
     static constexpr int kFrameLaneMinFramesStep2Fs9 = 48;
     static constexpr int kFrameLaneMinFramesStep2Fs7 = 64;
@@ -122,6 +133,20 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         if (!direct_ok(t, i) || quasi_declined(t)) return false;
         return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
     };
+    // Runs form of the direct kernel (DeviceTable::use_runs): drifting plans with filter sizes from 9 on (taps 4..16 at 1.5x, 3x,
+    // 5/2, 8/3 x 9/4 ...).  Above fs 9 the alternative is the gather kernel (1.5x with tap 8, one frame per call: 13.6 -> 24.8
+    // Gpix/s, 16 frames: 26 -> 77); at fs 9 the quasi-periodic kernel (1.5x with tap 4: 1 / 16 / 64 frames per call 39.5 / 138 /
+    // 244 -> 55 / 217 / 268; 3x: 35.6 / 146 -> 51.5 / 197).  kernel_mode 14: wherever the plan has runs.
+    auto wants_runs = [&](const DeviceTable& t, int i) {
+        if (!t.use_runs || !f.direct_premise || (f.kernel_mode != 0 && f.kernel_mode != 14)) return false;
+        // tiny calls: the gather kernel's single launch is over before border + interior launches of this form are
+        // (640 x 360 -> 960 x 540 with tap 4, one frame, 42e6 taps: 21.5 against 15.6 Gpix/s; four frames: 48 against 54;
+        // with tap 8, one frame, 150e6 taps: 7.4 against 8.8)
+        if (f.kernel_mode == 0 && static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs * nframes < Rules::kRunsMinTaps)
+            return false;
+        const uint64_t plane_bytes = static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb;
+        return direct_fetch_is_safe(src_fs ? src_fs[i] : 0, nframes, plane_bytes, src_pitch[i], t.plan.fs);
+    };
     // Frame-lane kernel (lanes = frames): the choice for batches whose plan has no phase structure for the other
     // interior kernels (they would run on the gather kernel with per-lane coefficient traffic); kernel_mode 11 forces
     // it for every plan and batch size.
@@ -135,6 +160,8 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         // 1080p (72 phases), 42 for 1.5x with tap 4, ~50 for 1.5x
         if (nframes < (t.plan.fs > 9 ? Rules::kFrameLaneMinFramesBigFs : kFrameLaneMinFrames)) return false;
         if (wants_periodic(t)) return false;
+        if (f.kernel_mode == 0 && wants_runs(t, i))
+            return t.runs.px * t.runs.py > Rules::kRunsMaxPhasesInBatches && nframes >= Rules::kFrameLaneMinFramesRuns;
         if (wants_quasi(t)) {
             // whole groups of 128 frames: the frame-pair form is ahead of the quasi-periodic kernel on every plan measured
             // (256 frames: 1.5x 62 against 52 % of the VALU peak, 3x 69 against 68 %, 4/3x 60 against 54 %)
@@ -181,7 +208,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
     bool any_periodic = false;
     for (int i = 0; i < f.planecount; ++i) {
         const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        any_periodic |= f.simd_order == 0 && !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i));
+        any_periodic |= f.simd_order == 0 && !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i) || wants_runs(t, i));
     }
     // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
     // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
@@ -191,12 +218,15 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
     // -1: this automatic rule, 1: always, 0: never.
     bool want_overlap = f.overlap_border != 0;
     if (f.overlap_border < 0) {
-        double taps = 0.0;
+        double taps = 0.0, border_taps = 0.0;
         for (int i = 0; i < f.planecount; ++i) {
             const DeviceTable& t = f.tables[f.table_of_plane(i)];
             taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
+            if (wants_runs(t, i))
+                for (int r = 0; r < t.border_rects.n; ++r)
+                    border_taps += static_cast<double>(t.border_rects.w[r]) * t.border_rects.h[r] * t.plan.fs * t.plan.fs;
         }
-        want_overlap = taps * nframes >= Rules::kOverlapMinTaps;
+        want_overlap = taps * nframes >= Rules::kOverlapMinTaps || border_taps * nframes >= Rules::kOverlapMinBorderTaps;
     }
     const bool fork = any_periodic && want_overlap;
     if (fork) {  // border work may start once everything already queued on `stream` is done
@@ -272,6 +302,19 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                                         ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
                 timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             }
+            continue;
+        }
+        if (wants_runs(t, i)) {  // border frame on the gather kernel (every border pixel owns a coefficient set), interior in runs
+            t.last_kernel = "ewa_direct_runs_kernel";
+            if (t.border_rects.n > 0)
+                timed(f.ev_gather, border_stream, "border kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
+            timed(f.ev_periodic, stream, "direct runs kernel launch", [&](hipStream_t s) {
+                jinc::DirectArgs da = t.runs;
+                da.src_bytes = direct_src_bytes(
+                    src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                return jinc::launch_direct_runs(da, io, s);
+            });
             continue;
         }
         const bool direct = wants_direct(t, i);

@@ -96,6 +96,27 @@ int launch_direct(const DirectArgs& args, const PlaneIO& io, void* stream) {
 #undef JINC_WALK_BY_SX
 }
 
+bool direct_runs_supported(int fs, int px, int py, int sx, int sy) { return direct_supported(fs, px, py, sx, sy) && walk_supported(fs); }
+
+int launch_direct_runs(const DirectArgs& args, const PlaneIO& io, void* stream) {
+    if (args.n_items <= 0 || io.nframes <= 0) return 0;
+    if (!args.runs || !args.item_run || !walk_supported(args.fs)) return static_cast<int>(hipErrorInvalidValue);
+#define JINC_RUNS_SX(tag)                                                      \
+    switch (args.sx) {                                                         \
+        case 1: return launch_direct_runs_##tag##_sx1(args, io, stream);       \
+        case 2: return launch_direct_runs_##tag##_sx2(args, io, stream);       \
+        case 3: return launch_direct_runs_##tag##_sx3(args, io, stream);       \
+        case 4: return launch_direct_runs_##tag##_sx4(args, io, stream);       \
+        default: return static_cast<int>(hipErrorInvalidValue);                \
+    }
+    switch (io.sample_bytes) {
+        case 1: JINC_RUNS_SX(u8)
+        case 2: JINC_RUNS_SX(u16)
+        default: JINC_RUNS_SX(f32)
+    }
+#undef JINC_RUNS_SX
+}
+
 int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream) {
     if (args.ni <= 0 || io.nframes <= 0) return 0;
     return launch_direct_mode<kDirectRowStrip>(args, io, static_cast<hipStream_t>(stream));

@@ -2,4 +2,5 @@
 #define JINC_DIRECT_WALK_T float
 #define JINC_DIRECT_WALK_SX 1
 #define JINC_DIRECT_WALK_NAME launch_direct_walk_f32_sx1
+#define JINC_DIRECT_RUNS_NAME launch_direct_runs_f32_sx1
 #include "kernel_direct_walk.inc"

@@ -2,4 +2,5 @@
 #define JINC_DIRECT_WALK_T float
 #define JINC_DIRECT_WALK_SX 2
 #define JINC_DIRECT_WALK_NAME launch_direct_walk_f32_sx2
+#define JINC_DIRECT_RUNS_NAME launch_direct_runs_f32_sx2
 #include "kernel_direct_walk.inc"

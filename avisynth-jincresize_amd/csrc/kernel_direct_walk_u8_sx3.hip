@@ -2,4 +2,5 @@
 #define JINC_DIRECT_WALK_T uint8_t
 #define JINC_DIRECT_WALK_SX 3
 #define JINC_DIRECT_WALK_NAME launch_direct_walk_u8_sx3
+#define JINC_DIRECT_RUNS_NAME launch_direct_runs_u8_sx3
 #include "kernel_direct_walk.inc"

@@ -133,6 +133,18 @@ int launch_quasi(const QuasiArgs& args, int fs, const PlaneIO& io, void* stream)
 // The row walk of kernel_direct_impl.inc loads coefficient rows up to this many rows before / after a set without using
 // them ((R-1) * sy = 3 * 4); upload_table keeps that much addressable memory around the coefficient array.
 constexpr int kDirectCoeffSlackRows = 12;
+// One rectangle of the runs form (plans whose window origins are affine per residue while the phase classes change now and
+// then along an axis -- 1.5x, 3x, ...: PlanePlan::quasi): the pixels of column phase p and row phase q whose period-columns lie
+// in one run of constant column class and whose period-rows lie in one run of constant row class.  They share ONE coefficient
+// set, and their windows advance by (sx, sy) source samples per period -- inside the rectangle the plan is exactly periodic.
+struct DirectRun {
+    int32_t set = 0;
+    int32_t x0 = 0, y0 = 0;    // output pixel of the first period (then every px-th column, py-th row)
+    int32_t sx0 = 0, sy0 = 0;  // its window origin
+    int32_t ni = 0, nj = 0;    // periods
+    int32_t first_wave = 0;    // items before this rectangle's first (an item = 64 lanes x 4 x 4 periods)
+};
+
 struct DirectArgs {
     const float* coeffs = nullptr;
     int fs = 0, coeff_row = 0;   // filter size; floats per coefficient row on the device (padded_row(fs))
@@ -144,6 +156,10 @@ struct DirectArgs {
     DevicePlan plan;             // strips only: row/column tables
     uint32_t src_bytes = 0;      // readable bytes from the aligned-down base of one source plane (filter.cpp direct_src_bytes)
     int dst_h = 0;
+    // runs form only: the rectangles, the rectangle of every item, items per frame
+    const DirectRun* runs = nullptr;
+    const int32_t* item_run = nullptr;
+    int n_items = 0;
 };
 bool direct_supported(int fs, int px, int py, int sx, int sy);
 // Probe of the hardware premise of kernel_direct.hip (the buffer range check covers the scalar offset): `buf` holds
@@ -167,6 +183,18 @@ JINC_DECLARE_DIRECT_WALK(u16)
 JINC_DECLARE_DIRECT_WALK(f32)
 #undef JINC_DECLARE_DIRECT_WALK
 int launch_direct_row_strips(const DirectArgs& args, const PlaneIO& io, void* stream);
+// Runs form (DirectRun): ewa_direct_kernel's row walk over the rectangles of a drifting plan, one launch per plane.
+bool direct_runs_supported(int fs, int px, int py, int sx, int sy);
+int launch_direct_runs(const DirectArgs& args, const PlaneIO& io, void* stream);
+#define JINC_DECLARE_DIRECT_RUNS(tag)                                                 \
+    int launch_direct_runs_##tag##_sx1(const DirectArgs&, const PlaneIO&, void* stream); \
+    int launch_direct_runs_##tag##_sx2(const DirectArgs&, const PlaneIO&, void* stream); \
+    int launch_direct_runs_##tag##_sx3(const DirectArgs&, const PlaneIO&, void* stream); \
+    int launch_direct_runs_##tag##_sx4(const DirectArgs&, const PlaneIO&, void* stream);
+JINC_DECLARE_DIRECT_RUNS(u8)
+JINC_DECLARE_DIRECT_RUNS(u16)
+JINC_DECLARE_DIRECT_RUNS(f32)
+#undef JINC_DECLARE_DIRECT_RUNS
 
 // Left / right border columns of an exactly periodic plan over the interior's row range (kernel_colstrip.hip):
 // item = (output column x, row phase q), lanes = 64 consecutive period-rows, source footprint staged in LDS.

@@ -53,6 +53,13 @@ CONFIGS = {
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 128),  # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 256),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables (>= 128 frames: frame-pair kernel)
     "N15T4": ("Y8", 1280, 720, 1920, 1080, dict(tap=4), 256),  # 1.5x with Jinc64: fs 9, drifting (batches: frame-lane kernel)
+    "S15T4": ("Y8", 640, 360, 960, 540, dict(tap=4), 128),      # small frames at 1.5x: Jinc64 / Jinc256
+    "S15T8": ("Y8", 640, 360, 960, 540, dict(tap=8), 128),
+    "N3T4": ("Y8", 640, 360, 1920, 1080, dict(tap=4), 128),     # 3x with Jinc64: fs 9, source step 1, drifting
+    "N3T8": ("Y8", 640, 360, 1920, 1080, dict(tap=8), 128),     # 3x with Jinc256: fs 17
+    "N480T4": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=4), 128),  # DVD -> 1080p with Jinc64: 72 phases, source steps 3 / 4
+    "N480T6": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=6), 128),  # ... with Jinc144: fs 13
+    "N25T6": ("Y16", 768, 432, 1920, 1080, dict(tap=6), 128),   # 5/2 with Jinc144 on 16-bit: fs 13, period 5, source step 2
     "A137": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 256),    # 1.37x: no phase structure at all (>= 128 frames: frame-pair kernel)
     "A1875": ("Y8", 1024, 576, 1920, 1080, dict(tap=3), 256),  # PAL -> 1080p, 15/8: period 15, source step 8
     "D169": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 256),   # 5/6 down-scale: drifting, period 5, source step 6, fs 8

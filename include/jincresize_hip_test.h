@@ -52,7 +52,9 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * (lanes of a wave = frames of the batch; the automatic choice for batches of >= 16 frames whose plan has no phase
  * structure) for every plan and batch size, always in its 64-frame form, 12 = its frame-pair form (two frames per lane,
  * 128 frames per workgroup; the automatic choice for whole groups of 128 frames, filter sizes 5 and 7) for the whole batch
- * wherever it is configured. */
+ * wherever it is configured, 13 = the quad form of the periodic kernel (2x up-scales, filter sizes 7 and 9) wherever it is
+ * configured, 14 = the runs form of the direct kernel (drifting plans cut into rectangles of one coefficient set each; the
+ * automatic choice for drifting plans with filter sizes above 9) wherever the plan has runs. */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
 JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);

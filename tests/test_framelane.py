@@ -73,7 +73,11 @@ def test_batches_of_frames(gpu_pkg, O, case):
     for n in sizes:
         src_t = [torch.stack([to_t(fr[i]) for fr in frames[:n]]).cuda() for i in range(gfmt.planes)]
         dst_t = [torch.zeros((n, h, (w * sb + 63) // 64 * 64 // sb), dtype=tdtype, device="cuda") for (w, h) in ddims]
-        f.set_kernel_mode(0 if n >= 24 else 11)  # (automatic from 16 frames, from 24 for filter sizes above 9)
+        # automatic from 16 frames, from 24 for filter sizes above 9 -- except drifting plans the direct kernel's runs form takes
+        # (1.5x with tap 8: since round 3 the frame-lane kernel is never their automatic choice below 17 phases)
+        f.set_kernel_mode(0)
+        has_runs = f.interior_kernel(0) == "ewa_direct_runs_kernel"
+        f.set_kernel_mode(0 if n >= 24 and not has_runs else 11)
         stream = torch.cuda.current_stream()
         f.process_device([t.data_ptr() for t in src_t], [t.stride(1) * sb for t in src_t], [t.stride(0) * sb for t in src_t],
                          [t.data_ptr() for t in dst_t], [t.stride(1) * sb for t in dst_t], [t.stride(0) * sb for t in dst_t],

@@ -682,7 +682,7 @@ def test_randomised_arguments(gpu_pkg, O, seed, gen):
     # coefficient registers / exact, 8 = waterfall over sets in SGPRs, 10 = per-row look-up + per-lane registers; each also
     # with a tile's phases split over several workgroups (what small calls do in automatic mode).
     if any(f.plan_info(t).quasi for t in range(f.num_tables)):
-        for mode in (7, 8, 10):
+        for mode in (7, 8, 10, 14):  # 14: the direct kernel's runs form wherever the plan has runs (fs >= 9)
             f.set_kernel_mode(mode)
             assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + f" kernel mode {mode}")
     f.close()

@@ -33,7 +33,7 @@ def _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs):
 @pytest.mark.parametrize("case,depth,group,kernels", [
     (A137, 64, 0, "ewa_framelane_win"),   # automatic: groups of 32
     (A137, 64, 64, "ewa_framelane_win"),
-    (N15T8, 64, 32, "ewa_framelane_kernel"),
+    (N15T8, 64, 32, "ewa_direct_runs_kernel"),   # 1.5x with tap 8: since round 3 the runs form of the direct kernel, also in batches
 ], ids=["A137_auto", "A137_g64", "N15T8_g32"])
 def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg, O, case, depth, group, kernels):
     fmt, sw, sh, tw, th, kw = case
