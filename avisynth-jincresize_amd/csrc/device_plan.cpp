@@ -563,6 +563,11 @@ void init_device(jinc_filter& f, int device) {
         }
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].border_rects, f.stream);
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].corner_rects, f.stream);
+        if (f.tables[i].use_runs && f.tables[i].border_rects.n > 0) {
+            f.tables[i].use_fl_border =
+                jinc::framelane_configure(f.plans[i], f.tables[i].border_rects, f.vi_in.component_size, 64, f.tables[i].fl_border);
+            f.tables[i].fl_border.plan = f.tables[i].plan;
+        }
         f.tables[i].use_framelane =
             jinc::framelane_configure(f.plans[i], f.tables[i].whole, f.vi_in.component_size, 64, f.tables[i].fl_whole);
         f.tables[i].fl_whole.plan = f.tables[i].plan;

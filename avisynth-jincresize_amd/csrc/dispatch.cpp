@@ -20,17 +20,21 @@ struct Rules {
     // kFrameLaneMinFrames (16) frames, filter sizes above 9 from 24, drifting plans with more than 16 phases from 36,
     // drifting fs-9 / fs-7 plans with a source step of 2 from 48 / 64
     static constexpr int kFrameLaneMinFramesBigFs = 24;
-    // ... against the runs form of the direct kernel (drifting plans with fs >= 9), plans with more than 16 phases only
-    // (round3/runs_vs_auto.txt: DVD -> 1080p with tap 4, 72 phases: 16 frames 118 (runs) against 82 Gpix/s, 128 frames 151 against
-    // 159; 5/2 with tap 6: 128 frames 120.5 against 124.7; with 9 phases the runs form is ahead at every batch size)
-    static constexpr int kFrameLaneMinFramesRuns = 48;
-    static constexpr int kRunsMaxPhasesInBatches = 16;
+    // (against the runs form of the direct kernel -- drifting plans with fs >= 9 -- the frame-lane kernel is never chosen:
+    // round3/runs_vs_auto.txt, 128 frames, border frame on the frame-lane kernel: DVD -> 1080p with tap 4 169 against 159 Gpix/s,
+    // 5/2 with tap 6 135.5 against 124.7, 1.5x with tap 8 at 256 frames 88.9 against 79.7, with tap 4 265 against 255)
+    // batches from this many frames on: the border frame of a runs-form plan on the frame-lane kernel instead of the gather kernel
+    // where the frame is at least this many pixels wide (same log, 128 / 256 frames: 1.5x with tap 8 82.6 -> 88.9 Gpix/s, 3x with
+    // tap 8 77 -> 86, with tap 4 246 -> 272, 5/2 with tap 6 120 -> 135.5, DVD -> 1080p with tap 4 152 -> 169; 1.5x with tap 4, whose
+    // frame is 6 pixels wide: 265 -> 259, at 64 frames 267.5 -> 245)
+    static constexpr int kRunsFrameLaneBorderMinFrames = 64;
+    static constexpr int kRunsFrameLaneBorderMinWidth = 8;
     // calls (per plane) below this many taps stay with the gather kernel
     static constexpr double kRunsMinTaps = 1.0e8;
     // border kernels also move to the side stream when the border frame alone holds this many taps per call (drifting plans
     // with large taps: every border pixel owns a set; 1.5x with tap 8, one frame: 20.5e6 border taps, 24.8 -> 29.0 Gpix/s;
-    // with tap 4: 2.9e6, 55.6 -> 44.3 when forked)
-    static constexpr double kOverlapMinBorderTaps = 1.0e7;
+    // with tap 4: 2.9e6, 55.6 -> 44.3 when forked; four frames: 11.7e6, 143 -> 129)
+    static constexpr double kOverlapMinBorderTaps = 2.0e7;
     static constexpr int kFrameLaneMinFramesManyPhases = 36;
     static constexpr int kFrameLaneMinFramesStep2Fs9 = 48;
     static constexpr int kFrameLaneMinFramesStep2Fs7 = 64;
@@ -63,6 +67,17 @@ void validate_planes(const jinc_filter& f, const void* const src[4], const int s
         if (static_cast<uint64_t>(dst_pitch[i]) * t.plan.dst_h >= (1ull << 32))
             throw ArgError("JincResize: destination plane larger than 4 GiB is not supported (32-bit store offsets).");
     }
+}
+
+// Frames per call from which the border frame of a runs-form plan goes to the frame-lane kernel; A/B knob
+// JINC_RUNS_FL_BORDER_FRAMES (0: never); read once.
+int runs_fl_border_min_frames() {
+    static const int v = [] {
+        const char* e = std::getenv("JINC_RUNS_FL_BORDER_FRAMES");
+        const int n = e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinFrames;
+        return n <= 0 ? INT32_MAX : n;
+    }();
+    return v;
 }
 
 // A/B knob JINC_QUASI_SPLIT: workgroups per tile of the quasi-periodic kernel (0 / 1: no split); read once.
@@ -160,8 +175,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         // 1080p (72 phases), 42 for 1.5x with tap 4, ~50 for 1.5x
         if (nframes < (t.plan.fs > 9 ? Rules::kFrameLaneMinFramesBigFs : kFrameLaneMinFrames)) return false;
         if (wants_periodic(t)) return false;
-        if (f.kernel_mode == 0 && wants_runs(t, i))
-            return t.runs.px * t.runs.py > Rules::kRunsMaxPhasesInBatches && nframes >= Rules::kFrameLaneMinFramesRuns;
+        if (f.kernel_mode == 0 && wants_runs(t, i)) return false;
         if (wants_quasi(t)) {
             // whole groups of 128 frames: the frame-pair form is ahead of the quasi-periodic kernel on every plan measured
             // (256 frames: 1.5x 62 against 52 % of the VALU peak, 3x 69 against 68 %, 4/3x 60 against 54 %)
@@ -306,7 +320,18 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         }
         if (wants_runs(t, i)) {  // border frame on the gather kernel (every border pixel owns a coefficient set), interior in runs
             t.last_kernel = "ewa_direct_runs_kernel";
-            if (t.border_rects.n > 0)
+            if (t.use_fl_border && nframes >= runs_fl_border_min_frames() &&
+                std::min(t.runs.ix0, t.runs.iy0) >= Rules::kRunsFrameLaneBorderMinWidth) {
+                // batches: the border pixels' private sets as scalar loads of the frame-lane kernel (lanes = frames)
+                auto aligned_to = [&](uintptr_t bytes) {
+                    return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
+                           (nframes <= 1 || io.dst_frame_stride % bytes == 0);
+                };
+                jinc::FrameLaneArgs fa = t.fl_border;
+                fa.io = io;
+                fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
+                timed(f.ev_gather, border_stream, "border frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            } else if (t.border_rects.n > 0)
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
             timed(f.ev_periodic, stream, "direct runs kernel launch", [&](hipStream_t s) {

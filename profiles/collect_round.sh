@@ -11,7 +11,7 @@ ulimit -c 0
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out/$JINC_PROFILE_DIR
 if [ "$part" != lines ]; then
-for c in C2 C3 C4 A137 N15; do
+for c in ${JINC_PROFILE_CONFIGS:-C2 C3 C4 A137 N15}; do   # (JINC_PROFILE_CONFIGS / JINC_LINE_CONFIGS: other lists for partial re-collections)
   export JINC_FRAMES_PER_LAUNCH=$(python -c "import bench; print(bench.CONFIGS['$c'][6])")
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$c -- python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/${tag}_stats_$c.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-sampler > /dev/null 2>&1
@@ -23,9 +23,10 @@ done
 cp profiles/$JINC_PROFILE_DIR/${tag}_* gpurun_out/$JINC_PROFILE_DIR/ 2>/dev/null
 fi
 [ "$part" = profiles ] && exit 0
-for c in C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875; do
+for c in ${JINC_LINE_CONFIGS:-C1 C2 C3 C4 N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875 N3T4 N3T8 N480T4 N480T6 N25T6}; do
   timeout 120 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
   python profiles/bench_line.py < gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
 done
+[ -n "$JINC_LINE_CONFIGS" ] && exit 0
 timeout 300 python bench.py 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_default.json
 python profiles/bench_line.py < gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_default.json

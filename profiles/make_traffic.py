@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Rebuilds profiles/traffic.json (what bench.py copies into roofline.traffic) from the PMC summaries of a round.
 
-usage: make_traffic.py <round-dir> <tag>     e.g.  make_traffic.py round3 r3v  -> reads profiles/round3/r3v_c{2,3,4}.json
+usage: make_traffic.py <round-dir> <tag> [<tag> ...]   e.g.  make_traffic.py round3 r3w r3y  -> reads profiles/round3/r3w_c{2,3,4}.json ...;
+       a later tag replaces the configurations it holds
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB x 1024, separate --pmc passes).  The x2 on the read side is the
 gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the requests are 128 B); round 1
@@ -14,17 +15,20 @@ import os
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-rdir, tag = sys.argv[1], sys.argv[2]
+rdir, tags = sys.argv[1], sys.argv[2:]
+tag = "{" + ",".join(tags) + "}"
 
 out = {"_comment": "HBM bytes per launch of the dominant (interior) kernel from rocprofv3 PMC passes: 2 x FETCH_SIZE + WRITE_SIZE "
                    "(separate --pmc runs, KiB*1024; x2 = gfx950 FETCH_SIZE correction of the micro-architecture guide). Sources: "
                    f"profiles/{rdir}/{tag}_c*.json (profiles/collect_round.sh). For C3/C4 a step has three launches (one per "
                    "plane); the figure is the mean over them, like roofline.algorithmic_bytes_per_launch. bench.py copies the "
                    "value for its config into roofline.traffic, scaled to the frames per launch of the run."}
-for cfg in ("C2", "C3", "C4", "A137", "N15"):
-    path = os.path.join(HERE, rdir, f"{tag}_{cfg.lower()}.json")
-    if not os.path.exists(path):
+for cfg in ("C2", "C3", "C4", "A137", "N15", "N15T8", "N15T4"):
+    paths = [os.path.join(HERE, rdir, f"{t}_{cfg.lower()}.json") for t in tags]
+    paths = [q for q in paths if os.path.exists(q)]
+    if not paths:
         continue
+    path = paths[-1]
     d = json.load(open(path))
     name, e = max(((k, v) for k, v in d["kernels"].items() if "hbm_bytes_per_launch_raw" in v), key=lambda kv: kv[1]["avg_ns"] * kv[1]["calls"])
     out[cfg] = {"hbm_bytes_per_launch": int(round(2 * e["FETCH_SIZE_bytes_mean"] + e["WRITE_SIZE_bytes_mean"])),

@@ -135,3 +135,33 @@ def test_randomised_drifting_ratios(gpu_pkg, O, seed):
         f.set_kernel_mode(mode)
         assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + f" mode {mode}")
     f.close()
+
+
+@pytest.mark.parametrize("fmt,tap,n", [("Y8", 6, 70), ("Y16", 4, 64), ("Y32", 8, 65)], ids=["Y8_tap6_70", "Y16_tap4_64", "Y32_tap8_65"])
+def test_batches_take_the_border_frame_to_the_framelane_kernel(gpu_pkg, O, fmt, tap, n):
+    """From 64 frames per call on the border frame of a runs-form plan (every border pixel owns a coefficient set) runs on the
+    frame-lane kernel (lanes = frames) beside the interior's runs: every frame equals the forced gather kernel's result, some
+    are checked against the oracle."""
+    torch = pytest.importorskip("torch")
+    sw, sh, tw, th = 160, 92, 240, 138
+    kw = dict(tap=tap)
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=5200 + i) for i in range(n)]
+    host = np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])
+    sb = host.dtype.itemsize
+    src = torch.from_numpy(host.view(np.int16) if sb == 2 else host).cuda().contiguous()
+    outs = {}
+    for mode in (14, 1):
+        dst = torch.zeros((n, th, tw), dtype=src.dtype, device="cuda")
+        f.set_kernel_mode(mode)
+        stream = torch.cuda.current_stream()
+        f.process_device([src.data_ptr()], [sw * sb], [sw * sh * sb], [dst.data_ptr()], [tw * sb], [tw * th * sb], n, stream=stream.cuda_stream)
+        stream.synchronize()
+        outs[mode] = dst.cpu().numpy().view(host.dtype if sb != 4 else np.uint32)
+        assert f.last_kernel(0) == (RUNS if mode == 14 else "ewa_gather_kernel")
+    assert np.array_equal(outs[14], outs[1])
+    for i in (0, 63, n - 1):
+        want = np.ascontiguousarray(of.get_frame(frames[i], threads=4)[0][:th, :tw])
+        assert np.array_equal(outs[14][i], want.view(np.uint32) if sb == 4 else want), f"frame {i}"
+    f.close()
