@@ -114,7 +114,8 @@ def _random_case(rng):
     return fmt, sw, sh, sw * nx // dx, sh * ny // dy, kw
 
 
-@pytest.mark.parametrize("seed", range(32))
+# JINC_RUNS_SWEEP_SEEDS=N widens the sweep for soak runs
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("JINC_RUNS_SWEEP_SEEDS", "32"))))
 def test_randomised_drifting_ratios(gpu_pkg, O, seed):
     """Seeded sweep over drifting ratios with taps 4..12: automatic choice and the forced runs form, bit for bit."""
     rng = np.random.default_rng(4000 + seed)
