@@ -24,11 +24,12 @@ struct Rules {
     // round3/runs_vs_auto.txt, 128 frames, border frame on the frame-lane kernel: DVD -> 1080p with tap 4 169 against 159 Gpix/s,
     // 5/2 with tap 6 135.5 against 124.7, 1.5x with tap 8 at 256 frames 88.9 against 79.7, with tap 4 265 against 255)
     // batches from this many frames on: the border frame of a runs-form plan on the frame-lane kernel instead of the gather kernel
-    // where the frame is at least this many pixels wide (same log, 128 / 256 frames: 1.5x with tap 8 82.6 -> 88.9 Gpix/s, 3x with
-    // tap 8 77 -> 86, with tap 4 246 -> 272, 5/2 with tap 6 120 -> 135.5, DVD -> 1080p with tap 4 152 -> 169; 1.5x with tap 4, whose
-    // frame is 6 pixels wide: 265 -> 259, at 64 frames 267.5 -> 245)
+    // (round3/runs_vs_auto.txt, 128 / 256 frames, same box: 1.5x with tap 8 82.6 -> 88.9 Gpix/s, 3x with tap 8 77 -> 86, with tap 4
+    // 246 -> 272, 5/2 with tap 6 120 -> 135.5, DVD -> 1080p with tap 4 152 -> 169; 1.5x with tap 4, whose frame is 6 pixels wide:
+    // 276 -> 300, at 64 frames 268 -> 288 -- once the tile choice prices a tile by the pixels it really holds, framelane_dispatch.cpp;
+    // with the square tiles chosen before, it lost 2 .. 8 % there)
     static constexpr int kRunsFrameLaneBorderMinFrames = 64;
-    static constexpr int kRunsFrameLaneBorderMinWidth = 8;
+    static constexpr int kRunsFrameLaneBorderMinWidth = 4;
     // calls (per plane) below this many taps stay with the gather kernel
     static constexpr double kRunsMinTaps = 1.0e8;
     // border kernels also move to the side stream when the border frame alone holds this many taps per call (drifting plans
@@ -76,6 +77,14 @@ int runs_fl_border_min_frames() {
         const char* e = std::getenv("JINC_RUNS_FL_BORDER_FRAMES");
         const int n = e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinFrames;
         return n <= 0 ? INT32_MAX : n;
+    }();
+    return v;
+}
+
+int runs_fl_border_min_width() {  // A/B knob JINC_RUNS_FL_BORDER_WIDTH; read once
+    static const int v = [] {
+        const char* e = std::getenv("JINC_RUNS_FL_BORDER_WIDTH");
+        return e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinWidth;
     }();
     return v;
 }
@@ -321,7 +330,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         if (wants_runs(t, i)) {  // border frame on the gather kernel (every border pixel owns a coefficient set), interior in runs
             t.last_kernel = "ewa_direct_runs_kernel";
             if (t.use_fl_border && nframes >= runs_fl_border_min_frames() &&
-                std::min(t.runs.ix0, t.runs.iy0) >= Rules::kRunsFrameLaneBorderMinWidth) {
+                std::min(t.runs.ix0, t.runs.iy0) >= runs_fl_border_min_width()) {
                 // batches: the border pixels' private sets as scalar loads of the frame-lane kernel (lanes = frames)
                 auto aligned_to = [&](uintptr_t bytes) {
                     return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&

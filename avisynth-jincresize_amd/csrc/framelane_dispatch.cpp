@@ -27,6 +27,12 @@ namespace {
 bool configure_tiles(const PlanePlan& p, const RectList& rects, int ps, size_t budget, int frames_per_group, int nframes_hint,
                      double col_weight, FrameLaneArgs& out) {
     const int groups = std::max(1, (nframes_hint + frames_per_group - 1) / frames_per_group);
+    // A/B knob JINC_FL_FILL_WEIGHT (default on): see the cost below (whole planes: no change of any choice measured; the 6-pixel
+    // border frame of 1.5x with tap 4 at 256 frames: border kernel 2.02 -> 0.37 ms, step 259 -> 300 Gpix/s)
+    static const bool fill_weighted = [] {
+        const char* e = std::getenv("JINC_FL_FILL_WEIGHT");
+        return !e || std::atoi(e) != 0;
+    }();
 
     bool found = false, found_enough = false;
     double best_cost = 0.0;
@@ -45,7 +51,13 @@ bool configure_tiles(const PlanePlan& p, const RectList& rects, int ps, size_t b
             // (+ 1 row: the sliding-window form pads the column pitch of its column-major tile to an odd number)
             const size_t bytes = kFrameLaneTableBytes(tys) + (static_cast<size_t>(max_tw) * (max_th + 1) + 8) * ps;
             if (bytes > budget) continue;
-            const double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty) + col_weight * max_tw / tx;
+            double cost = static_cast<double>(max_tw) * max_th / (static_cast<double>(tx) * ty) + col_weight * max_tw / tx;
+            if (fill_weighted) {  // thin rectangles (border frames): a tile's cost is spread over the pixels it really holds
+                double area = 0.0;
+                for (int r = 0; r < rects.n; ++r)
+                    if (rects.w[r] > 0 && rects.h[r] > 0) area += static_cast<double>(rects.w[r]) * rects.h[r];
+                cost *= static_cast<double>(tiles) * tx * ty / area;
+            }
             const bool enough = tiles * groups >= 1024;  // >= 2 workgroups in flight per CU, twice over
             if (found && ((found_enough && !enough) || (enough == found_enough && cost >= best_cost))) continue;
             found = true;
