@@ -28,7 +28,9 @@ struct Rules {
     // 246 -> 272, 5/2 with tap 6 120 -> 135.5, DVD -> 1080p with tap 4 152 -> 169; 1.5x with tap 4, whose frame is 6 pixels wide:
     // 276 -> 300, at 64 frames 268 -> 288 -- once the tile choice prices a tile by the pixels it really holds, framelane_dispatch.cpp;
     // with the square tiles chosen before, it lost 2 .. 8 % there)
-    static constexpr int kRunsFrameLaneBorderMinFrames = 64;
+    // (by batch size, frame-lane against gather border: 1.5x with tap 4 +6 % at 16 frames, +9 % at 32; with tap 8 -8 % at 16, level
+    // at 32, +3 % at 48; 3x with tap 4 -2 % / +3 % / +5 %; DVD -> 1080p with tap 4 +1 % / +5.5 % / +10 %)
+    static constexpr int kRunsFrameLaneBorderMinFrames = 32;
     static constexpr int kRunsFrameLaneBorderMinWidth = 4;
     // calls (per plane) below this many taps stay with the gather kernel
     static constexpr double kRunsMinTaps = 1.0e8;
