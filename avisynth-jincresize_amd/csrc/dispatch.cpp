@@ -32,6 +32,8 @@ struct Rules {
     // at 32, +3 % at 48; 3x with tap 4 -2 % / +3 % / +5 %; DVD -> 1080p with tap 4 +1 % / +5.5 % / +10 %)
     static constexpr int kRunsFrameLaneBorderMinFrames = 32;
     static constexpr int kRunsFrameLaneBorderMinWidth = 4;
+    // multi-plane calls whose first plane has at most this many output samples run their other planes on the side stream
+    static constexpr double kPlaneForkMaxSamples = 1.0e7;
     // calls (per plane) below this many taps stay with the gather kernel
     static constexpr double kRunsMinTaps = 1.0e8;
     // border kernels also move to the side stream when the border frame alone holds this many taps per call (drifting plans
@@ -87,6 +89,14 @@ int runs_fl_border_min_width() {  // A/B knob JINC_RUNS_FL_BORDER_WIDTH; read on
     static const int v = [] {
         const char* e = std::getenv("JINC_RUNS_FL_BORDER_WIDTH");
         return e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinWidth;
+    }();
+    return v;
+}
+
+bool plane_fork_enabled() {  // A/B knob JINC_PLANE_FORK (default: on); read once
+    static const bool v = [] {
+        const char* e = std::getenv("JINC_PLANE_FORK");
+        return !e || std::atoi(e) != 0;
     }();
     return v;
 }
@@ -254,12 +264,21 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         want_overlap = taps * nframes >= Rules::kOverlapMinTaps || border_taps * nframes >= Rules::kOverlapMinBorderTaps;
     }
     const bool fork = any_periodic && want_overlap;
-    if (fork) {  // border work may start once everything already queued on `stream` is done
+    // Small calls with chroma planes (no border fork): the planes behind the first go to the side stream, interior and border, so
+    // that luma and chroma run beside each other -- a single frame's planes fill the chip even less one by one.
+    // Measured, one frame per call (round3/plane_fork_ab.txt): 1080p -> 4K 4:2:0 44.1 -> 49.6 Gpix/s, 4K -> 1080p 4:2:0 16-bit 8.7 -> 9.9,
+    // DVD -> 1080p with tap 6 13.2 -> 15.6, four DVD frames with tap 3 57.7 -> 61.8; level where the first plane fills the chip
+    // alone (four 4K frames) and -2 % on 8K float RGB planes, hence the limit on the first plane's samples.
+    const bool plane_fork = !fork && f.planecount >= 2 && f.simd_order == 0 && plane_fork_enabled() &&
+                            static_cast<double>(f.tables[f.table_of_plane(0)].plan.dst_w) * f.tables[f.table_of_plane(0)].plan.dst_h * nframes <=
+                                Rules::kPlaneForkMaxSamples;
+    if (fork || plane_fork) {  // side-stream work may start once everything already queued on `stream` is done
         hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");
         hip_check(hipStreamWaitEvent(f.aux_stream, f.ev_fork, 0), "hipStreamWaitEvent(fork)");
     }
-    hipStream_t border_stream = fork ? f.aux_stream : stream;
     for (int i = 0; i < f.planecount; ++i) {
+        hipStream_t plane_stream = (plane_fork && i >= 1) ? f.aux_stream : stream;
+        hipStream_t border_stream = fork ? f.aux_stream : plane_stream;
         DeviceTable& t = f.tables[f.table_of_plane(i)];
         jinc::PlaneIO io;
         io.src = src[i];
@@ -287,7 +306,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         if (f.simd_order != 0) {  // compatibility modes (private switch): whole plane on kernel_simdorder.hip
             const float min_val = (i != 0 && !f.vi_in.is_rgb) ? -0.5f : 0.f;  // ref resize_plane_sse41.cpp:20
             t.last_kernel = "ewa_simd_order_kernel";
-            timed(f.ev_gather, stream, "SIMD-order kernel launch",
+            timed(f.ev_gather, plane_stream, "SIMD-order kernel launch",
                   [&](hipStream_t s) { return jinc::launch_simd_order(t.plan, io, f.simd_order, min_val, s); });
             continue;
         }
@@ -312,7 +331,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                 fa.io.nframes = npair;
                 fa.vec_store_ok = vec_ok;
                 t.last_kernel = "ewa_framelane_pair_kernel";
-                timed(f.ev_periodic, stream, "frame-pair kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_pair(fa, s); });
+                timed(f.ev_periodic, plane_stream, "frame-pair kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_pair(fa, s); });
             }
             if (npair < nframes) {
                 jinc::FrameLaneArgs fa = t.fl_whole;
@@ -325,7 +344,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                     t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
                                     : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
                                         ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
-                timed(f.ev_periodic, stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+                timed(f.ev_periodic, plane_stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             }
             continue;
         }
@@ -345,7 +364,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
             } else if (t.border_rects.n > 0)
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
-            timed(f.ev_periodic, stream, "direct runs kernel launch", [&](hipStream_t s) {
+            timed(f.ev_periodic, plane_stream, "direct runs kernel launch", [&](hipStream_t s) {
                 jinc::DirectArgs da = t.runs;
                 da.src_bytes = direct_src_bytes(
                     src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
@@ -390,14 +409,14 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
             }
             if (direct)
-                timed(f.ev_periodic, stream, "direct periodic kernel launch", [&](hipStream_t s) {
+                timed(f.ev_periodic, plane_stream, "direct periodic kernel launch", [&](hipStream_t s) {
                     jinc::DirectArgs da = t.direct;
                     da.src_bytes = direct_src_bytes(
                         src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
                     return jinc::launch_direct(da, io, s);
                 });
             else if (quasi)
-                timed(f.ev_periodic, stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
+                timed(f.ev_periodic, plane_stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
                     jinc::QuasiArgs qa = t.quasi;
                     if (f.kernel_mode == 8) qa.exact = 0;   // A/B: per-row lookup + waterfall over sets in SGPRs
                     if (f.kernel_mode == 10) qa.exact = 2;  // A/B: per-row lookup + per-lane coefficient registers
@@ -417,7 +436,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                     return jinc::launch_quasi(qa, t.plan.fs, io, s);
                 });
             else
-                timed(f.ev_periodic, stream, "periodic kernel launch", [&](hipStream_t s) {
+                timed(f.ev_periodic, plane_stream, "periodic kernel launch", [&](hipStream_t s) {
                     int variant = (f.kernel_mode >= 3 && f.kernel_mode <= 6) ? f.kernel_mode - 2 : 0;
                     // quad form (2x up-scales whose phases share their window origin: a lane computes a period's 2 x 2 pixels from
                     // one window on packed multiplies / adds), chosen where it measured ahead (profiles/round3/quad_ab.log):
@@ -442,11 +461,11 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                     return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);
                 });
         } else {
-            timed(f.ev_gather, stream, "gather kernel launch",
+            timed(f.ev_gather, plane_stream, "gather kernel launch",
                   [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.whole, s); });
         }
     }
-    if (fork) {  // `stream` continues only after the border kernels have finished too
+    if (fork || plane_fork) {  // `stream` continues only after the side stream's kernels have finished too
         hip_check(hipEventRecord(f.ev_join, f.aux_stream), "hipEventRecord(join)");
         hip_check(hipStreamWaitEvent(stream, f.ev_join, 0), "hipStreamWaitEvent(join)");
     }

@@ -53,6 +53,7 @@ CONFIGS = {
     "U43": ("Y8", 1440, 1080, 1920, 1440, dict(tap=3), 128),  # 4/3x: exactly periodic, period 4 / source step 3
     "N480": ("YUV420P8", 720, 480, 1920, 1080, dict(tap=3), 256),  # DVD -> 1080p: 8/3 x 9/4, luma and chroma tables (>= 128 frames: frame-pair kernel)
     "N15T4": ("Y8", 1280, 720, 1920, 1080, dict(tap=4), 256),  # 1.5x with Jinc64: fs 9, drifting (batches: frame-lane kernel)
+    "C2YUV": ("YUV420P8", 1920, 1080, 3840, 2160, dict(tap=3), 64),  # C2's geometry on a 4:2:0 frame (luma + two chroma planes)
     "D12Y16": ("Y16", 3840, 2160, 1920, 1080, dict(tap=3), 64),   # 4K -> 1080p, one 16-bit / float plane (D12H / D12F without the chroma planes)
     "D12Y32": ("Y32", 3840, 2160, 1920, 1080, dict(tap=3), 32),
     "S15T4": ("Y8", 640, 360, 960, 540, dict(tap=4), 128),      # small frames at 1.5x: Jinc64 / Jinc256
