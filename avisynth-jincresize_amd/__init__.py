@@ -79,7 +79,7 @@ ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_hei
 EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
            "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
-           "jinc_filter_plan_dump", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
+           "jinc_filter_plan_dump", "jinc_filter_plan_runs", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
@@ -129,6 +129,7 @@ def lib():
         L.jinc_filter_plan_pixel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
                                              C.POINTER(C.c_int), C.c_void_p]
         L.jinc_filter_plan_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jinc_filter_plan_runs.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_int]
         L.jinc_filter_plan_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.jinc_filter_lut.argtypes = [C.c_void_p, C.c_void_p]
         L.jinc_filter_set_kernel_mode.argtypes = [C.c_void_p, C.c_int]
@@ -534,6 +535,16 @@ class Filter:
         ids = np.zeros((info.dst_height, info.dst_width), np.int32)
         self._check(lib().jinc_filter_plan_dump(self._h, table, sx.ctypes.data, sy.ctypes.data, ids.ctypes.data))
         return sx, sy, ids
+
+    def plan_runs(self, table: int = 0):
+        """Rectangles of a drifting plan (what the runs form of the direct kernel walks): (array [n, 8] of set, x0, y0, sx0, sy0,
+        ni, nj, first_item; number of items).  Empty for plans without runs.  Works without a device."""
+        n, items = C.c_int(0), C.c_int(0)
+        self._check(lib().jinc_filter_plan_runs(self._h, table, C.byref(n), C.byref(items), None, 0))
+        runs = np.zeros((n.value, 8), np.int32)
+        if n.value:
+            self._check(lib().jinc_filter_plan_runs(self._h, table, C.byref(n), C.byref(items), runs.ctypes.data, n.value))
+        return runs, items.value
 
     def plan_sets(self, table: int = 0) -> np.ndarray:
         info = self.plan_info(table)

@@ -271,6 +271,19 @@ int jinc_filter_plan_dump(const jinc_filter* f, int table, int* start_x, int* st
     return JINC_OK;
 }
 
+int jinc_filter_plan_runs(const jinc_filter* f, int table, int* n_runs, int* n_items, int32_t* runs, int capacity) {
+    const jinc::PlanePlan* p = table_or_null(f, table);
+    if (!p || !n_runs || !n_items) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad table index or null argument.");
+    std::vector<jinc::PlanRun> list;
+    std::vector<int32_t> item_run;
+    if (!jinc::build_plan_runs(*p, list, item_run)) list.clear(), item_run.clear();
+    *n_runs = static_cast<int>(list.size());
+    *n_items = static_cast<int>(item_run.size());
+    if (runs && capacity > 0)
+        std::memcpy(runs, list.data(), sizeof(jinc::PlanRun) * std::min<size_t>(list.size(), static_cast<size_t>(capacity)));
+    return JINC_OK;
+}
+
 int jinc_filter_plan_set(const jinc_filter* f, int table, int set, float* coeffs) {
     const jinc::PlanePlan* p = table_or_null(f, table);
     if (!p || !coeffs || set < 0 || set >= p->num_sets) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad table or set index.");

@@ -3,6 +3,8 @@
 // ("ref:" = /root/reference/src/JincResize.cpp).
 #include "plan.h"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstring>
 #include <stdexcept>
@@ -311,6 +313,61 @@ PlanePlan build_plane_plan(const JincLut& lut, const TableGeometry& g) {
         plan.ix0 = plan.ix1 = plan.iy0 = plan.iy1 = 0;
     }
     return plan;
+}
+
+bool build_plan_runs(const PlanePlan& p, std::vector<PlanRun>& runs, std::vector<int32_t>& item_run) {
+    runs.clear();
+    item_run.clear();
+    if (p.periodic || !p.quasi || p.qpx < 1 || p.qpy < 1) return false;
+    const int px = p.qpx, py = p.qpy, sx = p.qsx, sy = p.qsy;
+    const int ni = (p.ix1 - p.ix0) / px, nj = (p.iy1 - p.iy0) / py;
+    if (ni < 1 || nj < 1) return false;
+    struct AxisRun {
+        int first, count, cls;
+    };
+    bool ok = true;
+    auto axis_runs = [&](const std::vector<int32_t>& cls, const std::vector<int32_t>& start, int o0, int period, int step, int n, int phase) {
+        std::vector<AxisRun> r;
+        for (int i = 0; i < n; ++i) {
+            const int x = o0 + period * i + phase;
+            if (cls[x] < 0 || start[x] != start[o0 + phase] + step * i) ok = false;  // not what PlanePlan::quasi promises
+            if (r.empty() || r.back().cls != cls[x])
+                r.push_back({i, 1, cls[x]});
+            else
+                ++r.back().count;
+        }
+        return r;
+    };
+    for (int q = 0; q < py; ++q) {
+        const std::vector<AxisRun> ry = axis_runs(p.row_class, p.row_start, p.iy0, py, sy, nj, q);
+        for (int r = 0; r < px; ++r) {
+            const std::vector<AxisRun> rx = axis_runs(p.col_class, p.col_start, p.ix0, px, sx, ni, r);
+            if (!ok) {
+                runs.clear();
+                return false;
+            }
+            for (const AxisRun& b : ry)
+                for (const AxisRun& a : rx) {
+                    PlanRun d;
+                    d.set = p.interior_set[static_cast<std::size_t>(b.cls) * p.n_col_classes + a.cls];
+                    d.x0 = p.ix0 + px * a.first + r;
+                    d.y0 = p.iy0 + py * b.first + q;
+                    d.sx0 = p.col_start[d.x0];
+                    d.sy0 = p.row_start[d.y0];
+                    d.ni = a.count;
+                    d.nj = b.count;
+                    runs.push_back(d);
+                }
+        }
+    }
+    // rectangles of the same neighbourhood next to each other: consecutive items then read the same source rows
+    std::sort(runs.begin(), runs.end(), [](const PlanRun& a, const PlanRun& b) { return a.y0 != b.y0 ? a.y0 < b.y0 : a.x0 < b.x0; });
+    for (std::size_t k = 0; k < runs.size(); ++k) {
+        const long long lanes = static_cast<long long>((runs[k].ni + 3) / 4) * ((runs[k].nj + 3) / 4);  // 4 x 4 periods per lane
+        runs[k].first_item = static_cast<int32_t>(item_run.size());
+        item_run.insert(item_run.end(), static_cast<std::size_t>((lanes + 63) / 64), static_cast<int32_t>(k));
+    }
+    return !item_run.empty() && item_run.size() <= 0x3fffffffu;
 }
 
 }  // namespace jinc

@@ -70,6 +70,21 @@ struct PlanePlan {
     const float* set_ptr(int set) const { return coeffs.data() + static_cast<std::size_t>(set) * fs * fs; }
 };
 
+// One rectangle of a drifting plan (quasi && !periodic): the pixels of column phase p and row phase q whose period-columns lie in
+// one run of constant column class and whose period-rows lie in one run of constant row class.  They share ONE coefficient set and
+// their windows advance by (qsx, qsy) source samples per period: inside the rectangle the plan is exactly periodic (the premise of
+// the direct kernel; kernels.h DirectRun has this layout).
+struct PlanRun {
+    int32_t set = 0;
+    int32_t x0 = 0, y0 = 0;    // output pixel of the first period (then every qpx-th column, qpy-th row)
+    int32_t sx0 = 0, sy0 = 0;  // its window origin
+    int32_t ni = 0, nj = 0;    // periods
+    int32_t first_item = 0;    // items before this rectangle's first (an item = 64 lanes x 4 x 4 periods)
+};
+// The rectangles of the interior block [ix0, ix0 + qpx * ni) x [iy0, iy0 + qpy * nj), ni = (ix1 - ix0) / qpx (nj likewise), ordered by
+// position, and the rectangle of every item.  False when the plan is not a drifting one or does not keep what `quasi` promises.
+bool build_plan_runs(const PlanePlan& p, std::vector<PlanRun>& runs, std::vector<int32_t>& item_run);
+
 // Throws std::runtime_error for geometry the reference handles only through out-of-bounds reads
 // (source plane smaller than the filter footprint) or degenerate sizes.
 PlanePlan build_plane_plan(const JincLut& lut, const TableGeometry& g);

@@ -37,6 +37,10 @@ JINC_API int jinc_filter_plan_pixel(const jinc_filter *f, int table, int x, int 
                                     float *coeffs);
 /* Bulk form: fills start_x[dst_w], start_y[dst_h] and set_id[dst_h*dst_w]; any pointer may be NULL. */
 JINC_API int jinc_filter_plan_dump(const jinc_filter *f, int table, int *start_x, int *start_y, int *set_id);
+/* Rectangles of a drifting plan (quasi && !periodic): what the runs form of the direct kernel walks (csrc/plan.h PlanRun, 8 ints
+ * each: set, x0, y0, sx0, sy0, ni, nj, first_item).  *n_runs / *n_items receive the counts (0 / 0 when the plan has no runs);
+ * up to `capacity` rectangles are copied to `runs` when it is not NULL.  Host code: works on instances without a device. */
+JINC_API int jinc_filter_plan_runs(const jinc_filter *f, int table, int *n_runs, int *n_items, int32_t *runs, int capacity);
 /* Copies the coefficient set `set` (filter_size^2 floats). */
 JINC_API int jinc_filter_plan_set(const jinc_filter *f, int table, int set, float *coeffs);
 /* The 1024-entry LUT (ref :265-275) as doubles. */
