@@ -523,7 +523,7 @@ void init_device(jinc_filter& f, int device) {
         }
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].border_rects, f.stream);
         attach_lane_coeffs(f.plans[i], f.tables[i], f.tables[i].corner_rects, f.stream);
-        if (f.tables[i].use_runs && f.tables[i].border_rects.n > 0) {
+        if ((f.tables[i].use_runs || (f.tables[i].use_quasi && !f.plans[i].periodic)) && f.tables[i].border_rects.n > 0) {
             f.tables[i].use_fl_border =
                 jinc::framelane_configure(f.plans[i], f.tables[i].border_rects, f.vi_in.component_size, 64, f.tables[i].fl_border);
             f.tables[i].fl_border.plan = f.tables[i].plan;

@@ -31,7 +31,6 @@ struct Rules {
     // (by batch size, frame-lane against gather border: 1.5x with tap 4 +6 % at 16 frames, +9 % at 32; with tap 8 -8 % at 16, level
     // at 32, +3 % at 48; 3x with tap 4 -2 % / +3 % / +5 %; DVD -> 1080p with tap 4 +1 % / +5.5 % / +10 %)
     static constexpr int kRunsFrameLaneBorderMinFrames = 32;
-    static constexpr int kRunsFrameLaneBorderMinWidth = 4;
     // multi-plane calls whose first plane has at most this many output samples run their other planes on the side stream
     static constexpr double kPlaneForkMaxSamples = 1.0e7;
     // calls (per plane) below this many taps stay with the gather kernel
@@ -81,14 +80,6 @@ int runs_fl_border_min_frames() {
         const char* e = std::getenv("JINC_RUNS_FL_BORDER_FRAMES");
         const int n = e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinFrames;
         return n <= 0 ? INT32_MAX : n;
-    }();
-    return v;
-}
-
-int runs_fl_border_min_width() {  // A/B knob JINC_RUNS_FL_BORDER_WIDTH; read once
-    static const int v = [] {
-        const char* e = std::getenv("JINC_RUNS_FL_BORDER_WIDTH");
-        return e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinWidth;
     }();
     return v;
 }
@@ -348,11 +339,10 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
             }
             continue;
         }
-        if (wants_runs(t, i)) {  // border frame on the gather kernel (every border pixel owns a coefficient set), interior in runs
-            t.last_kernel = "ewa_direct_runs_kernel";
-            if (t.use_fl_border && nframes >= runs_fl_border_min_frames() &&
-                std::min(t.runs.ix0, t.runs.iy0) >= runs_fl_border_min_width()) {
-                // batches: the border pixels' private sets as scalar loads of the frame-lane kernel (lanes = frames)
+        // Border frame of a drifting plan (every border pixel owns a coefficient set): the gather kernel, or in batches the frame-lane
+        // kernel (lanes = frames make the private sets scalar loads).
+        auto drifting_border = [&]() {
+            if (t.use_fl_border && nframes >= runs_fl_border_min_frames() && t.border_rects.n > 0) {
                 auto aligned_to = [&](uintptr_t bytes) {
                     return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
                            (nframes <= 1 || io.dst_frame_stride % bytes == 0);
@@ -361,9 +351,14 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                 fa.io = io;
                 fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
                 timed(f.ev_gather, border_stream, "border frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
-            } else if (t.border_rects.n > 0)
+            } else if (t.border_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
+            }
+        };
+        if (wants_runs(t, i)) {
+            t.last_kernel = "ewa_direct_runs_kernel";
+            drifting_border();
             timed(f.ev_periodic, plane_stream, "direct runs kernel launch", [&](hipStream_t s) {
                 jinc::DirectArgs da = t.runs;
                 da.src_bytes = direct_src_bytes(
@@ -404,9 +399,8 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                     timed(f.ev_gather, border_stream, "border column kernel launch",
                           [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
                 }
-            } else if (t.border_rects.n > 0) {
-                timed(f.ev_gather, border_stream, "border kernel launch",
-                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
+            } else {
+                drifting_border();  // (use_fl_border is set for drifting plans only: the others keep the gather kernel here)
             }
             if (direct)
                 timed(f.ev_periodic, plane_stream, "direct periodic kernel launch", [&](hipStream_t s) {

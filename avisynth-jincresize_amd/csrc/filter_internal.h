@@ -52,7 +52,7 @@ struct DeviceTable {
     jinc::DirectArgs row_strips;  // border rows of the same plan over the interior's columns (any interior kernel)
     bool use_runs = false;        // drifting plan cut into rectangles of one coefficient set each: the direct kernel's runs form
     jinc::DirectArgs runs;
-    bool use_fl_border = false;   // ... and its border frame on the frame-lane kernel when the call is a batch
+    bool use_fl_border = false;   // border frame of a drifting plan (runs form or quasi-periodic kernel) on the frame-lane kernel when the call is a batch
     jinc::FrameLaneArgs fl_border;
     bool strips_ok = false;       // the border rows / columns really repeat their coefficient sets per phase (plan_direct)
     bool use_colstrip = false;    // border columns over the interior's rows on kernel_colstrip.hip
