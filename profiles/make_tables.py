@@ -4,7 +4,7 @@ import glob, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 rdir, tag = sys.argv[1], sys.argv[2]
 order = ["C2", "C1", "C3", "C4", "A137", "A1875", "N15", "N3", "U43", "N480", "N15T4", "N15T8", "D169", "D12", "D23", "D13", "D12H", "D12F",
-         "D12T4", "D12T8", "T6", "T16"]
+         "D12T4", "D12T8", "T6", "T16", "N3T4", "N3T8", "N480T4", "N480T6", "N25T6"]
 print("| config (frames per step) | GPU Mpix/s | of the VALU ceiling | HBM fraction (algorithmic bytes) | interior kernel |")
 print("|---|---|---|---|---|")
 for c in order:
