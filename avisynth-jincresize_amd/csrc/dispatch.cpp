@@ -1,5 +1,7 @@
 // dispatch.cpp -- the kernel launches of one frame call: per plane, which interior kernel and which border kernels run,
 // on which stream (the body of the process_frame call, ref /root/reference/src/JincResize.cpp:615, on device planes).
+// Layout: Rules (the measured cross-over constants) -> Choice (the rules applied to one call: no launches) -> launch_plane (the
+// launches of one plane under a Choice) -> enqueue_run (batch split, fork / join of the side stream, the plane loop).
 #include <algorithm>
 #include <cstdlib>
 
@@ -123,48 +125,58 @@ const char* last_interior_kernel_in_process() { return g_last_interior_kernel.lo
 int last_call_frames_in_process() { return g_last_call_frames.load(std::memory_order_relaxed); }
 
 namespace {
-void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4], void* const dst[4],
-                 const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream, bool may_split) {
-    const int sb = f.vi_in.component_size;
+// What one call launches for each plane: the rules of the automatic kernel choice (and the forced kernel modes), evaluated for the
+// call's planes, pitches and frame count.  No launches here.
+struct Choice {
+    const jinc_filter& f;
+    const int* src_pitch;
+    const size_t* src_fs;
+    const int nframes;
+    const int sb;
+    double call_samples = 0.0;  // output samples of the whole call
+
+    Choice(const jinc_filter& filter, const int src_pitch_[4], const size_t src_fs_[4], int nframes_)
+        : f(filter), src_pitch(src_pitch_), src_fs(src_fs_), nframes(nframes_), sb(filter.vi_in.component_size) {
+        for (int i = 0; i < f.planecount; ++i) {
+            const DeviceTable& t = f.tables[f.table_of_plane(i)];
+            call_samples += static_cast<double>(t.plan.dst_w) * t.plan.dst_h;
+        }
+        call_samples *= nframes;
+    }
+
     // kernel_mode: 0 automatic, 1 gather only, 2.. A/B variants of the periodic kernels, 7 quasi-periodic
     // kernel wherever it applies (also for exactly periodic plans)
     // Calls of fewer than ~3e6 output samples (one 1080p frame, two 960 x 540 frames) leave the quasi-periodic kernel with a
     // few dozen workgroups of long serial phase loops even after the phase split below; the gather kernel's many small
     // blocks finish sooner: one frame per call 4/3x 45 -> 68 Gpix/s, 4/3x with tap 4 37 -> 46, 960 x 540 at 1.5x 16.5 -> 28
     // (two frames: 33 -> 44), 5/4x and 1.5x at 1080p equal; 1.5x with tap 4 loses 11 % (45 -> 40).
-    double call_samples = 0.0;
-    for (int i = 0; i < f.planecount; ++i) {
-        const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        call_samples += static_cast<double>(t.plan.dst_w) * t.plan.dst_h;
-    }
-    call_samples *= nframes;
-    auto quasi_declined = [&](const DeviceTable& t) {  // (... in favour of the gather kernel, not of the direct kernel)
+    bool quasi_declined(const DeviceTable& t) const {  // (... in favour of the gather kernel, not of the direct kernel)
         return f.kernel_mode == 0 && call_samples < Rules::kQuasiMinSamples && t.use_quasi && !t.use_periodic;
-    };
-    auto wants_quasi = [&](const DeviceTable& t) {
+    }
+    bool wants_quasi(const DeviceTable& t) const {
         if (quasi_declined(t)) return false;
         return t.use_quasi && (f.kernel_mode == 7 || f.kernel_mode == 8 || f.kernel_mode == 10 || (f.kernel_mode != 1 && !t.use_periodic));
-    };
-    auto wants_periodic = [&](const DeviceTable& t) {
+    }
+    bool wants_periodic(const DeviceTable& t) const {
         return t.use_periodic && f.kernel_mode != 1 && f.kernel_mode != 7 && f.kernel_mode != 8 && f.kernel_mode != 10;
-    };
+    }
     // Is kernel_direct.hip usable for plane i (interior and border strips)?  See direct_fetch_is_safe().
-    auto direct_ok = [&](const DeviceTable& t, int i) {
+    bool direct_ok(const DeviceTable& t, int i) const {
         if (!t.use_direct || f.kernel_mode == 1 || !f.direct_premise) return false;
         const uint64_t plane_bytes = static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb;
         return direct_fetch_is_safe(src_fs ? src_fs[i] : 0, nframes, plane_bytes, src_pitch[i], t.plan.fs);
-    };
+    }
     // kernel_mode 9: the direct kernel wherever it applies; otherwise it takes the interior of the exactly periodic
     // plans the register/LDS kernels do not cover.
-    auto wants_direct = [&](const DeviceTable& t, int i) {
+    bool wants_direct(const DeviceTable& t, int i) const {
         if (!direct_ok(t, i) || quasi_declined(t)) return false;
         return f.kernel_mode == 9 || (!wants_periodic(t) && !wants_quasi(t));
-    };
+    }
     // Runs form of the direct kernel (DeviceTable::use_runs): drifting plans with filter sizes from 9 on (taps 4..16 at 1.5x, 3x,
     // 5/2, 8/3 x 9/4 ...).  Above fs 9 the alternative is the gather kernel (1.5x with tap 8, one frame per call: 13.6 -> 24.8
     // Gpix/s, 16 frames: 26 -> 77); at fs 9 the quasi-periodic kernel (1.5x with tap 4: 1 / 16 / 64 frames per call 39.5 / 138 /
     // 244 -> 55 / 217 / 268; 3x: 35.6 / 146 -> 51.5 / 197).  kernel_mode 14: wherever the plan has runs.
-    auto wants_runs = [&](const DeviceTable& t, int i) {
+    bool wants_runs(const DeviceTable& t, int i) const {
         if (!t.use_runs || !f.direct_premise || (f.kernel_mode != 0 && f.kernel_mode != 14)) return false;
         // tiny calls: the gather kernel's single launch is over before border + interior launches of this form are
         // (640 x 360 -> 960 x 540 with tap 4, one frame, 42e6 taps: 21.5 against 15.6 Gpix/s; four frames: 48 against 54;
@@ -173,11 +185,11 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
             return false;
         const uint64_t plane_bytes = static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb;
         return direct_fetch_is_safe(src_fs ? src_fs[i] : 0, nframes, plane_bytes, src_pitch[i], t.plan.fs);
-    };
+    }
     // Frame-lane kernel (lanes = frames): the choice for batches whose plan has no phase structure for the other
     // interior kernels (they would run on the gather kernel with per-lane coefficient traffic); kernel_mode 11 forces
     // it for every plan and batch size.
-    auto wants_framelane = [&](const DeviceTable& t, int i) {
+    bool wants_framelane(const DeviceTable& t, int i) const {
         if (!t.use_framelane || f.kernel_mode == 1) return false;
         if (f.kernel_mode == 11 || (f.kernel_mode == 12 && t.use_framelane_pair)) return true;
         if (f.kernel_mode != 0) return false;
@@ -202,7 +214,260 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                    nframes >= (t.plan.fs == 9 ? Rules::kFrameLaneMinFramesStep2Fs9 : Rules::kFrameLaneMinFramesStep2Fs7);
         }
         return !wants_direct(t, i);
+    }
+    // quad form of the periodic kernel (2x up-scales whose phases share their window origin), where it measured ahead
+    bool quad_chosen(const DeviceTable& t) const {
+        if (!t.periodic.quad) return false;
+        if (f.kernel_mode == 13) return true;
+        if (f.kernel_mode != 0) return false;
+        const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
+        // (fs 7: large planes only -- on 1280 x 720 the border kernels beside the denser interior become the step's tail:
+        // C1 at 256 frames 492 -> 465 Gpix/s)
+        const long long periods = static_cast<long long>(t.periodic.ni) * t.periodic.nj;
+        return t.plan.fs == 7 ? (wgs >= Rules::kHalfTileMaxWorkgroups && periods >= Rules::kQuadMinPeriods) : wgs < Rules::kQuad9MaxWorkgroups;
+    }
+
+    // does any plane launch border kernels beside an interior kernel?
+    bool any_border_frame() const {
+        bool any = false;
+        for (int i = 0; i < f.planecount; ++i) {
+            const DeviceTable& t = f.tables[f.table_of_plane(i)];
+            any |= f.simd_order == 0 && !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i) || wants_runs(t, i));
+        }
+        return any;
+    }
+    // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
+    // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
+    // ... but not for calls so small that the fork / join through events costs more than the border kernels in front of
+    // the interior (measured, one frame per call: C2 114 against 103 Gpix/s without the side stream, 4K->1080p 27 against
+    // 23; from ~1e9 taps per call the side stream wins: C2 at 4 frames 319 against 287, C3 at 1 frame 24 against 20).
+    // -1: this automatic rule, 1: always, 0: never.
+    bool wants_border_overlap() const {
+        if (f.overlap_border >= 0) return f.overlap_border != 0;
+        double taps = 0.0, border_taps = 0.0;
+        for (int i = 0; i < f.planecount; ++i) {
+            const DeviceTable& t = f.tables[f.table_of_plane(i)];
+            taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
+            if (wants_runs(t, i))
+                for (int r = 0; r < t.border_rects.n; ++r)
+                    border_taps += static_cast<double>(t.border_rects.w[r]) * t.border_rects.h[r] * t.plan.fs * t.plan.fs;
+        }
+        return taps * nframes >= Rules::kOverlapMinTaps || border_taps * nframes >= Rules::kOverlapMinBorderTaps;
+    }
+    // Small calls with chroma planes (no border fork): the planes behind the first go to the side stream, interior and border, so
+    // that luma and chroma run beside each other -- a single frame's planes fill the chip even less one by one.
+    // Measured, one frame per call (round3/plane_fork_ab.txt): 1080p -> 4K 4:2:0 44.1 -> 49.6 Gpix/s, 4K -> 1080p 4:2:0 16-bit 8.7 -> 9.9,
+    // DVD -> 1080p with tap 6 13.2 -> 15.6, four DVD frames with tap 3 57.7 -> 61.8; level where the first plane fills the chip
+    // alone (four 4K frames) and -2 % on 8K float RGB planes, hence the limit on the first plane's samples.
+    bool wants_plane_fork(bool border_fork) const {
+        const jinc::DevicePlan& first = f.tables[f.table_of_plane(0)].plan;
+        return !border_fork && f.planecount >= 2 && f.simd_order == 0 && plane_fork_enabled() &&
+               static_cast<double>(first.dst_w) * first.dst_h * nframes <= Rules::kPlaneForkMaxSamples;
+    }
+};
+}  // namespace
+
+namespace {
+// The launches of plane i: interior kernel on `plane_stream`, border kernels on `border_stream` (the same stream unless forked).
+void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
+                  void* const dst[4], const int dst_pitch[4], const size_t dst_fs[4], hipStream_t plane_stream, hipStream_t border_stream) {
+    const int sb = c.sb, nframes = c.nframes;
+    DeviceTable& t = f.tables[f.table_of_plane(i)];
+    jinc::PlaneIO io;
+    io.src = src[i];
+    io.dst = dst[i];
+    io.src_pitch = src_pitch[i];
+    io.dst_pitch = dst_pitch[i];
+    io.src_frame_stride = src_fs ? src_fs[i] : 0;
+    io.dst_frame_stride = dst_fs ? dst_fs[i] : 0;
+    io.nframes = nframes;
+    io.sample_bytes = sb;
+    io.peak = f.peak;
+    auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
+        EventPair ev;
+        if (f.profiling) {
+            hip_check(hipEventCreate(&ev.start), "hipEventCreate");
+            hip_check(hipEventCreate(&ev.stop), "hipEventCreate");
+            hip_check(hipEventRecord(ev.start, s), "hipEventRecord");
+        }
+        hip_check(static_cast<hipError_t>(launch(s)), what);
+        if (f.profiling) {
+            hip_check(hipEventRecord(ev.stop, s), "hipEventRecord");
+            sink.push_back(ev);
+        }
     };
+    if (f.simd_order != 0) {  // compatibility modes (private switch): whole plane on kernel_simdorder.hip
+        const float min_val = (i != 0 && !f.vi_in.is_rgb) ? -0.5f : 0.f;  // ref resize_plane_sse41.cpp:20
+        t.last_kernel = "ewa_simd_order_kernel";
+        timed(f.ev_gather, plane_stream, "SIMD-order kernel launch",
+              [&](hipStream_t s) { return jinc::launch_simd_order(t.plan, io, f.simd_order, min_val, s); });
+        return;
+    }
+    if (c.wants_framelane(t, i)) {
+        auto aligned_to = [&](uintptr_t bytes) {
+            return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
+                   (nframes <= 1 || io.dst_frame_stride % bytes == 0);
+        };
+        // bit 0: packed stores of 4 samples, bit 1: 16-byte stores (8-bit planes in the frame-pair form)
+        const int vec_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
+        // Whole groups of 128 frames go to the frame-pair form (two frames per lane: half the per-pixel coefficient
+        // traffic and scalar work, packed multiplies / adds; measured at 256 frames against the 64-frame form: 1.37x
+        // 55 against 42 % of the VALU peak, 1.5x 62 against 54 %, DVD -> 1080p 63 against 49 %, 15 / 8 61 against 52 %);
+        // what is left of the batch, and every batch below 128 frames, to the 64-frame form.  kernel_mode 12 (tests,
+        // A/B): the frame-pair form for the whole batch, 11: the 64-frame form for the whole batch.
+        int npair = 0;
+        if (t.use_framelane_pair && f.kernel_mode != 11)
+            npair = f.kernel_mode == 12 ? nframes : nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames;
+        if (npair > 0) {
+            jinc::FrameLaneArgs fa = t.fl_pair;
+            fa.io = io;
+            fa.io.nframes = npair;
+            fa.vec_store_ok = vec_ok;
+            t.last_kernel = "ewa_framelane_pair_kernel";
+            timed(f.ev_periodic, plane_stream, "frame-pair kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_pair(fa, s); });
+        }
+        if (npair < nframes) {
+            jinc::FrameLaneArgs fa = t.fl_whole;
+            fa.io = io;
+            fa.io.src = static_cast<const char*>(io.src) + static_cast<size_t>(npair) * io.src_frame_stride;
+            fa.io.dst = static_cast<char*>(io.dst) + static_cast<size_t>(npair) * io.dst_frame_stride;
+            fa.io.nframes = nframes - npair;
+            fa.vec_store_ok = vec_ok;
+            if (npair == 0)
+                t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
+                                : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
+                                    ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
+            timed(f.ev_periodic, plane_stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+        }
+        return;
+    }
+    // Border frame of a drifting plan (every border pixel owns a coefficient set): the gather kernel, or in batches the frame-lane
+    // kernel (lanes = frames make the private sets scalar loads).
+    auto drifting_border = [&]() {
+        if (t.use_fl_border && nframes >= runs_fl_border_min_frames() && t.border_rects.n > 0) {
+            auto aligned_to = [&](uintptr_t bytes) {
+                return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
+                       (nframes <= 1 || io.dst_frame_stride % bytes == 0);
+            };
+            jinc::FrameLaneArgs fa = t.fl_border;
+            fa.io = io;
+            fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
+            timed(f.ev_gather, border_stream, "border frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+        } else if (t.border_rects.n > 0) {
+            timed(f.ev_gather, border_stream, "border kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
+        }
+    };
+    if (c.wants_runs(t, i)) {
+        t.last_kernel = "ewa_direct_runs_kernel";
+        drifting_border();
+        timed(f.ev_periodic, plane_stream, "direct runs kernel launch", [&](hipStream_t s) {
+            jinc::DirectArgs da = t.runs;
+            da.src_bytes = direct_src_bytes(
+                src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+            return jinc::launch_direct_runs(da, io, s);
+        });
+        return;
+    }
+    const bool direct = c.wants_direct(t, i);
+    const bool quasi = !direct && c.wants_quasi(t);
+    const bool periodic = !direct && !quasi && c.wants_periodic(t);
+    t.last_kernel = direct     ? "ewa_direct_kernel"
+                    : quasi    ? "ewa_quasi_kernel"
+                    : periodic ? (c.quad_chosen(t) ? "ewa_periodic_quad_kernel"
+                                  : (f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
+                                  : (f.kernel_mode == 3 || (t.plan.fs != 7 && t.plan.fs != 9)) ? "ewa_periodic_rows_kernel"
+                                                                                                : "ewa_periodic_kernel")
+                               : "ewa_gather_kernel";
+    if (direct || periodic || quasi) {
+        // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
+        const bool strips = f.border_strips != 0 && t.strips_ok && c.direct_ok(t, i);
+        if (strips) {
+            jinc::DirectArgs rs = t.row_strips;
+            rs.src_bytes = direct_src_bytes(
+                src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+            const bool colstrip = t.use_colstrip && f.border_strips != 2;
+            // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
+            // last it would start when the interior kernel already holds every wave slot
+            if (colstrip && t.corner_rects.n > 0)
+                timed(f.ev_gather, border_stream, "corner kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
+            timed(f.ev_gather, border_stream, "border row kernel launch",
+                  [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
+            if (colstrip) {
+                timed(f.ev_gather, border_stream, "border column kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
+            } else if (t.column_rects.n > 0) {
+                timed(f.ev_gather, border_stream, "border column kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
+            }
+        } else {
+            drifting_border();  // (use_fl_border is set for drifting plans only: the others keep the gather kernel here)
+        }
+        if (direct)
+            timed(f.ev_periodic, plane_stream, "direct periodic kernel launch", [&](hipStream_t s) {
+                jinc::DirectArgs da = t.direct;
+                da.src_bytes = direct_src_bytes(
+                    src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
+                return jinc::launch_direct(da, io, s);
+            });
+        else if (quasi)
+            timed(f.ev_periodic, plane_stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
+                jinc::QuasiArgs qa = t.quasi;
+                if (f.kernel_mode == 8) qa.exact = 0;   // A/B: per-row lookup + waterfall over sets in SGPRs
+                if (f.kernel_mode == 10) qa.exact = 2;  // A/B: per-row lookup + per-lane coefficient registers
+                {   // Calls that do not fill the chip split a tile's phases over several workgroups (each stages the tile
+                    // again): one DVD -> 1080p frame is 72 + 2 x 20 workgroups of 18 phases per wave, 0.23 ms whether the
+                    // call holds one frame or four.  Aim: ~1024 workgroups per launch (fs 9, whose tiles cost more to
+                    // stage: ~400).  Measured, one frame per call: DVD -> 1080p 8.8 -> 21 Gpix/s, 3x 102 -> 156, 1.5x 49 -> 61,
+                    // 1.5x with tap 4 38 -> 45; equal from 4 .. 16 frames per call on.
+                    const int tile_rows = qa.rg * t.plan.fs;
+                    const long long wgs = static_cast<long long>((qa.ni + 63) / 64) * ((qa.nj + tile_rows - 1) / tile_rows) * nframes;
+                    const int per_wave = (qa.px * qa.py + qa.nwaves - 1) / std::max(1, qa.nwaves);
+                    const long long target = t.plan.fs == 9 ? Rules::kQuasiSplitTargetFs9 : Rules::kQuasiSplitTarget;
+                    int split = wgs > 0 ? static_cast<int>((target + wgs - 1) / wgs) : 1;
+                    qa.phase_split = std::max(1, std::min(split, per_wave));
+                    if (quasi_split_knob() >= 0) qa.phase_split = std::max(1, std::min(quasi_split_knob(), per_wave));
+                }
+                return jinc::launch_quasi(qa, t.plan.fs, io, s);
+            });
+        else
+            timed(f.ev_periodic, plane_stream, "periodic kernel launch", [&](hipStream_t s) {
+                int variant = (f.kernel_mode >= 3 && f.kernel_mode <= 6) ? f.kernel_mode - 2 : 0;
+                // quad form (2x up-scales whose phases share their window origin: a lane computes a period's 2 x 2 pixels from
+                // one window on packed multiplies / adds), chosen where it measured ahead (profiles/round3/quad_ab.log):
+                // fs 7 on calls that fill the chip (C2 at 16 / 1024 frames 544 -> 560 / 591 -> 606 Gpix/s, 16-bit 4:2:0 356 ->
+                // 365, float RGB 165 -> 175; a 4-frame call loses 5 %), fs 9 on calls that do not (C4, one frame per call: 80
+                // -> 94 Gpix/s; 4 / 16 frames: equal).  Kernel mode 13 forces it, 2 excludes it.
+                const bool quad = c.quad_chosen(t);
+                if (quad) variant = 5;
+                // Small calls (single frames, short batches) take the window kernels' half-height tiles: twice the
+                // workgroups for a launch that does not fill the chip (C2, one frame: 600 workgroups on 1536 slots,
+                // kernel 27.2 -> 22.3 us; 4 frames: 323 -> 354 Gpix/s); long batches keep the full tiles (+2 %).
+                if (f.kernel_mode == 0 && (t.plan.fs == 7 || t.plan.fs == 9)) {
+                    const int rows = t.plan.fs * (t.plan.fs == 7 ? 8 : 9);  // period-rows of a full tile
+                    const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + rows - 1) / rows) * nframes;
+                    if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
+                }
+                if (quad) {
+                    const long long quad_wgs = static_cast<long long>((t.periodic.ni + 63) / 64) *
+                                               ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
+                    if (quad_wgs < Rules::kHalfTileMaxWorkgroups) variant = 6;
+                }
+                return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);
+            });
+    } else {
+        timed(f.ev_gather, plane_stream, "gather kernel launch",
+              [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.whole, s); });
+    }
+}
+
+}  // namespace
+
+namespace {
+void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4], void* const dst[4],
+                 const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream, bool may_split) {
+    const Choice c(f, src_pitch, src_fs, nframes);
     // A batch of 128 k + r frames whose whole groups of 128 go to the frame-pair form: the r frames left over are a call of
     // their own, chosen by the same rules with their own frame count (as a 64-frame frame-lane launch a
     // remainder of 1..15 frames cost as much as 64 frames; 129 frames took ~1.5 x the time of 128).
@@ -210,7 +475,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
         bool pair_somewhere = false;
         for (int i = 0; i < f.planecount; ++i) {
             const DeviceTable& t = f.tables[f.table_of_plane(i)];
-            pair_somewhere |= t.use_framelane_pair && wants_framelane(t, i);
+            pair_somewhere |= t.use_framelane_pair && c.wants_framelane(t, i);
         }
         if (pair_somewhere) {
             const int whole = nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames;
@@ -225,243 +490,15 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
             return;
         }
     }
-    auto quad_chosen = [&](const DeviceTable& t) {
-        if (!t.periodic.quad) return false;
-        if (f.kernel_mode == 13) return true;
-        if (f.kernel_mode != 0) return false;
-        const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
-        // (fs 7: large planes only -- on 1280 x 720 the border kernels beside the denser interior become the step's tail:
-        // C1 at 256 frames 492 -> 465 Gpix/s)
-        const long long periods = static_cast<long long>(t.periodic.ni) * t.periodic.nj;
-        return t.plan.fs == 7 ? (wgs >= Rules::kHalfTileMaxWorkgroups && periods >= Rules::kQuadMinPeriods) : wgs < Rules::kQuad9MaxWorkgroups;
-    };
-    bool any_periodic = false;
-    for (int i = 0; i < f.planecount; ++i) {
-        const DeviceTable& t = f.tables[f.table_of_plane(i)];
-        any_periodic |= f.simd_order == 0 && !wants_framelane(t, i) && (wants_periodic(t) || wants_quasi(t) || wants_direct(t, i) || wants_runs(t, i));
-    }
-    // A/B on MI355X with the strip border kernels: overlapping wins 11 % on C3 (fs 17), 3 % on C4 (fs 9) and 2 % on
-    // C2 (fs 7) -- three small border launches per plane would otherwise sit serially in front of the interior.
-    // ... but not for calls so small that the fork / join through events costs more than the border kernels in front of
-    // the interior (measured, one frame per call: C2 114 against 103 Gpix/s without the side stream, 4K->1080p 27 against
-    // 23; from ~1e9 taps per call the side stream wins: C2 at 4 frames 319 against 287, C3 at 1 frame 24 against 20).
-    // -1: this automatic rule, 1: always, 0: never.
-    bool want_overlap = f.overlap_border != 0;
-    if (f.overlap_border < 0) {
-        double taps = 0.0, border_taps = 0.0;
-        for (int i = 0; i < f.planecount; ++i) {
-            const DeviceTable& t = f.tables[f.table_of_plane(i)];
-            taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
-            if (wants_runs(t, i))
-                for (int r = 0; r < t.border_rects.n; ++r)
-                    border_taps += static_cast<double>(t.border_rects.w[r]) * t.border_rects.h[r] * t.plan.fs * t.plan.fs;
-        }
-        want_overlap = taps * nframes >= Rules::kOverlapMinTaps || border_taps * nframes >= Rules::kOverlapMinBorderTaps;
-    }
-    const bool fork = any_periodic && want_overlap;
-    // Small calls with chroma planes (no border fork): the planes behind the first go to the side stream, interior and border, so
-    // that luma and chroma run beside each other -- a single frame's planes fill the chip even less one by one.
-    // Measured, one frame per call (round3/plane_fork_ab.txt): 1080p -> 4K 4:2:0 44.1 -> 49.6 Gpix/s, 4K -> 1080p 4:2:0 16-bit 8.7 -> 9.9,
-    // DVD -> 1080p with tap 6 13.2 -> 15.6, four DVD frames with tap 3 57.7 -> 61.8; level where the first plane fills the chip
-    // alone (four 4K frames) and -2 % on 8K float RGB planes, hence the limit on the first plane's samples.
-    const bool plane_fork = !fork && f.planecount >= 2 && f.simd_order == 0 && plane_fork_enabled() &&
-                            static_cast<double>(f.tables[f.table_of_plane(0)].plan.dst_w) * f.tables[f.table_of_plane(0)].plan.dst_h * nframes <=
-                                Rules::kPlaneForkMaxSamples;
+    const bool fork = c.any_border_frame() && c.wants_border_overlap();
+    const bool plane_fork = c.wants_plane_fork(fork);
     if (fork || plane_fork) {  // side-stream work may start once everything already queued on `stream` is done
         hip_check(hipEventRecord(f.ev_fork, stream), "hipEventRecord(fork)");
         hip_check(hipStreamWaitEvent(f.aux_stream, f.ev_fork, 0), "hipStreamWaitEvent(fork)");
     }
     for (int i = 0; i < f.planecount; ++i) {
         hipStream_t plane_stream = (plane_fork && i >= 1) ? f.aux_stream : stream;
-        hipStream_t border_stream = fork ? f.aux_stream : plane_stream;
-        DeviceTable& t = f.tables[f.table_of_plane(i)];
-        jinc::PlaneIO io;
-        io.src = src[i];
-        io.dst = dst[i];
-        io.src_pitch = src_pitch[i];
-        io.dst_pitch = dst_pitch[i];
-        io.src_frame_stride = src_fs ? src_fs[i] : 0;
-        io.dst_frame_stride = dst_fs ? dst_fs[i] : 0;
-        io.nframes = nframes;
-        io.sample_bytes = sb;
-        io.peak = f.peak;
-        auto timed = [&](std::vector<EventPair>& sink, hipStream_t s, const char* what, auto&& launch) {
-            EventPair ev;
-            if (f.profiling) {
-                hip_check(hipEventCreate(&ev.start), "hipEventCreate");
-                hip_check(hipEventCreate(&ev.stop), "hipEventCreate");
-                hip_check(hipEventRecord(ev.start, s), "hipEventRecord");
-            }
-            hip_check(static_cast<hipError_t>(launch(s)), what);
-            if (f.profiling) {
-                hip_check(hipEventRecord(ev.stop, s), "hipEventRecord");
-                sink.push_back(ev);
-            }
-        };
-        if (f.simd_order != 0) {  // compatibility modes (private switch): whole plane on kernel_simdorder.hip
-            const float min_val = (i != 0 && !f.vi_in.is_rgb) ? -0.5f : 0.f;  // ref resize_plane_sse41.cpp:20
-            t.last_kernel = "ewa_simd_order_kernel";
-            timed(f.ev_gather, plane_stream, "SIMD-order kernel launch",
-                  [&](hipStream_t s) { return jinc::launch_simd_order(t.plan, io, f.simd_order, min_val, s); });
-            continue;
-        }
-        if (wants_framelane(t, i)) {
-            auto aligned_to = [&](uintptr_t bytes) {
-                return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
-                       (nframes <= 1 || io.dst_frame_stride % bytes == 0);
-            };
-            // bit 0: packed stores of 4 samples, bit 1: 16-byte stores (8-bit planes in the frame-pair form)
-            const int vec_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
-            // Whole groups of 128 frames go to the frame-pair form (two frames per lane: half the per-pixel coefficient
-            // traffic and scalar work, packed multiplies / adds; measured at 256 frames against the 64-frame form: 1.37x
-            // 55 against 42 % of the VALU peak, 1.5x 62 against 54 %, DVD -> 1080p 63 against 49 %, 15 / 8 61 against 52 %);
-            // what is left of the batch, and every batch below 128 frames, to the 64-frame form.  kernel_mode 12 (tests,
-            // A/B): the frame-pair form for the whole batch, 11: the 64-frame form for the whole batch.
-            int npair = 0;
-            if (t.use_framelane_pair && f.kernel_mode != 11)
-                npair = f.kernel_mode == 12 ? nframes : nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames;
-            if (npair > 0) {
-                jinc::FrameLaneArgs fa = t.fl_pair;
-                fa.io = io;
-                fa.io.nframes = npair;
-                fa.vec_store_ok = vec_ok;
-                t.last_kernel = "ewa_framelane_pair_kernel";
-                timed(f.ev_periodic, plane_stream, "frame-pair kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_pair(fa, s); });
-            }
-            if (npair < nframes) {
-                jinc::FrameLaneArgs fa = t.fl_whole;
-                fa.io = io;
-                fa.io.src = static_cast<const char*>(io.src) + static_cast<size_t>(npair) * io.src_frame_stride;
-                fa.io.dst = static_cast<char*>(io.dst) + static_cast<size_t>(npair) * io.dst_frame_stride;
-                fa.io.nframes = nframes - npair;
-                fa.vec_store_ok = vec_ok;
-                if (npair == 0)
-                    t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
-                                    : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
-                                        ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
-                timed(f.ev_periodic, plane_stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
-            }
-            continue;
-        }
-        // Border frame of a drifting plan (every border pixel owns a coefficient set): the gather kernel, or in batches the frame-lane
-        // kernel (lanes = frames make the private sets scalar loads).
-        auto drifting_border = [&]() {
-            if (t.use_fl_border && nframes >= runs_fl_border_min_frames() && t.border_rects.n > 0) {
-                auto aligned_to = [&](uintptr_t bytes) {
-                    return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
-                           (nframes <= 1 || io.dst_frame_stride % bytes == 0);
-                };
-                jinc::FrameLaneArgs fa = t.fl_border;
-                fa.io = io;
-                fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
-                timed(f.ev_gather, border_stream, "border frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
-            } else if (t.border_rects.n > 0) {
-                timed(f.ev_gather, border_stream, "border kernel launch",
-                      [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
-            }
-        };
-        if (wants_runs(t, i)) {
-            t.last_kernel = "ewa_direct_runs_kernel";
-            drifting_border();
-            timed(f.ev_periodic, plane_stream, "direct runs kernel launch", [&](hipStream_t s) {
-                jinc::DirectArgs da = t.runs;
-                da.src_bytes = direct_src_bytes(
-                    src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
-                return jinc::launch_direct_runs(da, io, s);
-            });
-            continue;
-        }
-        const bool direct = wants_direct(t, i);
-        const bool quasi = !direct && wants_quasi(t);
-        const bool periodic = !direct && !quasi && wants_periodic(t);
-        t.last_kernel = direct     ? "ewa_direct_kernel"
-                        : quasi    ? "ewa_quasi_kernel"
-                        : periodic ? (quad_chosen(t) ? "ewa_periodic_quad_kernel"
-                                      : (f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
-                                      : (f.kernel_mode == 3 || (t.plan.fs != 7 && t.plan.fs != 9)) ? "ewa_periodic_rows_kernel"
-                                                                                                    : "ewa_periodic_kernel")
-                                   : "ewa_gather_kernel";
-        if (direct || periodic || quasi) {
-            // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
-            const bool strips = f.border_strips != 0 && t.strips_ok && direct_ok(t, i);
-            if (strips) {
-                jinc::DirectArgs rs = t.row_strips;
-                rs.src_bytes = direct_src_bytes(
-                    src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
-                const bool colstrip = t.use_colstrip && f.border_strips != 2;
-                // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
-                // last it would start when the interior kernel already holds every wave slot
-                if (colstrip && t.corner_rects.n > 0)
-                    timed(f.ev_gather, border_stream, "corner kernel launch",
-                          [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
-                timed(f.ev_gather, border_stream, "border row kernel launch",
-                      [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
-                if (colstrip) {
-                    timed(f.ev_gather, border_stream, "border column kernel launch",
-                          [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
-                } else if (t.column_rects.n > 0) {
-                    timed(f.ev_gather, border_stream, "border column kernel launch",
-                          [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
-                }
-            } else {
-                drifting_border();  // (use_fl_border is set for drifting plans only: the others keep the gather kernel here)
-            }
-            if (direct)
-                timed(f.ev_periodic, plane_stream, "direct periodic kernel launch", [&](hipStream_t s) {
-                    jinc::DirectArgs da = t.direct;
-                    da.src_bytes = direct_src_bytes(
-                        src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
-                    return jinc::launch_direct(da, io, s);
-                });
-            else if (quasi)
-                timed(f.ev_periodic, plane_stream, "quasi-periodic kernel launch", [&](hipStream_t s) {
-                    jinc::QuasiArgs qa = t.quasi;
-                    if (f.kernel_mode == 8) qa.exact = 0;   // A/B: per-row lookup + waterfall over sets in SGPRs
-                    if (f.kernel_mode == 10) qa.exact = 2;  // A/B: per-row lookup + per-lane coefficient registers
-                    {   // Calls that do not fill the chip split a tile's phases over several workgroups (each stages the tile
-                        // again): one DVD -> 1080p frame is 72 + 2 x 20 workgroups of 18 phases per wave, 0.23 ms whether the
-                        // call holds one frame or four.  Aim: ~1024 workgroups per launch (fs 9, whose tiles cost more to
-                        // stage: ~400).  Measured, one frame per call: DVD -> 1080p 8.8 -> 21 Gpix/s, 3x 102 -> 156, 1.5x 49 -> 61,
-                        // 1.5x with tap 4 38 -> 45; equal from 4 .. 16 frames per call on.
-                        const int tile_rows = qa.rg * t.plan.fs;
-                        const long long wgs = static_cast<long long>((qa.ni + 63) / 64) * ((qa.nj + tile_rows - 1) / tile_rows) * nframes;
-                        const int per_wave = (qa.px * qa.py + qa.nwaves - 1) / std::max(1, qa.nwaves);
-                        const long long target = t.plan.fs == 9 ? Rules::kQuasiSplitTargetFs9 : Rules::kQuasiSplitTarget;
-                        int split = wgs > 0 ? static_cast<int>((target + wgs - 1) / wgs) : 1;
-                        qa.phase_split = std::max(1, std::min(split, per_wave));
-                        if (quasi_split_knob() >= 0) qa.phase_split = std::max(1, std::min(quasi_split_knob(), per_wave));
-                    }
-                    return jinc::launch_quasi(qa, t.plan.fs, io, s);
-                });
-            else
-                timed(f.ev_periodic, plane_stream, "periodic kernel launch", [&](hipStream_t s) {
-                    int variant = (f.kernel_mode >= 3 && f.kernel_mode <= 6) ? f.kernel_mode - 2 : 0;
-                    // quad form (2x up-scales whose phases share their window origin: a lane computes a period's 2 x 2 pixels from
-                    // one window on packed multiplies / adds), chosen where it measured ahead (profiles/round3/quad_ab.log):
-                    // fs 7 on calls that fill the chip (C2 at 16 / 1024 frames 544 -> 560 / 591 -> 606 Gpix/s, 16-bit 4:2:0 356 ->
-                    // 365, float RGB 165 -> 175; a 4-frame call loses 5 %), fs 9 on calls that do not (C4, one frame per call: 80
-                    // -> 94 Gpix/s; 4 / 16 frames: equal).  Kernel mode 13 forces it, 2 excludes it.
-                    const bool quad = quad_chosen(t);
-                    if (quad) variant = 5;
-                    // Small calls (single frames, short batches) take the window kernels' half-height tiles: twice the
-                    // workgroups for a launch that does not fill the chip (C2, one frame: 600 workgroups on 1536 slots,
-                    // kernel 27.2 -> 22.3 us; 4 frames: 323 -> 354 Gpix/s); long batches keep the full tiles (+2 %).
-                    if (f.kernel_mode == 0 && (t.plan.fs == 7 || t.plan.fs == 9)) {
-                        const int rows = t.plan.fs * (t.plan.fs == 7 ? 8 : 9);  // period-rows of a full tile
-                        const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + rows - 1) / rows) * nframes;
-                        if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
-                    }
-                    if (quad) {
-                        const long long quad_wgs = static_cast<long long>((t.periodic.ni + 63) / 64) *
-                                                   ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
-                        if (quad_wgs < Rules::kHalfTileMaxWorkgroups) variant = 6;
-                    }
-                    return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);
-                });
-        } else {
-            timed(f.ev_gather, plane_stream, "gather kernel launch",
-                  [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.whole, s); });
-        }
+        launch_plane(f, c, i, src, src_pitch, src_fs, dst, dst_pitch, dst_fs, plane_stream, fork ? f.aux_stream : plane_stream);
     }
     if (fork || plane_fork) {  // `stream` continues only after the side stream's kernels have finished too
         hip_check(hipEventRecord(f.ev_join, f.aux_stream), "hipEventRecord(join)");
