@@ -499,7 +499,7 @@ class Filter:
         return lib().jinc_filter_last_kernel(self._h, int(table)).decode()
 
     def set_border_strips(self, mode) -> None:
-        """Border frame of exactly periodic plans: True/1 strip kernels (default), 2 rows only, False/0 gather kernel."""
+        """Border frame of exactly periodic plans: -1 by call size (default), True/1 strip kernels, 2 rows only, False/0 gather kernel."""
         self._check(lib().jinc_filter_set_border_strips(self._h, int(mode)))
 
     def set_border_overlap(self, enable) -> None:

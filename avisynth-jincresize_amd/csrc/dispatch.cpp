@@ -33,6 +33,8 @@ struct Rules {
     // (by batch size, frame-lane against gather border: 1.5x with tap 4 +6 % at 16 frames, +9 % at 32; with tap 8 -8 % at 16, level
     // at 32, +3 % at 48; 3x with tap 4 -2 % / +3 % / +5 %; DVD -> 1080p with tap 4 +1 % / +5.5 % / +10 %)
     static constexpr int kRunsFrameLaneBorderMinFrames = 32;
+    // calls of exactly periodic plans below this many taps: one gather launch over the border frame instead of the strip kernels
+    static constexpr double kStripBorderMinTaps = 5.0e9;
     // multi-plane calls whose first plane has at most this many output samples run their other planes on the side stream
     static constexpr double kPlaneForkMaxSamples = 1.0e7;
     // calls (per plane) below this many taps stay with the gather kernel
@@ -254,6 +256,20 @@ struct Choice {
         }
         return taps * nframes >= Rules::kOverlapMinTaps || border_taps * nframes >= Rules::kOverlapMinBorderTaps;
     }
+    // Border frame of exactly periodic plans: three strip launches per plane (corners, rows, columns) or ONE launch of the gather
+    // kernel over the frame's four rectangles.  The strips are the leaner kernels (C3 at 32 frames: +11 %), but below ~5e9 taps per
+    // call their launches cost more than they save (round3/border_strips_ab.txt, one frame per call: C2 122 -> 183 Gpix/s, C1 15.7 ->
+    // 25.4, 1080p -> 4K 4:2:0 49 -> 74, 4K -> 1080p 27.7 -> 45, C3 24 -> 31; four frames: C2 346 -> 412, C1 59 -> 93; level from 3e9 ..
+    // 7e9 taps on; tap 16 at 9e9 taps: -30 %).  f.border_strips: -1 this rule, 1 / 2 / 0 forced (tests, A/B).
+    bool wants_border_strips() const {
+        if (f.border_strips >= 0) return f.border_strips != 0;
+        double taps = 0.0;
+        for (int i = 0; i < f.planecount; ++i) {
+            const DeviceTable& t = f.tables[f.table_of_plane(i)];
+            taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
+        }
+        return taps * nframes >= Rules::kStripBorderMinTaps;
+    }
     // Small calls with chroma planes (no border fork): the planes behind the first go to the side stream, interior and border, so
     // that luma and chroma run beside each other -- a single frame's planes fill the chip even less one by one.
     // Measured, one frame per call (round3/plane_fork_ab.txt): 1080p -> 4K 4:2:0 44.1 -> 49.6 Gpix/s, 4K -> 1080p 4:2:0 16-bit 8.7 -> 9.9,
@@ -381,7 +397,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                                : "ewa_gather_kernel";
     if (direct || periodic || quasi) {
         // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
-        const bool strips = f.border_strips != 0 && t.strips_ok && c.direct_ok(t, i);
+        const bool strips = c.wants_border_strips() && t.strips_ok && c.direct_ok(t, i);
         if (strips) {
             jinc::DirectArgs rs = t.row_strips;
             rs.src_bytes = direct_src_bytes(

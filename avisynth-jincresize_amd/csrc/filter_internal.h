@@ -154,7 +154,7 @@ struct jinc_filter {
     jinc::JincLut lut;
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
-    int border_strips = 1;  // border rows/columns of exactly periodic plans on kernel_direct.hip (0: gather kernel)
+    int border_strips = -1;  // border frame of exactly periodic plans: -1 by call size (dispatch.cpp Rules), 1 strip kernels, 2 rows only, 0 gather kernel
     bool direct_premise = false;  // buffer_range_check_covers_soffset(device) == 1
     int simd_order = 0;  // 0: opt=0 results (default); 1 / 2 / 3: summation order of the reference's SSE4.1 / AVX2 / AVX-512 path
     int overlap_border = -1;  // -1: automatic (side stream unless the call is tiny: dispatch.cpp), 0: off, 1: on

@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--kernel-mode", type=int, default=0, help="0 auto, 1 force gather kernel")
     ap.add_argument("--simd-order", type=int, default=0, help="1 / 2 / 3: the compatibility kernel in the reference's SSE4.1 / AVX2 / AVX-512 summation order")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
+    ap.add_argument("--border-strips", type=int, default=-1, help="-1 default, 1 strip kernels, 2 row strips only, 0 gather kernel over the border frame")
     args = ap.parse_args()
     if args.config not in CONFIGS:
         ap.error(f"unknown --config {args.config}; choose from {', '.join(sorted(CONFIGS))}")
@@ -406,6 +407,8 @@ def main():
         flt.set_simd_order(args.simd_order)
     if args.border_overlap >= 0:
         flt.set_border_overlap(bool(args.border_overlap))
+    if args.border_strips >= 0:
+        flt.set_border_strips(args.border_strips)
     info = flt.plan_info(0)
     sb = fmt.sample_bytes
 

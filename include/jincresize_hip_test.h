@@ -86,9 +86,9 @@ JINC_API int jinc_debug_valu_pair_probe(int device, int waves_per_simd, double *
 /* Interior kernel (of table 0) and frame count of the most recent kernel call of ANY filter instance in this process:
  * for tests that drive the plugin shell and cannot reach its jinc_filter handles. */
 JINC_API const char *jinc_debug_last_call(int *nframes);
-/* Border frame of exactly periodic plans: 1 (default) = rows and columns on the strip kernels, corners on the
- * gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel; 0 = everything on the
- * gather kernel (A/B measurements, tests). */
+/* Border frame of exactly periodic plans: -1 (default) = by call size (strip kernels from ~5e9 taps per call on, one gather
+ * launch below); 1 = rows and columns on the strip kernels, corners on the gather kernel; 2 = rows on the strip kernel,
+ * columns and corners on the gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */
 JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
 /* 1: the border kernels run on a side stream concurrently with the interior kernel (fork/join by events around
  * every call); 0: all on the caller's stream, back to back; -1 (default): the side stream unless the call is so small
