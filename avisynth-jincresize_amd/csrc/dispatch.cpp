@@ -404,7 +404,9 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
             const bool colstrip = t.use_colstrip && f.border_strips != 2;
             // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
-            // last it would start when the interior kernel already holds every wave slot
+            // last it would start when the interior kernel already holds every wave slot.  (Measured again in round 3 with
+            // the corners last: no difference on any of eight configurations -- in a long batch the border kernels cost their
+            // stand-alone time whatever the order: C2 at 1024 frames 0.19 + 0.37 + 0.05 ms of 13.9; round3/corner_order_ab.txt)
             if (colstrip && t.corner_rects.n > 0)
                 timed(f.ev_gather, border_stream, "corner kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
