@@ -37,6 +37,10 @@ struct Rules {
     static constexpr double kStripBorderMinTaps = 5.0e9;
     // multi-plane calls whose first plane has at most this many output samples run their other planes on the side stream
     static constexpr double kPlaneForkMaxSamples = 1.0e7;
+    // filter sizes from which the runs form is the automatic choice at every call size; below (the quasi-periodic kernel's plans)
+    // only for calls of at most this many output samples
+    static constexpr int kRunsMinFilterSize = 9;
+    static constexpr double kRunsSmallFsMaxSamples = 4.0e7, kRunsSmallFsMaxSamplesManyPhases = 8.0e7;
     // calls (per plane) below this many taps stay with the gather kernel
     static constexpr double kRunsMinTaps = 1.0e8;
     // border kernels also move to the side stream when the border frame alone holds this many taps per call (drifting plans
@@ -180,6 +184,14 @@ struct Choice {
     // 244 -> 55 / 217 / 268; 3x: 35.6 / 146 -> 51.5 / 197).  kernel_mode 14: wherever the plan has runs.
     bool wants_runs(const DeviceTable& t, int i) const {
         if (!t.use_runs || !f.direct_premise || (f.kernel_mode != 0 && f.kernel_mode != 14)) return false;
+        if (f.kernel_mode == 0 && t.plan.fs < Rules::kRunsMinFilterSize) {
+            // fs 7 / 8 (the quasi-periodic kernel's plans): small and medium calls of plans with source steps >= 2 only --
+            // round3/runs_vs_auto.txt: 1.5x at 4 / 16 frames per call 148 -> 173 / 277 -> 283 Gpix/s, at 64 the frame-lane kernel
+            // is ahead (437 against 407); DVD -> 1080p (72 phases) at 1 / 4 / 16 frames 16.7 -> 19.5 / 62 -> 74 / 126 -> 141, at 64
+            // 274 against 194; 3x (source step 1) loses from 4 frames on (467 -> 350 at 16)
+            if (t.runs.sx < 2 || t.runs.sy < 2 || call_samples < Rules::kQuasiMinSamples) return false;
+            if (call_samples > (t.runs.px * t.runs.py > 16 ? Rules::kRunsSmallFsMaxSamplesManyPhases : Rules::kRunsSmallFsMaxSamples)) return false;
+        }
         // tiny calls: the gather kernel's single launch is over before border + interior launches of this form are
         // (640 x 360 -> 960 x 540 with tap 4, one frame, 42e6 taps: 21.5 against 15.6 Gpix/s; four frames: 48 against 54;
         // with tap 8, one frame, 150e6 taps: 7.4 against 8.8)

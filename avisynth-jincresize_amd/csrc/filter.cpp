@@ -352,7 +352,7 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
     const bool quasi = t.use_quasi && (m == 7 || m == 8 || m == 10 || (m != 1 && !t.use_periodic));
     const bool periodic = t.use_periodic && m != 1 && m != 7 && m != 8 && m != 10;
     if (t.use_direct && m != 1 && (m == 9 || (!periodic && !quasi))) return "ewa_direct_kernel";
-    if (t.use_runs && f->direct_premise && (m == 14 || m == 0)) return "ewa_direct_runs_kernel";
+    if (t.use_runs && f->direct_premise && (m == 14 || (m == 0 && t.plan.fs >= 9))) return "ewa_direct_runs_kernel";
     if (quasi) return "ewa_quasi_kernel";
     if (periodic) {
         const int fs = t.plan.fs;

@@ -41,7 +41,7 @@ int interior_shape(const DirectArgs& da, const PlaneIO& io) {
         forced = e && *e ? std::atoi(e) : -1;
         g_forced_shape.store(forced, std::memory_order_relaxed);
     }
-    if (!walk_supported(da.fs) || forced == 0) return 0;
+    if (da.fs < kWalkMinTapsPeriodic || !walk_supported(da.fs) || forced == 0) return 0;
     if (!walk_wide_supported(da.fs, da.sx)) return 2;
     if (forced == 2 || forced == 3) return forced;
     const long long waves8 = (static_cast<long long>((da.ni + 7) / 8) * ((da.nj + 3) / 4) + 63) / 64 * da.px * da.py * io.nframes;

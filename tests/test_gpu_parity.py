@@ -246,6 +246,13 @@ def test_full_size_frames_of_the_other_kernels_match_the_oracle(gpu_pkg, O, case
     assert f.interior_kernel(0) == kernel
     got = f.get_frame(src)
     assert_planes_equal(got, want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th}")
+    if kernel == "ewa_quasi_kernel":
+        # one frame of this size goes to the runs form of the direct kernel by itself (fs 7, source step 2, small call:
+        # csrc/dispatch.cpp Rules); the quasi-periodic kernel, which larger calls take, is forced here
+        assert f.last_kernel(0) == "ewa_direct_runs_kernel"
+        f.set_kernel_mode(10)
+        assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=f"{fmt} {sw}x{sh}->{tw}x{th} quasi-periodic kernel")
+        assert f.last_kernel(0) == "ewa_quasi_kernel"
     f.close()
 
 
