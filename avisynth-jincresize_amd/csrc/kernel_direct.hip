@@ -41,9 +41,10 @@ int interior_shape(const DirectArgs& da, const PlaneIO& io) {
         forced = e && *e ? std::atoi(e) : -1;
         g_forced_shape.store(forced, std::memory_order_relaxed);
     }
-    if (da.fs < kWalkMinTapsPeriodic || !walk_supported(da.fs) || forced == 0) return 0;
+    if (!walk_supported(da.fs) || forced == 0) return 0;
+    if (forced == 2 || (forced == 3 && walk_wide_supported(da.fs, da.sx))) return forced;
+    if (da.fs < kWalkMinTapsPeriodic) return 0;
     if (!walk_wide_supported(da.fs, da.sx)) return 2;
-    if (forced == 2 || forced == 3) return forced;
     const long long waves8 = (static_cast<long long>((da.ni + 7) / 8) * ((da.nj + 3) / 4) + 63) / 64 * da.px * da.py * io.nframes;
     // 8-bit only: 16-bit and float planes hold too many raw words per lane at 8 columns (measured 4K -> 1080p:
     // 8-bit 146 against 138 Gpix/s, 16-bit 71 against 73, float 31 against 35)

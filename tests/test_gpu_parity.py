@@ -415,6 +415,8 @@ WALK_CASES = [
     ("Y8", 150, 110, 300, 220, dict(tap=9)),              # 2x tap 9: fs 19 = 10 + 9, source step 1
     ("Y32", 150, 110, 300, 220, dict(tap=11)),            # fs 23 = 12 + 11
     ("YUV420P8", 516, 292, 258, 146, {}),                 # luma and chroma tables
+    ("Y8", 303, 213, 202, 142, dict(tap=2)),              # 2/3 with tap 2: fs 7 -- the ladders' lowest rungs (forced shape only)
+    ("Y16", 363, 273, 484, 364, {}),                      # 4/3x: fs 7 at source step 3
 ]
 
 
