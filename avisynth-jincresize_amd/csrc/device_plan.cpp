@@ -493,8 +493,10 @@ void init_device(jinc_filter& f, int device) {
         hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
         hip_check(hipStreamCreateWithPriority(&f.aux_stream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
     }
-    hip_check(hipEventCreateWithFlags(&f.ev_fork, hipEventDisableTiming), "hipEventCreate");
-    hip_check(hipEventCreateWithFlags(&f.ev_join, hipEventDisableTiming), "hipEventCreate");
+    for (int k = 0; k < jinc_filter::kForkEvents; ++k) {
+        hip_check(hipEventCreateWithFlags(&f.ev_fork[k], hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&f.ev_join[k], hipEventDisableTiming), "hipEventCreate");
+    }
     {   // a probe that could not run (-1) is a broken device, not "the premise does not hold": the latter silently moves every
         // exactly periodic down-scale and tap > 8 plan to the gather kernel at a fraction of the rate
         const int probe = buffer_range_check_covers_soffset(device);

@@ -98,8 +98,10 @@ struct GroupFrame {
 };
 
 struct FrameGroup {
-    void* src[4] = {nullptr, nullptr, nullptr, nullptr};  // device planes of `capacity` frames, frame stride *_fs
-    void* dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    void* src[4] = {nullptr, nullptr, nullptr, nullptr};  // device planes of `capacity` frames, frame stride *_fs: parts, in plane
+    void* dst[4] = {nullptr, nullptr, nullptr, nullptr};  // order, of ONE allocation each (src_base / dst_base) -- the chroma planes of
+    void* src_base = nullptr;                             // a single-frame group then lie at the same kind of distance in source and
+    void* dst_base = nullptr;                             // destination, which lets them go out as one launch (dispatch.cpp plane_pair)
     int src_pitch[4] = {0, 0, 0, 0};
     int dst_pitch[4] = {0, 0, 0, 0};
     size_t src_fs[4] = {0, 0, 0, 0};
@@ -178,7 +180,11 @@ struct jinc_filter {
     // The border gather kernel (load/store-issue bound) runs on a side stream next to the periodic
     // interior kernel (VALU bound): fork/join with two reusable events.
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // (a ring of event pairs, one pair per call in turn: a call never re-records an event that a stream of an earlier call --
+    // the look-ahead pipeline's groups have streams of their own -- may still be waiting on)
+    static constexpr int kForkEvents = 16;
+    hipEvent_t ev_fork[kForkEvents] = {}, ev_join[kForkEvents] = {};
+    unsigned fork_turn = 0;
 
     ~jinc_filter() {
         if (device >= 0) {
@@ -195,8 +201,10 @@ struct jinc_filter {
                     (void)hipEventDestroy(e.start);
                     (void)hipEventDestroy(e.stop);
                 }
-            if (ev_fork) (void)hipEventDestroy(ev_fork);
-            if (ev_join) (void)hipEventDestroy(ev_join);
+            for (hipEvent_t e : ev_fork)
+                if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : ev_join)
+                if (e) (void)hipEventDestroy(e);
             if (aux_stream) (void)hipStreamDestroy(aux_stream);
             if (stream) (void)hipStreamDestroy(stream);
         }

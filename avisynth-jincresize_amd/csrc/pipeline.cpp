@@ -27,11 +27,10 @@ namespace host {
 namespace {
 
 void release_group(FrameGroup& g) {  // (the belts are idle: callers drain first)
-    for (int i = 0; i < 4; ++i) {
-        if (g.src[i]) (void)hipFree(g.src[i]);
-        if (g.dst[i]) (void)hipFree(g.dst[i]);
-        g.src[i] = g.dst[i] = nullptr;
-    }
+    if (g.src_base) (void)hipFree(g.src_base);
+    if (g.dst_base) (void)hipFree(g.dst_base);
+    g.src_base = g.dst_base = nullptr;
+    for (int i = 0; i < 4; ++i) g.src[i] = g.dst[i] = nullptr;
     for (hipEvent_t e : g.done) (void)hipEventDestroy(e);
     g.done.clear();
     if (g.table) (void)hipHostFree(g.table);
@@ -80,8 +79,17 @@ void ensure_group(jinc_filter& f, FrameGroup& g) {
             g.dst_pitch[i] = static_cast<int>(align_up(static_cast<size_t>(dw) * sb, 256));
             g.src_fs[i] = align_up(static_cast<size_t>(g.src_pitch[i]) * sh, 256);
             g.dst_fs[i] = align_up(static_cast<size_t>(g.dst_pitch[i]) * dh, 256);
-            hip_check(hipMalloc(&g.src[i], g.src_fs[i] * cap), "hipMalloc(src planes of a frame group)");
-            hip_check(hipMalloc(&g.dst[i], g.dst_fs[i] * cap), "hipMalloc(dst planes of a frame group)");
+        }
+        size_t src_total = 0, dst_total = 0;
+        for (int i = 0; i < f.planecount; ++i) src_total += g.src_fs[i] * cap, dst_total += g.dst_fs[i] * cap;
+        hip_check(hipMalloc(&g.src_base, src_total), "hipMalloc(src planes of a frame group)");
+        hip_check(hipMalloc(&g.dst_base, dst_total), "hipMalloc(dst planes of a frame group)");
+        size_t so = 0, dof = 0;
+        for (int i = 0; i < f.planecount; ++i) {
+            g.src[i] = static_cast<char*>(g.src_base) + so;
+            g.dst[i] = static_cast<char*>(g.dst_base) + dof;
+            so += g.src_fs[i] * cap;
+            dof += g.dst_fs[i] * cap;
         }
         if (use_belts(f)) {
             hip_check(hipEventCreateWithFlags(&g.h2d_ready, hipEventDisableTiming), "hipEventCreate");
