@@ -77,7 +77,7 @@ ARG_BITS = {"src_left": 1 << 0, "src_top": 1 << 1, "src_width": 1 << 2, "src_hei
             "initial_capacity": 1 << 11, "initial_factor": 1 << 12}
 
 EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_filter_create", "jinc_filter_free", "jinc_filter_output_info",
-           "jinc_filter_chroma_location", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
+           "jinc_filter_chroma_location", "jinc_filter_set_chroma_location_mode", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_runs", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_filter_set_pipeline",
@@ -107,6 +107,7 @@ def lib():
         L.jinc_filter_free.argtypes = [C.c_void_p]
         L.jinc_filter_output_info.argtypes = [C.c_void_p, C.POINTER(VideoInfo)]
         L.jinc_filter_chroma_location.argtypes = [C.c_void_p]
+        L.jinc_filter_set_chroma_location_mode.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_get_frame.argtypes = [C.c_void_p, _P4, _I4, _P4, _I4]
         L.jinc_filter_process_device.argtypes = [C.c_void_p, _P4, _I4, _S4, _P4, _I4, _S4, C.c_int, C.c_void_p]
         L.jinc_filter_sync.argtypes = [C.c_void_p]
@@ -421,7 +422,13 @@ class Filter:
 
     @property
     def chroma_location(self) -> int:
+        """What GetFrame writes to _ChromaLocation: 2 for every sub-sampled format (the reference binary's behaviour, ref
+        :617-625 with d->cplace never assigned), -1 = not written; 0 / 1 / 2 by siting after set_chroma_location_mode(1)."""
         return int(lib().jinc_filter_chroma_location(self._h))
+
+    def set_chroma_location_mode(self, mode: int) -> None:
+        """0: as the reference binary (default); 1: by the siting in use (private switch, a deliberate deviation)."""
+        self._check(lib().jinc_filter_set_chroma_location_mode(self._h, int(mode)))
 
     def out_dims(self) -> List[Tuple[int, int]]:
         return self.fmt.plane_dims(self.dst_w, self.dst_h)

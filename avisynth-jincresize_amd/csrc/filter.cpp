@@ -99,7 +99,17 @@ int jinc_filter_output_info(const jinc_filter* f, jinc_video_info* out_vi) {
     return JINC_OK;
 }
 
-int jinc_filter_chroma_location(const jinc_filter* f) { return f ? f->chroma_location : -1; }
+int jinc_filter_chroma_location(const jinc_filter* f) {
+    if (!f) return -1;
+    return f->chroma_location_mode == JINC_CHROMA_LOCATION_BY_SITING ? f->chroma_location_by_siting : f->chroma_location;
+}
+
+int jinc_filter_set_chroma_location_mode(jinc_filter* f, int mode) {
+    if (!f || (mode != JINC_CHROMA_LOCATION_AS_REFERENCE && mode != JINC_CHROMA_LOCATION_BY_SITING))
+        return fail(JINC_ERR_INVALID_ARG, "JincResize: chroma location mode must be 0 or 1.");
+    f->chroma_location_mode = mode;
+    return JINC_OK;
+}
 
 int jinc_filter_get_frame(jinc_filter* f, const void* const src[4], const int src_pitch[4], void* const dst[4],
                           const int dst_pitch[4]) {

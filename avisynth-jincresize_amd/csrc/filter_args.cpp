@@ -38,7 +38,7 @@ void configure(jinc_filter& f, const jinc_video_info& vi, const jinc_args& a) {
         if (cplace != "mpeg2" && cplace != "mpeg1" && cplace != "topleft")
             throw ArgError("JincResize: cplace must be MPEG2, MPEG1 or topleft.");
     } else {
-        if (a.frame0_chroma_location >= 0) {  // the property exists and is an integer (ref :730)
+        if (a.frame0_chroma_location != -1) {  // the property exists and is an integer (ref :730)
             switch (a.frame0_chroma_location) {
                 case 0: cplace = "mpeg2"; break;
                 case 1: cplace = "mpeg1"; break;
@@ -134,11 +134,18 @@ void configure(jinc_filter& f, const jinc_video_info& vi, const jinc_args& a) {
         f.plans.push_back(jinc::build_plane_plan(f.lut, gc));
     }
 
-    // ref :617-625
-    if (is_420 || is_yuv_subsampled(vi, 1, 0) || is_yuv_subsampled(vi, 2, 0))
-        f.chroma_location = cplace == "mpeg2" ? 0 : (cplace == "mpeg1" ? 1 : 2);
-    else
+    // ref :617-625.  The reference compares `d->cplace`, a member that nothing ever assigns (`new JincResize()` :676
+    // leaves it empty; the string the arguments and frame 0 decide is the LOCAL `cplace` of :715, which drives the
+    // chroma geometry above and nothing else), so its GetFrame always takes the `else` of :623-624 and writes 2.
+    // chroma_location is what the reference binary writes; chroma_location_by_siting is what its source means to
+    // write, kept behind jinc_filter_set_chroma_location_mode.
+    if (is_420 || is_yuv_subsampled(vi, 1, 0) || is_yuv_subsampled(vi, 2, 0)) {
+        f.chroma_location = 2;
+        f.chroma_location_by_siting = cplace == "mpeg2" ? 0 : (cplace == "mpeg1" ? 1 : 2);
+    } else {
         f.chroma_location = -1;
+        f.chroma_location_by_siting = -1;
+    }
 }
 
 }  // namespace host

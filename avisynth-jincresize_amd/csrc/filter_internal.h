@@ -149,7 +149,9 @@ struct jinc_filter {
     jinc_video_info vi_in{};
     jinc_video_info vi_out{};
     std::string cplace;
-    int chroma_location = -1;
+    int chroma_location = -1;            // what the reference binary writes: 2 for sub-sampled chroma, else -1 (ref :617-625)
+    int chroma_location_by_siting = -1;  // 0 / 1 / 2 by cplace: what the reference's source means to write
+    int chroma_location_mode = 0;        // jinc_filter_set_chroma_location_mode
     float peak = 0.f;
     int planecount = 0;
     bool subsampled = false;

@@ -10,6 +10,15 @@ collective -- the only communication is the barrier and the MAX over ranks of th
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frames B] [--config C2|C3|C4]
 
+How N > 1 starts (frames shard, nothing is exchanged, so any of these is the same measurement):
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, the driver's form):
+    one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment, barrier and MAX / SUM over RCCL;
+  * started plainly (`python bench.py --gpus N`, no WORLD_SIZE): this process touches no GPU and starts N rank
+    processes itself (one per device, fresh interpreters), which meet over a torch TCPStore on 127.0.0.1 -- no RCCL,
+    the north_star's "independent per-device streams"; `--sync rccl` makes the children use RCCL instead;
+  * `--inproc`: ONE process, one filter instance + one HIP stream per device, steps issued to all devices from one
+    host thread.
+
 Rank 0 prints ONE JSON line (see the task contract): value = Mpix/s over all ranks, plus
   "roofline"     -- dominant (periodic-interior) kernel: algorithmic HBM bytes / its mean launch
                     duration measured with hipEvents on the launch stream, vs the 8 TB/s peak;
@@ -107,6 +116,186 @@ def aggregate(elapsed_s: float, units: float, dist=None):
     return float(t.item()), float(u.item())
 
 
+class NoSync:
+    """One rank: nothing to meet."""
+    name = "none"
+
+    def barrier(self):
+        pass
+
+    def reduce(self, elapsed_s, units):
+        return elapsed_s, units, [units]
+
+    def close(self):
+        pass
+
+
+class DistSync(NoSync):
+    """torch.distributed over RCCL (backend "nccl"): what a launcher-started run uses."""
+    name = "rccl"
+
+    def __init__(self, dist, rank, world, local_rank, backend="nccl"):
+        self.dist, self.rank, self.world, self.local_rank, self.backend = dist, rank, world, local_rank, backend
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def barrier(self):
+        if self.backend == "nccl":
+            self.dist.barrier(device_ids=[self.local_rank])
+        else:
+            self.dist.barrier()
+
+    def reduce(self, elapsed_s, units):
+        import torch
+        t, u = aggregate(elapsed_s, units, self.dist)
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        mine = torch.tensor([units], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(every, mine)
+        return t, u, [float(x.item()) for x in every]
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+class StoreSync(NoSync):
+    """Ranks that share nothing but a key-value store on 127.0.0.1 (torch's TCPStore, rank 0 serves): the barrier is a
+    counter every rank adds to and then waits on; MAX / SUM are rank 0 reading every rank's figures.  No RCCL, no GPU
+    memory, no collective: frames are independent units and the ranks only agree on when the clock runs."""
+    name = "store"
+
+    def __init__(self, rank, world, host=None, port=None, timeout_s=600.0):
+        from datetime import timedelta
+        from torch.distributed import TCPStore
+        self.rank, self.world, self.round = rank, world, 0
+        host = host or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port = int(port or os.environ.get("MASTER_PORT", "29500"))
+        # under torch.distributed.run the launcher's agent already serves a store on MASTER_PORT; every rank is then a client
+        serve = rank == 0 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") != "True"
+        self.store = TCPStore(host, port, world, is_master=serve, timeout=timedelta(seconds=timeout_s), wait_for_workers=True)
+
+    def barrier(self):
+        self.round += 1
+        key = f"barrier/{self.round}"
+        if self.store.add(key, 1) == self.world:
+            self.store.set(key + "/open", b"1")
+        self.store.wait([key + "/open"])   # blocks inside the store client, no polling
+
+    def reduce(self, elapsed_s, units):
+        self.store.set(f"result/{self.rank}", json.dumps([elapsed_s, units]))
+        self.barrier()
+        every = [json.loads(self.store.get(f"result/{r}")) for r in range(self.world)]
+        self.barrier()   # nobody leaves (and rank 0 does not close the store) before every rank has read
+        return max(e for e, _ in every), sum(u for _, u in every), [u for _, u in every]
+
+    def close(self):
+        self.store = None
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv, sync="store", worker=None, timeout_s=1800.0):
+    """`python bench.py --gpus N` started plainly: N rank processes, one per device, started from THIS process, which never
+    touches a GPU (fresh interpreters: no exec of, and no fork from, a process that has initialised HIP).  Rank k gets
+    RANK = LOCAL_RANK = k, WORLD_SIZE = n, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT -- what torch.distributed.run
+    would set -- plus JINC_BENCH_SYNC, the way the ranks meet.  Rank 0's stdout (the ONE JSON line) and every rank's stderr
+    pass through; the first rank to fail ends the others.  Returns the exit code for the parent.
+    `worker`: the command each rank runs (tests drive this logic on the CPU with a stub)."""
+    import subprocess
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    port = free_port()
+    procs = []
+    for k in range(n):
+        env = dict(os.environ, RANK=str(k), LOCAL_RANK=str(k), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), JINC_BENCH_SYNC=sync, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if k == 0 else subprocess.DEVNULL))
+    deadline, rc = time.time() + timeout_s, 0
+    live = set(range(n))
+    while live:
+        for k in sorted(live):
+            r = procs[k].poll()
+            if r is not None:
+                live.discard(k)
+                if r != 0 and rc == 0:
+                    rc = r
+                    print(f"bench.py: rank {k} exited with code {r}; stopping the other ranks", file=sys.stderr)
+        if live and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"bench.py: ranks {sorted(live)} still running after {timeout_s:.0f} s; stopping them", file=sys.stderr)
+            for k in live:
+                procs[k].terminate()   # the exact processes started above, nothing by pattern
+            for k in list(live):
+                try:
+                    procs[k].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[k].kill()
+                    procs[k].wait()
+                live.discard(k)
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def under_profiler():
+    """rocprofv3 preloads its tool library into the benchmark: the clock-sampler pass, the instruction-pair probe, the
+    host-to-host record and the CPU baseline would all land in the profile, so they are skipped there."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprofiler" in pre or "rocprof" in pre or any(k.startswith(("ROCPROF_", "ROCPROFILER_", "ROCP_")) for k in os.environ)
+
+
+def cpu_quota():
+    """What limits this process's CPU time besides the affinity mask: the cgroup's CFS quota (cpu.max on cgroup v2,
+    cpu.cfs_quota_us / cpu.cfs_period_us on v1, looked up from this process's cgroup towards the root) and the cpuset.
+    Returns {"quota_cores": float | None, "source": ..., "cpuset_cpus": ... | None}."""
+    def read(path):
+        try:
+            return open(path, encoding="utf-8").read().strip()
+        except OSError:
+            return None
+
+    def parents(rel):
+        rel = rel.strip("/")
+        parts = rel.split("/") if rel else []
+        for k in range(len(parts), -1, -1):
+            yield "/".join(parts[:k])
+
+    groups = {}
+    for line in (read("/proc/self/cgroup") or "").splitlines():
+        f = line.split(":", 2)
+        if len(f) == 3:
+            for ctl in (f[1].split(",") if f[1] else [""]):
+                groups[ctl] = f[2]
+    best, source, cpuset = None, None, None
+    for rel in parents(groups.get("", "")):            # v2
+        base = os.path.join("/sys/fs/cgroup", rel)
+        v = read(os.path.join(base, "cpu.max"))
+        if v and v.split()[0] != "max":
+            q = float(v.split()[0]) / float(v.split()[1])
+            if best is None or q < best:
+                best, source = q, os.path.join(base, "cpu.max") + f" = {v}"
+        cpuset = cpuset or read(os.path.join(base, "cpuset.cpus.effective"))
+    for ctl in ("cpu", "cpu,cpuacct"):                 # v1
+        for rel in parents(groups.get("cpu", groups.get("cpuacct", ""))):
+            base = os.path.join("/sys/fs/cgroup", ctl, rel)
+            q, per = read(os.path.join(base, "cpu.cfs_quota_us")), read(os.path.join(base, "cpu.cfs_period_us"))
+            if q and per and int(q) > 0:
+                c = int(q) / int(per)
+                if best is None or c < best:
+                    best, source = c, os.path.join(base, "cpu.cfs_quota_us") + f" = {q} / {per}"
+    for rel in parents(groups.get("cpuset", "")):
+        cpuset = cpuset or read(os.path.join("/sys/fs/cgroup/cpuset", rel, "cpuset.effective_cpus")) \
+            or read(os.path.join("/sys/fs/cgroup/cpuset", rel, "cpuset.cpus"))
+    return {"quota_cores": round(best, 2) if best is not None else None, "source": source or "no CFS quota found in this process's cgroup path",
+            "cpuset_cpus": cpuset}
+
+
 def algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh):
     """every source sample read once + every output sample written once."""
     b = 0
@@ -154,7 +343,12 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
                 return dw * dh * n / el / 1e6, n, el
 
     run(1, 0.0)  # touch tables once
-    cands = sorted({t for t in (8, 16, 32, 64, 128, avail) if t <= avail} or {avail})
+    quota = cpu_quota()
+    q = quota["quota_cores"]
+    qn = max(1, int(round(q))) if q else None
+    # counts to try: the usual powers of two up to the affinity mask and, where the cgroup states a CFS quota, the points
+    # around it (half, the quota, twice) -- the knee of the scan belongs to the quota, not to the mask
+    cands = sorted({t for t in ((8, 16, 32, 64, 128, avail) + ((max(1, qn // 2), qn, 2 * qn) if qn else ())) if 1 <= t <= avail} or {avail})
     # the fast CPU path: own AVX2 + FMA code in the summation order of the reference's opt=2 path (oracle/simd_avx2.c; the
     # reference itself cannot be built on this box).  Not bit-equal to opt=0 -- the GPU result is; it is the CPU SPEED baseline.
     have_avx2 = bool(O.lib().oracle_avx2_available())
@@ -180,7 +374,7 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
             else "oracle (opt=0 port)")
     # SURVEY 8(d)'s method next to it: whole frames in parallel, one single-thread instance per worker (how the reference is
     # deployed: Prefetch(P), MT_MULTI_INSTANCE).  `value` = the better of the two methods, named in `method`.
-    fp_counts = sorted({p for p in (16, 64, 128, avail) if p <= avail} or {avail})
+    fp_counts = sorted({p for p in ((max(1, qn // 2), qn, 2 * qn, min(avail, 4 * qn)) if qn else (16, 64, 128, avail)) if 1 <= p <= avail} or {avail})
     fp = cpu_frame_parallel(cfg_name, fp_counts)
     fp_key = "avx2_order_Mpix_s" if have_avx2 else "opt0_port_Mpix_s"
     fp_best = max(fp[fp_key], key=lambda k: fp[fp_key][k])
@@ -189,13 +383,22 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     if fp[fp_key][fp_best] > v:
         v, best = fp[fp_key][fp_best], int(fp_best)
         method = "whole frames in parallel, one single-thread filter instance per worker (MT_MULTI_INSTANCE)"
+    # why more workers than `cores` do not help, from this run's own figures: CPU seconds the process was GIVEN per second
+    # of wall time at each P (all threads; time.process_time()).  Where that stops growing with P the lease's CPU time --
+    # a CFS quota, or neighbours on the same cores -- is the limit, whatever the affinity mask says.
+    given = fp["cpu_s_per_wall_s"].get(fp_key, {})
+    most = max(given.values()) if given else None
+    knee = (f"the process received at most {most:.1f} CPU-seconds per second ({given}) although {avail} CPUs are in its affinity mask"
+            + (f"; cgroup quota {q} cores ({quota['source']})" if q else "; no CFS quota is visible from inside this cgroup")) if most else None
     return {"value": round(v, 2), "unit": "Mpix/s", "cores": best, "kind": "port", "method": method,
-            "sample": f"{path}; best of two methods on a host with {avail} usable cores ({cpu_model()}): (a) frame-parallel, "
+            "cpu_quota_cores": q, "cpu_quota_source": quota["source"], "cpuset_cpus": quota["cpuset_cpus"],
+            "cpu_seconds_per_wall_second_at_most": round(most, 1) if most else None, "knee": knee,
+            "sample": f"{path}; best of two methods on a host with {avail} CPUs in the affinity mask ({cpu_model()}): (a) frame-parallel, "
                       f"P single-thread instances for P in {fp_counts}, {fp['seconds_per_point']:.0f}s each; (b) {n} frames of {cfg_name} "
                       f"in {el:.1f}s with rows over {row_cores} OpenMP threads, the fastest of {cands} at {scan_s:.0f}s each",
             "path": "avx2_order" if have_avx2 else "opt0_port",
             "frame_parallel": fp, "row_parallel_value": round(row_value, 2), "row_parallel_cores": row_cores,
-            "cpu_model": cpu_model(), "host_cores": avail,
+            "cpu_model": cpu_model(), "affinity_cpus": avail,
             "single_core_value": round(v1, 2), "single_core_sample": f"{n1} frames in {el1:.1f}s",
             "runs_at_chosen_count_Mpix_s": [round(x, 1) for x in vals],
             "opt0_port_value": round(o_best, 2), "opt0_port_single_core_value": round(o1, 2),
@@ -244,19 +447,24 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
 
         ts = [threading.Thread(target=work, args=(k,)) for k in range(p)]
         [t.start() for t in ts]
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         go.set()
         time.sleep(seconds)
         stop.set()
         [t.join() for t in ts]   # frames in progress are finished and counted: elapsed includes them
-        el = time.perf_counter() - t0
-        return sum(done) * dw * dh / el / 1e6
+        el, cpu = time.perf_counter() - t0, time.process_time() - c0
+        return sum(done) * dw * dh / el / 1e6, cpu / el
 
-    out = {"instances_built_in_s": round(t_build, 2), "seconds_per_point": seconds, "avx2_order_Mpix_s": {}, "opt0_port_Mpix_s": {}}
+    out = {"instances_built_in_s": round(t_build, 2), "seconds_per_point": seconds, "avx2_order_Mpix_s": {}, "opt0_port_Mpix_s": {},
+           # CPU seconds (all threads of this process) per second of wall time while P workers ran: the cores it really got
+           "cpu_s_per_wall_s": {"avx2_order_Mpix_s": {}, "opt0_port_Mpix_s": {}}}
     for p in counts:
-        if have_avx2:
-            out["avx2_order_Mpix_s"][str(p)] = round(run(p, True), 1)
-        out["opt0_port_Mpix_s"][str(p)] = round(run(p, False), 1)
+        for key, avx2 in (("avx2_order_Mpix_s", True), ("opt0_port_Mpix_s", False)):
+            if avx2 and not have_avx2:
+                continue
+            rate, cores = run(p, avx2)
+            out[key][str(p)] = round(rate, 1)
+            out["cpu_s_per_wall_s"][key][str(p)] = round(cores, 1)
     return out
 
 
@@ -355,13 +563,17 @@ def make_workload(pkg, torch, config, frames, device, seed):
     return flt, step, stream, fmt, ddims
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default per config)")
     ap.add_argument("--config", default="C2", help="one of CONFIGS (scripts may add entries before calling main())")
+    ap.add_argument("--sync", choices=("auto", "rccl", "store"), default="auto",
+                    help="how ranks meet for the barrier and the MAX / SUM: rccl = torch.distributed (default under a launcher), "
+                         "store = a TCPStore on 127.0.0.1, no RCCL (default when bench.py starts the ranks itself)")
+    ap.add_argument("--inproc", action="store_true", help="N devices from ONE process: a filter instance and a stream per device, one host thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-to-host record (untimed, after the timed region)")
     ap.add_argument("--no-clock-sampler", action="store_true")
@@ -369,48 +581,95 @@ def main():
     ap.add_argument("--simd-order", type=int, default=0, help="1 / 2 / 3: the compatibility kernel in the reference's SSE4.1 / AVX2 / AVX-512 summation order")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
     ap.add_argument("--border-strips", type=int, default=-1, help="-1 default, 1 strip kernels, 2 row strips only, 0 gather kernel over the border frame")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.config not in CONFIGS:
         ap.error(f"unknown --config {args.config}; choose from {', '.join(sorted(CONFIGS))}")
+    if args.gpus < 1:
+        ap.error("--gpus must be at least 1")
+    return args
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    # started plainly with --gpus N > 1: this process starts the N ranks itself and only waits for them (it must not touch
+    # the GPU: its children are fresh interpreters, and nothing that has initialised HIP is forked or exec'ed)
+    # (JINC_BENCH_SELF_LAUNCH=1 takes this way for N = 1 as well: the one-GPU box's test of it)
+    if world_env is None and not args.inproc and (args.gpus > 1 or os.environ.get("JINC_BENCH_SELF_LAUNCH") == "1"):
+        import torch
+        have = torch.cuda.device_count()   # counting devices does not initialise HIP
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this host shows {have} HIP device(s)")
+        sync = "store" if args.sync == "auto" else args.sync
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv), sync=sync))
 
     import torch
-    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    world = int(world_env or "1")
+    if args.inproc:
+        if world != 1:
+            raise SystemExit("bench.py --inproc runs in one process: start it without a launcher")
+    elif world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher that started {world} rank(s): the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists in the product path)")
-    torch.cuda.set_device(local_rank)
+    devices = list(range(args.gpus)) if args.inproc else [local_rank]
+    if args.inproc and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --inproc --gpus {args.gpus}: this host shows {torch.cuda.device_count()} HIP device(s)")
+    torch.cuda.set_device(devices[0])
     # under torch.distributed.run (RANK set) the process group is always created, also for one rank, so that
     # the N = 1 launch exercises the same RCCL barrier / reductions as N = 8
-    use_dist = world > 1 or "RANK" in os.environ
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # nccl == RCCL on ROCm
+    how = os.environ.get("JINC_BENCH_SYNC", "") if args.sync == "auto" else args.sync
+    if world > 1 or "RANK" in os.environ:
+        if how == "store":
+            sync = StoreSync(rank, world)
+        else:
+            import torch.distributed as dist
+            sync = DistSync(dist, rank, world, local_rank, "nccl")  # nccl == RCCL on ROCm
+    else:
+        sync = NoSync()
+    n_gpus = args.gpus if args.inproc else world
 
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, default_frames = CONFIGS[args.config]
-    B = args.frames or default_frames
     strong = args.config == "C5"
-    if strong:  # the clip's frames are the sharding unit: rank r owns a contiguous run of them
-        B = shard_frames(B, rank, world)[1]
-        if B < 1:
-            raise SystemExit("C5: more ranks than frames")
-    flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, local_rank, 12345 + rank * B)
-    flt.set_kernel_mode(args.kernel_mode)
-    if args.simd_order:
-        flt.set_simd_order(args.simd_order)
-    if args.border_overlap >= 0:
-        flt.set_border_overlap(bool(args.border_overlap))
-    if args.border_strips >= 0:
-        flt.set_border_strips(args.border_strips)
+    profiled = under_profiler()
+    quiet = profiled or args.no_clock_sampler   # no second dispatch, no probe kernels in a profile
+
+    # one workload per device this process drives (one, unless --inproc): a plan replica, a batch resident in that device's
+    # HBM, a stream.  Frames are the sharding unit; with C5 (one clip, strong scaling) shard k owns a contiguous run of them.
+    loads = []
+    for k, dev in enumerate(devices):
+        shard, nshards = (k, len(devices)) if args.inproc else (rank, world)
+        B = args.frames or default_frames
+        if strong:
+            B = shard_frames(B, shard, nshards)[1]
+            if B < 1:
+                raise SystemExit("C5: more ranks than frames")
+        torch.cuda.set_device(dev)
+        flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, dev, 12345 + shard * B)
+        flt.set_kernel_mode(args.kernel_mode)
+        if args.simd_order:
+            flt.set_simd_order(args.simd_order)
+        if args.border_overlap >= 0:
+            flt.set_border_overlap(bool(args.border_overlap))
+        if args.border_strips >= 0:
+            flt.set_border_strips(args.border_strips)
+        loads.append({"device": dev, "filter": flt, "step": step, "stream": stream, "frames": B})
+    torch.cuda.set_device(devices[0])
+    flt, stream, B = loads[0]["filter"], loads[0]["stream"], loads[0]["frames"]
     info = flt.plan_info(0)
     sb = fmt.sample_bytes
+
+    def step_all():   # one step on every device of this process: launches only, nothing waits in here
+        for w in loads:
+            w["step"]()
+
+    def sync_all():
+        for w in loads:
+            torch.cuda.synchronize(w["device"])
 
     # Untimed device spin-up before the W warm-up steps: a C2 step is ~1 ms, so a handful of warm-up steps ends before the
     # shader clock and the caches have settled (measured: 482 vs 541 Gpix/s for --steps 5 --warmup 2 without / with it).
@@ -418,22 +677,20 @@ def main():
     spin_ms = float(os.environ.get("JINC_BENCH_SPINUP_MS", "300"))
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
-        step()
-        torch.cuda.synchronize()
+        step_all()
+        sync_all()
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+        step_all()
+    sync_all()
     flt.set_profiling(True)
     flt.kernel_times()  # reset
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
+    sync.barrier()
+    sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        step_all()
+    sync_all()
+    sync.barrier()
     elapsed = time.perf_counter() - t0
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
@@ -442,22 +699,40 @@ def main():
     # small, costs kernels with short-lived workgroups 10-15 % (1080p -> 720p 253 -> 222 Gpix/s, C2 1 %;
     # profiles/round3/clock_sampler_priority.log), so the value is taken without it and the clock right after.
     clock_ghz = None
-    if rank == 0 and not args.no_clock_sampler:
-        sampler = pkg.ClockSampler(local_rank, 60.0)
+    if rank == 0 and not quiet:
+        sampler = pkg.ClockSampler(devices[0], 60.0)
         for _ in range(args.steps):
-            step()
+            loads[0]["step"]()
         stream.synchronize()   # the steps' stream only: a device-wide synchronize would wait for the samplers themselves
         clock_ghz = sampler.stop()
     # untimed, right after the timed region (clocks warm): what the kernels' instruction pair sustains on THIS part
     pair_probe = None
-    if rank == 0 and not args.no_clock_sampler:
+    if rank == 0 and not quiet:
         try:
-            pair_probe = {str(w): pkg.valu_pair_probe(local_rank, w) for w in (4, 6, 8)}
+            pair_probe = {str(w): pkg.valu_pair_probe(devices[0], w) for w in (4, 6, 8)}
         except Exception:  # noqa: BLE001
             pair_probe = None
+    # what the border kernels cost when nothing runs beside them: a few untimed steps with the border launches queued
+    # BEHIND the interior on the same stream (their event times beside the interior only say how long they sat there)
+    border_alone_ms = None
+    if rank == 0 and not quiet and per_n > 0 and gat_n > 0 and args.border_overlap < 0:
+        try:
+            flt.set_border_overlap(False)
+            flt.set_profiling(True)
+            flt.kernel_times()
+            for _ in range(3):
+                loads[0]["step"]()
+            torch.cuda.synchronize(devices[0])
+            border_alone_ms = flt.kernel_times()[2] / 3.0
+            flt.set_profiling(False)
+            flt.set_border_overlap(None)
+        except Exception:  # noqa: BLE001
+            border_alone_ms = None
 
-    frames_done = float(B * args.steps)
-    elapsed_max, frames_all = aggregate(elapsed, frames_done, dist if use_dist else None)
+    frames_done = float(sum(w["frames"] for w in loads) * args.steps)
+    elapsed_max, frames_all, frames_by_rank = sync.reduce(elapsed, frames_done)
+    if args.inproc:
+        frames_by_rank = [float(w["frames"] * args.steps) for w in loads]
     mpix = frames_all * dw * dh / elapsed_max / 1e6
 
     if rank == 0:
@@ -465,7 +740,6 @@ def main():
         fs = info.filter_size
         samples_frame = sum(w * h for (w, h) in ddims)
         src_bytes_frame = sum(w * h for (w, h) in fmt.plane_dims(sw, sh)) * sb
-        n_planes = fmt.planes
         if per_n > 0:
             dom_name, dom_ms, dom_n = flt.last_kernel(0), per_ms, per_n
         else:   # whole planes on the gather kernel (or, with --simd-order, on the compatibility kernel)
@@ -491,19 +765,24 @@ def main():
                     traffic_raw = int(rec.get("hbm_bytes_per_launch_raw", 0) * scale) or None
             except Exception:  # noqa: BLE001
                 traffic = traffic_raw = None
+        how_parallel = (f"frames sharded over {n_gpus} GPU(s), no collective; "
+                        + ("one process, a filter instance and a stream per device" if args.inproc else
+                           f"one process per GPU, ranks meet over {sync.name}" if n_gpus > 1 or sync.name != "none" else "one process"))
         line = {
             "metric": baseline_metric() if args.config == "C2" else f"Mpix/s ({args.config})",
-            "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(mpix, 1), "unit": "Mpix/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32",  # arithmetic type of the path (un-fused fp32 accumulate over u8/u16/f32 samples)
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {sw}x{sh}->{dw}x{dh} {fmt_name} tap={kw['tap']}"
                                    + (f" blur={kw['blur']}" if 'blur' in kw else ""),
                        "sample_type": {1: "u8", 2: "u16", 4: "f32"}[sb], "frames_per_step_per_gpu": B,
+                       "frames_per_rank": [int(x) for x in frames_by_rank], "sync": sync.name, "launch": "inproc" if args.inproc else
+                       ("self-launched ranks" if os.environ.get("JINC_BENCH_SYNC") else ("launcher" if "RANK" in os.environ else "single process")),
                        "timed_region_s": round(elapsed_max, 4), "resident_bytes_per_gpu": (bytes_frame * B),
-                       "untimed_spinup_ms_before_warmup": spin_ms, "parallelism": f"frames sharded over {world} GPU(s), no collective",
+                       "untimed_spinup_ms_before_warmup": spin_ms, "parallelism": how_parallel,
                        "kernel": dom_name, "direct_kernel_premise": flt.direct_premise, "filter_size": fs, "plan_sets": info.num_sets,
-                       "plan_bytes": int(info.plan_bytes)},
+                       "plan_bytes": int(info.plan_bytes), "under_profiler": profiled},
             "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE from profiles/traffic.json (gfx950 FETCH correction); raw sum in traffic_raw",
@@ -531,23 +810,27 @@ def main():
                          "valu_frac_of_pair_sustained": round(valu_ops / 1e12 / max(t for t, _ in pair_probe.values()), 4) if pair_probe else None,
                          # the north_star's "HBM-read" reading: source bytes only (each source sample once)
                          "hbm_read_frac": round(src_bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "border_kernel_ms_per_step": round(gat_ms / args.steps, 4) if per_n > 0 else None},
+                         # what the border frame costs: the step minus its interior kernel (the border launches run beside the
+                         # interior on a side stream), and the border kernels' own duration with nothing beside them (untimed
+                         # serial pass after the timed region)
+                         "step_minus_interior_ms": round(elapsed_max / args.steps * 1e3 - kernel_ms_per_step, 4) if per_n > 0 else None,
+                         "border_ms_alone": round(border_alone_ms, 4) if border_alone_ms is not None else None},
         }
         line["e2e"] = None
-        if world == 1 and not args.no_e2e:
+        if n_gpus == 1 and not args.no_e2e and not profiled:
             try:
                 line["e2e"] = e2e_record(pkg, args.config)
             except Exception as exc:  # noqa: BLE001  (a record next to the value, never a reason to lose the line)
                 line["e2e"] = {"error": str(exc)}
-        if world == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and not profiled:
             line["cpu_baseline"] = cpu_baseline(args.config)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
 
-    flt.close()
-    if use_dist:
-        dist.destroy_process_group()
+    for w in loads:
+        w["filter"].close()
+    sync.close()
 
 
 if __name__ == "__main__":

@@ -102,8 +102,10 @@ typedef struct jinc_args {
     double initial_factor;  /* [initial_factor]f >= 1.0; validated, otherwise unused */
     unsigned defined;       /* JINC_ARG_* bits */
     /* Host facts the reference queries from the script environment: */
-    int frame0_chroma_location; /* _ChromaLocation of frame 0 if that property is an int, else -1
-                                   (only consulted when cplace is not given; ref :727-742) */
+    int frame0_chroma_location; /* _ChromaLocation of frame 0 if that property is an int, else -1 = "no such property"
+                                   (only consulted when cplace is not given; ref :727-742).  0 / 1 / 2 select the
+                                   siting; ANY other integer the property holds -- negative ones too: pass them as 3 --
+                                   is the reference's "invalid _ChromaLocation" (switch default, :737) */
     int cpu_has_sse41;      /* avs_get_cpu_flags() & AVS_CPUF_SSE4_1 (ref :755) */
     int cpu_has_avx2;       /* ... & AVS_CPUF_AVX2    (ref :753) */
     int cpu_has_avx512f;    /* ... & AVS_CPUF_AVX512F (ref :751) */
@@ -139,9 +141,21 @@ JINC_API void jinc_filter_free(jinc_filter *f);
 /* The output clip's AVS_VideoInfo: the input's with width/height replaced (ref :791-792). */
 JINC_API int jinc_filter_output_info(const jinc_filter *f, jinc_video_info *out_vi);
 
-/* Value JincResize_GetFrame writes to the _ChromaLocation frame property (ref :617-625):
- * 0 mpeg2, 1 mpeg1, 2 topleft; -1 when the property is not written (not 4:2:0/4:2:2/4:1:1). */
+/* Value JincResize_GetFrame writes to the _ChromaLocation frame property (ref :617-625): **2 for every 4:2:0 / 4:2:2 /
+ * 4:1:1 output, whatever the siting**; -1 when the property is not written (4:4:4, Y, RGB).  The reference's source
+ * reads as "0 mpeg2, 1 mpeg1, 2 topleft", but it compares the member `d->cplace`, which nothing assigns (`new
+ * JincResize()` :676; the siting string is the LOCAL `cplace` declared at :715), so the binary always takes the `else`
+ * at :623-624.  A drop-in writes what the binary writes.  (Pixels are not affected: the local string drives the chroma
+ * geometry, :838-841.) */
 JINC_API int jinc_filter_chroma_location(const jinc_filter *f);
+
+/* Private switch, in the manner of jinc_filter_set_simd_order: JINC_CHROMA_LOCATION_BY_SITING makes
+ * jinc_filter_chroma_location return what the reference's source means to write -- 0 mpeg2, 1 mpeg1, 2 topleft, by the
+ * cplace argument or frame 0's property -- for hosts that want the property to describe the chroma they get.  A
+ * deliberate deviation from the reference binary; off by default. */
+#define JINC_CHROMA_LOCATION_AS_REFERENCE 0
+#define JINC_CHROMA_LOCATION_BY_SITING 1
+JINC_API int jinc_filter_set_chroma_location_mode(jinc_filter *f, int mode);
 
 /* The body of JincResize_GetFrame between avs_new_video_frame_p and avs_prop_set_int, i.e.
  * (d->*d->process_frame)(src, dst, vi) (ref :615), on HOST plane buffers as AviSynth hands them

@@ -226,8 +226,10 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
         // (the reference asks the new filter's clip, whose get_frame is still unset and passes through to the child)
         if (AVS_VideoFrame* frame0 = avs_get_frame(fi->child, 0)) {
             const AVS_Map* props = avs_get_frame_props_ro(env, frame0);
-            if (avs_prop_get_type(env, props, "_ChromaLocation") == 'i')
-                a.frame0_chroma_location = static_cast<int>(avs_prop_get_int(env, props, "_ChromaLocation", 0, nullptr));
+            if (avs_prop_get_type(env, props, "_ChromaLocation") == 'i') {
+                const int64_t loc = avs_prop_get_int(env, props, "_ChromaLocation", 0, nullptr);
+                a.frame0_chroma_location = (loc >= 0 && loc <= 2) ? static_cast<int>(loc) : 3;  // anything else: "invalid _ChromaLocation" (ref :737)
+            }
             avs_release_video_frame(frame0);
         }
     }
@@ -244,6 +246,10 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
 
     Instance* inst = new Instance;
     inst->filter = filter;
+    // default: what the reference binary writes (2 for every sub-sampled format, ref :617-625 with d->cplace never
+    // assigned); JINCRESIZE_CHROMALOC=siting writes 0 / 1 / 2 by the siting actually used
+    if (const char* e = std::getenv("JINCRESIZE_CHROMALOC"))
+        if (std::strcmp(e, "siting") == 0) jinc_filter_set_chroma_location_mode(filter, JINC_CHROMA_LOCATION_BY_SITING);
     inst->chroma_location = jinc_filter_chroma_location(filter);
     if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("JINCRESIZE_GROUP")) inst->group = std::max(0, std::min(inst->lookahead, std::atoi(e)));

@@ -150,8 +150,10 @@ void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* c
         char msg[256];
         if (const VSFrame* frame0 = vsapi->getFrame(0, node, msg, sizeof msg)) {
             const VSMap* props = vsapi->getFramePropertiesRO(frame0);
-            if (vsapi->mapGetType(props, "_ChromaLocation") == ptInt)
-                a.frame0_chroma_location = static_cast<int>(vsapi->mapGetInt(props, "_ChromaLocation", 0, &err));
+            if (vsapi->mapGetType(props, "_ChromaLocation") == ptInt) {
+                const int64_t loc = vsapi->mapGetInt(props, "_ChromaLocation", 0, &err);
+                a.frame0_chroma_location = (loc >= 0 && loc <= 2) ? static_cast<int>(loc) : 3;  // anything else: "invalid _ChromaLocation" (ref :737)
+            }
             vsapi->freeFrame(frame0);
         }
     }
@@ -171,6 +173,10 @@ void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* c
     Instance* d = new Instance;
     d->node = node;
     d->filter = filter;
+    // default: what the reference binary writes (2 for every sub-sampled format, ref :617-625 with d->cplace never
+    // assigned); JINCRESIZE_CHROMALOC=siting writes 0 / 1 / 2 by the siting actually used
+    if (const char* e = std::getenv("JINCRESIZE_CHROMALOC"))
+        if (std::strcmp(e, "siting") == 0) jinc_filter_set_chroma_location_mode(filter, JINC_CHROMA_LOCATION_BY_SITING);
     d->chroma_location = jinc_filter_chroma_location(filter);
     d->planes = vi->format.numPlanes;
     d->vi = *vi;

@@ -13,7 +13,7 @@ mkdir -p gpurun_out/$JINC_PROFILE_DIR
 if [ "$part" != lines ]; then
 for c in ${JINC_PROFILE_CONFIGS:-C2 C3 C4 A137 N15}; do   # (JINC_PROFILE_CONFIGS / JINC_LINE_CONFIGS: other lists for partial re-collections)
   export JINC_FRAMES_PER_LAUNCH=$(python -c "import bench; print(bench.CONFIGS['$c'][6])")
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$c -- python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/${tag}_stats_$c.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_stats_$c -- python bench.py --no-clock-sampler --config $c --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > gpurun_out/${tag}_stats_$c.log 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/${tag}_fetch_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-sampler > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${tag}_write_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-sampler > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/${tag}_clock_$c -- python bench.py --config $c --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --no-clock-sampler > /dev/null 2>&1

@@ -7,7 +7,7 @@ R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$R" || exit 1
 out=gpurun_out/${tag}_stats_$cfg
 mkdir -p $out
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline "$@" > $out.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python bench.py --no-clock-sampler --no-e2e --config $cfg --steps 20 --warmup 5 --no-cpu-baseline "$@" > $out.log 2>&1
 tail -1 $out.log | cut -c1-160
 f=$(ls $out/*/*kernel_stats.csv | head -1)
 python - "$f" <<PY

@@ -6,7 +6,7 @@ R=$PWD
 cd /tmp && export TMPDIR=/tmp && cd "$R" || exit 1
 out=gpurun_out/${tag}_mem_$cfg
 mkdir -p $out
-run() { n=$1; shift; timeout 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$n -- python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $out/$n.log 2>&1 || echo "pass $n failed: $(tail -2 $out/$n.log)"; }
+run() { n=$1; shift; timeout 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$n -- python bench.py --no-clock-sampler --no-e2e --config $cfg --steps 3 --warmup 1 --no-cpu-baseline $EXTRA > $out/$n.log 2>&1 || echo "pass $n failed: $(tail -2 $out/$n.log)"; }
 EXTRA="$*"
 run m1 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run m2 TCC_HIT_sum TCC_MISS_sum TCC_READ_sum TCC_WRITE_sum

@@ -34,4 +34,57 @@ def test_bench_under_torch_distributed_run_with_one_rank(gpu_pkg, config, extra)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert d["scaling"] == ("strong" if config == "C5" else "weak")
     assert d["roofline"]["kernel"] in ("ewa_periodic_kernel", "ewa_periodic_quad_kernel") and d["roofline"]["frac"] > 0
-    assert d["config"]["parallelism"].startswith("frames sharded over 1 GPU")
+    assert d["config"]["parallelism"].startswith("frames sharded over 1 GPU") and d["config"]["sync"] == "rccl"
+
+
+def _one_line(r):
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _plain_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "JINC_BENCH_SYNC", "JINC_BENCH_SELF_LAUNCH")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    return env
+
+
+QUICK = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--no-clock-sampler"]
+
+
+def test_bench_started_plainly_runs_the_clip_config(gpu_pkg):
+    """`python bench.py --gpus 1 --config C5 --steps 3`, no launcher, no environment."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C5", *QUICK], cwd=ROOT, env=_plain_env(),
+                       capture_output=True, text=True, timeout=300)
+    d = _one_line(r)
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["frames_per_rank"] == [3 * 512] and d["config"]["sync"] == "none" and d["config"]["launch"] == "single process"
+
+
+@pytest.mark.parametrize("sync", ["store", "rccl"])
+def test_bench_starts_its_own_ranks(gpu_pkg, sync):
+    """The way `python bench.py --gpus N` takes for N > 1, here with the one rank a one-GPU box allows: the parent touches no
+    GPU, starts the rank as a fresh interpreter, passes its line through; the rank meets itself over the TCPStore (no RCCL) or,
+    with --sync rccl, over RCCL."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C5", "--sync", sync, *QUICK], cwd=ROOT,
+                       env=_plain_env(JINC_BENCH_SELF_LAUNCH="1"), capture_output=True, text=True, timeout=300)
+    d = _one_line(r)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["launch"] == "self-launched ranks"
+    assert d["config"]["sync"] == sync and d["config"]["frames_per_rank"] == [3 * 512]
+
+
+def test_bench_in_one_process_over_its_devices(gpu_pkg):
+    """--inproc: a filter instance and a stream per device from one host thread (one device here)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--inproc", "--config", "C1", "--frames", "64", *QUICK], cwd=ROOT,
+                       env=_plain_env(), capture_output=True, text=True, timeout=300)
+    d = _one_line(r)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["launch"] == "inproc" and d["config"]["frames_per_rank"] == [3 * 64]
+
+
+def test_bench_under_a_launcher_with_the_store_for_the_barrier(gpu_pkg):
+    env = dict(_plain_env(), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "C1", "--frames", "64", "--sync", "store", *QUICK]
+    d = _one_line(subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300))
+    assert d["config"]["sync"] == "store" and d["config"]["launch"] == "launcher" and d["value"] > 0

@@ -245,11 +245,11 @@ def test_filter_object_without_a_gpu_or_with_one(host, O, pkg):
 GPU_CASES = [
     ("Y8", 96, 64, 192, 128, "JincResize", {}, None),
     ("YUV420P8", 128, 96, 256, 192, "JincResize", dict(tap=4, cplace="topleft"), 2),
-    ("YUV420P16", 128, 96, 200, 150, "JincResize", dict(src_left=1.5, src_top=-0.5, src_width=120.0, src_height=90.0, quant_x=64), 0),
-    ("YUV422P10", 128, 96, 256, 192, "Jinc36Resize", dict(cplace="MPEG1"), 1),
+    ("YUV420P16", 128, 96, 200, 150, "JincResize", dict(src_left=1.5, src_top=-0.5, src_width=120.0, src_height=90.0, quant_x=64), 2),
+    ("YUV422P10", 128, 96, 256, 192, "Jinc36Resize", dict(cplace="MPEG1"), 2),
     ("RGBPS", 96, 64, 192, 128, "Jinc64Resize", {}, None),
     ("YUV444P8", 96, 64, 48, 32, "Jinc144Resize", dict(quant_y=32), None),
-    ("YUVA420P8", 128, 96, 256, 192, "Jinc256Resize", {}, 0),
+    ("YUVA420P8", 128, 96, 256, 192, "Jinc256Resize", {}, 2),
 ]
 
 
@@ -257,7 +257,7 @@ GPU_CASES = [
 @pytest.mark.parametrize("case", GPU_CASES, ids=lambda c: f"{c[5]}_{c[0]}")
 def test_frames_through_the_plugin_match_the_oracle(host, O, case):
     """Script call -> plugin -> C ABI -> GPU -> frame in the host's buffers, against the oracle; the alias functions
-    arrive in JincResize with tap 3/4/6/8; _ChromaLocation is written for sub-sampled formats only (ref :617-625)."""
+    arrive in JincResize with tap 3/4/6/8; _ChromaLocation = 2 is written for sub-sampled formats only, whatever the siting -- what the reference binary does (ref :617-625; d->cplace is never assigned)."""
     fmt_name, sw, sh, tw, th, fn, named, want_loc = case
     fmt = O.FORMATS[fmt_name]
     frames = [O.lcg_frame(fmt, sw, sh, seed=12345 + n) for n in range(2)]
@@ -284,8 +284,15 @@ def test_frames_through_the_plugin_match_the_oracle(host, O, case):
 
 
 @pytest.mark.gpu
-def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(host, O):
-    """ref :727-742: _ChromaLocation 0/1/2 of the first frame selects mpeg2/mpeg1/topleft; other values are an error."""
+@pytest.mark.parametrize("by_siting", [False, True], ids=["as_reference", "by_siting"])
+def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(host, O, monkeypatch, by_siting):
+    """ref :727-742: _ChromaLocation 0/1/2 of the first frame selects mpeg2/mpeg1/topleft (the pixels show it); other values
+    are an error.  The property written is 2 in every case, as the reference binary does (ref :617-625, d->cplace never
+    assigned); JINCRESIZE_CHROMALOC=siting writes the siting in use instead."""
+    if by_siting:
+        monkeypatch.setenv("JINCRESIZE_CHROMALOC", "siting")
+    else:
+        monkeypatch.delenv("JINCRESIZE_CHROMALOC", raising=False)
     fmt = O.FORMATS["YUV420P8"]
     frames = [O.lcg_frame(fmt, 128, 96)]
     for loc, cplace in ((0, "mpeg2"), (1, "mpeg1"), (2, "topleft")):
@@ -297,7 +304,7 @@ def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(host, O)
         got = [h.read_plane(fr, i, np.uint8) for i in range(3)]
         want = O.OracleFilter(fmt, 128, 96, 256, 192, cplace=cplace).get_frame(frames[0], threads=4)
         assert_planes_equal(got, want, fmt.plane_dims(256, 192), what=f"_ChromaLocation {loc}")
-        assert h.prop(fr, "_ChromaLocation") == loc
+        assert h.prop(fr, "_ChromaLocation") == (loc if by_siting else 2)
         host.mock_frame_release(fr)
         host.mock_clip_release(clip)
         host.mock_source_release(src)
@@ -355,7 +362,7 @@ def test_lookahead_ring_sequential_and_seek(host, O, depth, monkeypatch):
         assert host.mock_clip_error(clip) is None
         got = [h.read_plane(fr, i, np.uint8) for i in range(3)]
         assert_planes_equal(got, of.get_frame(frames[n], threads=4), fmt.plane_dims(192, 128), what=f"frame {n} depth {depth}")
-        assert h.prop(fr, "_ChromaLocation") == 0
+        assert h.prop(fr, "_ChromaLocation") == 2   # what the reference binary writes for 4:2:0 (ref :617-625)
         host.mock_frame_release(fr)
         if step == nframes - 1:
             assert host.mock_source_get_frame_calls(src) == nframes + 1   # + the frame-0 property probe at create time

@@ -215,8 +215,8 @@ def test_filter_object(vs, O, pkg):
 GPU_CASES = [
     ("Y8", 96, 64, 192, 128, "JincResize", {}, None),
     ("YUV420P8", 128, 96, 256, 192, "JincResize", dict(tap=4, cplace="topleft"), 2),
-    ("YUV420P16", 128, 96, 200, 150, "JincResize", dict(src_left=1.5, src_top=-0.5, src_width=120.0, src_height=90.0, quant_x=64, blur=0.98), 0),
-    ("YUV422P10", 128, 96, 256, 192, "Jinc36Resize", dict(cplace="MPEG1"), 1),
+    ("YUV420P16", 128, 96, 200, 150, "JincResize", dict(src_left=1.5, src_top=-0.5, src_width=120.0, src_height=90.0, quant_x=64, blur=0.98), 2),
+    ("YUV422P10", 128, 96, 256, 192, "Jinc36Resize", dict(cplace="MPEG1"), 2),
     ("RGBPS", 96, 64, 192, 128, "Jinc64Resize", {}, None),
     ("YUV444P8", 96, 64, 48, 32, "Jinc144Resize", dict(quant_y=32), None),
     ("RGBP8", 64, 48, 128, 96, "Jinc256Resize", {}, None),
@@ -255,8 +255,14 @@ def test_frames_through_the_front_end_match_the_oracle(vs, O, case):
 
 
 @pytest.mark.gpu
-def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(vs, O):
-    """ref :727-742 through the VapourSynth property of the same name."""
+@pytest.mark.parametrize("by_siting", [False, True], ids=["as_reference", "by_siting"])
+def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(vs, O, monkeypatch, by_siting):
+    """ref :727-742 through the VapourSynth property of the same name; the property written is 2 whatever the siting, as the
+    reference binary does (ref :617-625), unless JINCRESIZE_CHROMALOC=siting."""
+    if by_siting:
+        monkeypatch.setenv("JINCRESIZE_CHROMALOC", "siting")
+    else:
+        monkeypatch.delenv("JINCRESIZE_CHROMALOC", raising=False)
     fmt = O.FORMATS["YUV420P8"]
     frames = [O.lcg_frame(fmt, 128, 96)]
     for loc, cplace in ((0, "mpeg2"), (1, "mpeg1"), (2, "topleft")):
@@ -269,7 +275,7 @@ def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(vs, O):
         got = [c.read_plane(fr, i, np.uint8) for i in range(3)]
         want = O.OracleFilter(fmt, 128, 96, 256, 192, cplace=cplace).get_frame(frames[0], threads=4)
         assert_planes_equal(got, want, fmt.plane_dims(256, 192), what=f"_ChromaLocation {loc}")
-        assert c.prop(fr, "_ChromaLocation") == loc
+        assert c.prop(fr, "_ChromaLocation") == (loc if by_siting else 2)
         vs.mockvs_frame_release(fr)
         vs.mockvs_node_release(node)
         vs.mockvs_node_release(src)
