@@ -364,7 +364,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
     if (c.wants_framelane(t, i)) {
         auto aligned_to = [&](uintptr_t bytes) {
             return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
-                   (nframes <= 1 || io.dst_frame_stride % bytes == 0);
+                   (io.nframes <= 1 || io.dst_frame_stride % bytes == 0);  // io.nframes: 2 when two planes travel as one call
         };
         // bit 0: packed stores of 4 samples, bit 1: 16-byte stores (8-bit planes in the frame-pair form)
         const int vec_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
@@ -405,7 +405,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         if (t.use_fl_border && nframes >= runs_fl_border_min_frames() && t.border_rects.n > 0) {
             auto aligned_to = [&](uintptr_t bytes) {
                 return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
-                       (nframes <= 1 || io.dst_frame_stride % bytes == 0);
+                       (io.nframes <= 1 || io.dst_frame_stride % bytes == 0);  // io.nframes: 2 when two planes travel as one call
             };
             jinc::FrameLaneArgs fa = t.fl_border;
             fa.io = io;

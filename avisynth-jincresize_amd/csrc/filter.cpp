@@ -157,6 +157,11 @@ int jinc_filter_adopt_host_range(jinc_filter* f, void* base, size_t bytes) {
     });
 }
 
+int jinc_debug_transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, int reset) {
+    transport_counts(by_shader, by_dma, pinned_ranges, reset != 0);
+    return JINC_OK;
+}
+
 int jinc_filter_flush(jinc_filter* f) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");

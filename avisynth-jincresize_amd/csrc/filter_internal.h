@@ -125,6 +125,11 @@ struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-a
     long long ticket = -1;  // latest frame whose copies use this range (may still be in flight)
 };
 
+struct FailedTickets {  // a group whose launch failed: every wait on one of its frames reports `error`
+    long long first = 0, last = -1;
+    std::string error;
+};
+
 // Upper limits of the look-ahead pipeline: frames in flight per instance, and the device memory its staging may take.
 constexpr int kMaxPipelineDepth = 256;
 constexpr size_t kPipelineBudgetBytes = size_t(24) << 30;
@@ -176,6 +181,7 @@ struct jinc_filter {
     long long next_ticket = 0;
     bool register_host = false;
     std::vector<jinc::host::PinnedRange> pinned;
+    std::vector<jinc::host::FailedTickets> failed;  // groups whose launch failed and whose buffer has gone back into the ring
     unsigned long long pin_clock = 0;
     bool profiling = false;
     std::vector<jinc::host::EventPair> ev_periodic, ev_gather;  // recorded, not yet collected
@@ -195,9 +201,7 @@ struct jinc_filter {
                 if (t.blob) (void)hipFree(t.blob);
                 for (void* b : t.lane_blobs) (void)hipFree(b);
             }
-            jinc::host::release_pipeline(*this);
-            for (auto& p : pinned)
-                if (!p.adopted) (void)hipHostUnregister(p.base);
+            jinc::host::release_pipeline(*this);  // (also returns this instance's references to pinned host ranges)
             for (auto* v : {&ev_periodic, &ev_gather})
                 for (auto& e : *v) {
                     (void)hipEventDestroy(e.start);
@@ -247,6 +251,7 @@ void wait_frame(jinc_filter& f, long long ticket);  // flushes the open group if
 void adopt_host_range(jinc_filter& f, void* base, size_t bytes);  // caller-pinned memory: usable for async copies and shader transport
 void launch_open_group(jinc_filter& f);             // the frames submitted so far leave now (a client that knows no more are coming)
 void drain_pipeline(jinc_filter& f);                // every submitted frame complete
+void transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, bool reset);  // process-wide (test header)
 
 }  // namespace host
 }  // namespace jinc

@@ -17,7 +17,9 @@
 // one every 60 us = 35 GB/s of the link's 52 GB/s); a single launch per share of the group has no per-frame cost.
 // Results do not depend on the grouping: frames are independent and every kernel computes a frame's samples the same way
 // whatever the batch size (tests/test_gpu_parity.py, tests/test_pipeline_groups.py).
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 #include "filter_internal.h"
 
@@ -25,6 +27,58 @@ namespace jinc {
 namespace host {
 
 namespace {
+
+// ---- Host ranges pinned by this library, process-wide ------------------------------------------------------------
+// AviSynth's frame pool is shared by every filter instance of a script (MT_MULTI_INSTANCE under Prefetch(N): N instances
+// of this filter, ref /root/reference/src/JincResize.cpp:649-652), so the same buffer reaches different instances in turn.
+// hipHostRegister refuses a range that is registered already; with a cache per instance the second instance to see a buffer
+// fell back to pageable copies for good.  One registry for the process instead: a range is registered once (portable:
+// valid on every device), instances take and return references, the last reference unregisters.  Ranges somebody ELSE
+// pinned (the host itself, another library) are recognised by asking for their device address and are never unregistered.
+struct SharedPin {
+    char* base = nullptr;
+    size_t bytes = 0;
+    int refs = 0;
+    bool owned = false;  // registered here (else: found pinned)
+};
+std::mutex g_pin_mutex;
+std::vector<SharedPin> g_pins;
+std::atomic<long long> g_frames_by_shader{0}, g_frames_by_dma{0};  // how results left the device, process-wide (test header)
+
+// A reference to a registered range that contains [c, c + bytes), registering it if need be; false: not pinnable.
+bool shared_pin_acquire(char* c, size_t bytes, char** base, size_t* len) {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (auto& e : g_pins)
+        if (c >= e.base && c + bytes <= e.base + e.bytes) {
+            ++e.refs;
+            *base = e.base, *len = e.bytes;
+            return true;
+        }
+    bool owned = true;
+    if (hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
+        (void)hipGetLastError();  // e.g. registered by the host application: usable if both ends have a device address
+        void *d0 = nullptr, *d1 = nullptr;
+        if (hipHostGetDevicePointer(&d0, c, 0) != hipSuccess || hipHostGetDevicePointer(&d1, c + bytes - 1, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        owned = false;
+    }
+    g_pins.push_back({c, bytes, 1, owned});
+    *base = c, *len = bytes;
+    return true;
+}
+
+void shared_pin_release(char* base) {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (size_t i = 0; i < g_pins.size(); ++i)
+        if (g_pins[i].base == base) {
+            if (--g_pins[i].refs > 0) return;
+            if (g_pins[i].owned) (void)hipHostUnregister(base);
+            g_pins.erase(g_pins.begin() + static_cast<std::ptrdiff_t>(i));
+            return;
+        }
+}
 
 void release_group(FrameGroup& g) {  // (the belts are idle: callers drain first)
     if (g.src_base) (void)hipFree(g.src_base);
@@ -124,6 +178,12 @@ void finish_group(jinc_filter& f, FrameGroup& g) {
 
 void retire_group(jinc_filter& f, FrameGroup& g) {
     finish_group(f, g);
+    // the buffer goes back into the ring; what its frames' waits must still be told stays behind (a failed launch is
+    // reported by every wait on a frame of that group, also after the ring has rotated)
+    if (g.state == FrameGroup::Failed && !g.frames.empty()) {
+        if (f.failed.size() >= 64) f.failed.erase(f.failed.begin());
+        f.failed.push_back({g.frames.front().ticket, g.frames.back().ticket, g.error});
+    }
     g.frames.clear();
     g.error.clear();
     g.state = FrameGroup::Idle;
@@ -221,7 +281,9 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
                 hip_check(hipEventRecord(g.done[static_cast<size_t>(s)], d2h), "hipEventRecord(share done)");
                 for (int k = k0; k < k1; ++k) g.frames[static_cast<size_t>(k)].done_event = s;
             }
+            g_frames_by_shader += n;
         } else {
+            g_frames_by_dma += n;
             for (int k = 0; k < n; ++k) {
                 GroupFrame& fr = g.frames[static_cast<size_t>(k)];
                 for (int i = 0; i < planes; ++i) {
@@ -273,20 +335,19 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
                 if (fr.ticket == f.pinned[lru].ticket) {
                     if (g.state == FrameGroup::Filling || g.state == FrameGroup::Launched) finish_group(f, g);
                 }
-        (void)hipHostUnregister(f.pinned[lru].base);
+        shared_pin_release(f.pinned[lru].base);
         f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(lru));
     }
-    if (hipHostRegister(c, bytes, hipHostRegisterDefault) != hipSuccess) {
-        (void)hipGetLastError();  // clear; e.g. the range overlaps memory somebody else has registered
-        return nullptr;
-    }
+    char* base = nullptr;
+    size_t len = 0;
+    if (!shared_pin_acquire(c, bytes, &base, &len)) return nullptr;  // e.g. the range straddles memory somebody else has registered
     void* dev = nullptr;
-    if (hipHostGetDevicePointer(&dev, c, 0) != hipSuccess) {
+    if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess) {
         (void)hipGetLastError();
         dev = nullptr;
     }
-    f.pinned.push_back({c, bytes, static_cast<char*>(dev), false, ++f.pin_clock, ticket});
-    return static_cast<char*>(dev);
+    f.pinned.push_back({base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket});
+    return dev ? static_cast<char*>(dev) + (c - base) : nullptr;
 }
 
 }  // namespace
@@ -306,16 +367,26 @@ void ensure_belts(jinc_filter& f) {
         release_belts(f);
         return;
     }
-    if (f.h2d_stream) return;
-    hip_check(hipStreamCreateWithFlags(&f.h2d_stream, hipStreamNonBlocking), "hipStreamCreate(arrivals)");
-    int least = 0, greatest = 0;
-    hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-    const char* e = std::getenv("JINC_D2H_PRIORITY");  // A/B knob: 0 lowest, 1 highest (default), 2 normal
-    const int mode = e ? std::atoi(e) : 1;
-    if (mode == 2)
-        hip_check(hipStreamCreateWithFlags(&f.d2h_stream, hipStreamNonBlocking), "hipStreamCreate(departures)");
-    else
-        hip_check(hipStreamCreateWithPriority(&f.d2h_stream, hipStreamNonBlocking, mode == 0 ? least : greatest), "hipStreamCreate(departures)");
+    if (f.h2d_stream && f.d2h_stream) return;
+    release_belts(f);  // (a half-made pair from a failed attempt)
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    try {  // both or none: a missing departures belt would put transport, copies and events on the null stream
+        hip_check(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking), "hipStreamCreate(arrivals)");
+        int least = 0, greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+        const char* e = std::getenv("JINC_D2H_PRIORITY");  // A/B knob: 0 lowest, 1 highest (default), 2 normal
+        const int mode = e ? std::atoi(e) : 1;
+        if (mode == 2)
+            hip_check(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking), "hipStreamCreate(departures)");
+        else
+            hip_check(hipStreamCreateWithPriority(&d2h, hipStreamNonBlocking, mode == 0 ? least : greatest), "hipStreamCreate(departures)");
+    } catch (...) {
+        if (h2d) (void)hipStreamDestroy(h2d);
+        if (d2h) (void)hipStreamDestroy(d2h);
+        throw;
+    }
+    f.h2d_stream = h2d;
+    f.d2h_stream = d2h;
 }
 }  // namespace
 
@@ -328,7 +399,36 @@ void adopt_host_range(jinc_filter& f, void* base, size_t bytes) {
         (void)hipGetLastError();
         throw ArgError("JincResize: the host range is not pinned for this device (hipHostRegister / hipHostMalloc it first).");
     }
-    f.pinned.push_back({c, bytes, static_cast<char*>(dev), true, ++f.pin_clock, -1});
+    // Neighbours that continue each other in host AND device addresses become one range: a registrar that pins a frame
+    // pool piece by piece (jinc_batch_process: 16 frames at a time, clipped to what is pinned already) hands over pieces,
+    // and a plane that begins in one piece and ends in the next must still lie inside ONE range to travel by the shader.
+    PinnedRange nr{c, bytes, static_cast<char*>(dev), true, ++f.pin_clock, -1};
+    for (bool merged = true; merged;) {
+        merged = false;
+        for (size_t i = 0; i < f.pinned.size(); ++i) {
+            PinnedRange& r = f.pinned[i];
+            if (!r.adopted || !r.dev || !nr.dev) continue;
+            const bool after = r.base + r.bytes == nr.base && r.dev + r.bytes == nr.dev;    // nr continues r
+            const bool before = nr.base + nr.bytes == r.base && nr.dev + nr.bytes == r.dev;  // r continues nr
+            if (!after && !before) continue;
+            if (after) nr.base = r.base, nr.dev = r.dev;
+            nr.bytes += r.bytes;
+            f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
+            merged = true;
+            break;
+        }
+    }
+    f.pinned.push_back(nr);
+}
+
+void transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, bool reset) {
+    if (by_shader) *by_shader = g_frames_by_shader.load();
+    if (by_dma) *by_dma = g_frames_by_dma.load();
+    if (pinned_ranges) {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        *pinned_ranges = static_cast<long long>(g_pins.size());
+    }
+    if (reset) g_frames_by_shader = 0, g_frames_by_dma = 0;
 }
 
 void release_pipeline(jinc_filter& f) {
@@ -339,6 +439,9 @@ void release_pipeline(jinc_filter& f) {
         release_group(g);
     }
     release_belts(f);
+    for (auto& p : f.pinned)  // this instance's references to the process-wide registry; the last one unregisters
+        if (!p.adopted) shared_pin_release(p.base);
+    f.pinned.clear();
 }
 
 void launch_open_group(jinc_filter& f) {
@@ -356,6 +459,7 @@ void drain_pipeline(jinc_filter& f) {
 void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host) {
     drain_pipeline(f);
     for (auto& g : f.groups) retire_group(f, g);
+    f.failed.clear();  // the explicit reset: failures of the previous configuration are not carried over
     depth = std::max(1, std::min(depth, kMaxPipelineDepth));
     // Frames per launch unless the caller says otherwise: half the frames in flight, so that one group computes while the
     // client still collects the previous one -- from 16 frames in flight on; below that single frames on a stream each
@@ -380,7 +484,7 @@ void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host
     f.register_host = register_host;
     if (!f.register_host) {  // ranges this instance pinned go; ranges the caller pinned stay known
         for (auto& p : f.pinned)
-            if (!p.adopted) (void)hipHostUnregister(p.base);
+            if (!p.adopted) shared_pin_release(p.base);
         f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(), [](const PinnedRange& r) { return !r.adopted; }), f.pinned.end());
     }
     ensure_belts(f);
@@ -441,7 +545,10 @@ void wait_frame(jinc_filter& f, long long ticket) {
             return;
         }
     }
-    // unknown or long completed ticket: nothing to wait for (its group buffer has been reused, which waited for it)
+    for (const auto& r : f.failed)
+        if (ticket >= r.first && ticket <= r.last) throw HipError(r.error);
+    if (ticket < 0 || ticket >= f.next_ticket) throw ArgError("JincResize: no frame was submitted under this ticket.");
+    // long completed ticket: nothing to wait for (its group buffer has been reused, which waited for it)
 }
 
 }  // namespace host

@@ -86,6 +86,11 @@ JINC_API int jinc_debug_valu_pair_probe(int device, int waves_per_simd, double *
 /* Interior kernel (of table 0) and frame count of the most recent kernel call of ANY filter instance in this process:
  * for tests that drive the plugin shell and cannot reach its jinc_filter handles. */
 JINC_API const char *jinc_debug_last_call(int *nframes);
+/* How the frames of the look-ahead pipeline left the device since the last reset, over ALL filter instances of this process:
+ * written by the shader straight into pinned host planes (every destination plane of the group was pinned) or by DMA copies
+ * (some plane was pageable); and how many host ranges the process-wide registry currently holds pinned.  For tests that
+ * drive the plugin shell: several instances that share the host's frame pool must all keep the shader path. */
+JINC_API int jinc_debug_transport_counts(long long *by_shader, long long *by_dma, long long *pinned_ranges, int reset);
 /* Border frame of exactly periodic plans: -1 (default) = by call size (strip kernels from ~5e9 taps per call on, one gather
  * launch below); 1 = rows and columns on the strip kernels, corners on the gather kernel; 2 = rows on the strip kernel,
  * columns and corners on the gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,8 +39,12 @@ struct Instance {
     int chroma_location = -1;     // value written to _ChromaLocation, -1: format without sub-sampled chroma
     int lookahead = 1;            // frames in flight (JINCRESIZE_LOOKAHEAD, default 1 = the reference's synchronous GetFrame)
     int group = 0;                // of them coalesced into one launch (JINCRESIZE_GROUP, default 0 = lookahead / 2)
-    std::vector<Pending> ring;
-    int next_submit = 0;          // next frame number to submit when access is sequential
+    std::vector<Pending> ring;    // slot k % lookahead holds frame k while it is in the window
+    int base = 0;                 // the window [base, base + lookahead): lowest frame not yet served
+    int next_submit = 0;          // frames of the window below this one have been submitted
+    int resubmit = -1;            // a frame of the window that was served already and is wanted again
+    std::mutex mutex;             // look-ahead state (hosts that honour MT_SERIALIZED never contend for it)
+    bool pin_frames = false;      // JINCRESIZE_PIN_FRAMES: the host's frame buffers are pinned in place
     std::string error;            // storage for fi->error
 };
 
@@ -91,58 +96,87 @@ AVS_VideoFrame* get_frame_sync(AVS_FilterInfo* fi, Instance* inst, int n) {
     return dst;
 }
 
-// Look-ahead form: frames n .. n+depth-1 are in flight on the filter's
-// pipeline, which coalesces consecutive frames into groups that share one set of kernel launches (batch kernels);
-// each GetFrame still returns exactly frame n.  Sequential access is assumed, anything else drains the ring first.
+// Look-ahead form: the frames of a WINDOW [base, base + depth) are in flight on
+// the filter's pipeline, which coalesces consecutive frames into groups that share one set of kernel launches (batch
+// kernels); each GetFrame still returns exactly frame n.
+//
+// Who calls: with look-ahead on, the filter answers MT_SERIALIZED (jinc_set_cache_hints), so under Prefetch(N) the host
+// keeps ONE instance and its N worker threads call it one at a time -- but not in frame order: thread 2 may ask for frame
+// 7 before thread 1 asks for frame 5.  The ring therefore serves any frame of the window in any order without draining:
+//   * frame k lives in slot k % depth for as long as it is in the window;
+//   * a served frame frees its slot; `base` moves up over served frames, and the window is refilled up to base + depth;
+//   * a frame is dropped (waited for, its references returned) only when the window moves past it: the client skipped it
+//     (SelectEven: the window trails the newest request by at most depth / 2) or jumped (a request outside the window
+//     moves the window there; frames of the old window that the new one still covers stay in flight);
+//   * a frame of the window that was served already and is asked for again (a cache miss upstream) is fetched again.
+// The instance mutex makes the function safe for hosts that ignore the MT mode; under MT_SERIALIZED it is uncontended.
 AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
+    std::lock_guard<std::mutex> lock(inst->mutex);
     const int depth = inst->lookahead;
     const int last = fi->vi.num_frames - 1;
-    Pending& want = inst->ring[n % depth];
+    auto slot = [&](int k) -> Pending& { return inst->ring[static_cast<size_t>(k % depth)]; };
     auto drop = [&](Pending& p) {  // wait for a frame in flight and give its references back
         jinc_filter_wait(inst->filter, p.ticket);
         avs_release_video_frame(p.src);
         avs_release_video_frame(p.dst);
         p = Pending{};
     };
-    if (want.frame != n) {  // seek: wait for and drop whatever is in flight
+    auto move_window = [&](int base) {  // frames outside [base, base + depth) leave the ring
         for (Pending& p : inst->ring)
-            if (p.frame >= 0) drop(p);
+            if (p.frame >= 0 && (p.frame < base || p.frame >= base + depth)) drop(p);
+        inst->base = base;
+    };
+    if (n < inst->base || n >= inst->base + depth) {  // a jump
+        move_window(n);
         inst->next_submit = n;
-    } else {
-        // frames the client skipped (requests n, n+2, ...: SelectEven, a frame-dropping client) are still pending in
-        // their slots; drop them now, before the submit loop below reuses those slots
-        for (Pending& p : inst->ring)
-            if (p.frame >= 0 && p.frame < n) drop(p);
+    } else if (slot(n).frame != n && n < inst->next_submit) {  // served before, wanted again
+        inst->resubmit = n;
     }
-    for (int k = std::max(inst->next_submit, n); k <= std::min(n + depth - 1, last); ++k) {
-        Pending& p = inst->ring[k % depth];
+    if (n - inst->base > depth / 2) move_window(n - depth / 2);  // a client that skips frames: trail it, do not stall
+    while (inst->base < n && slot(inst->base).frame != inst->base) ++inst->base;  // over frames served (or dropped) already
+
+    auto submit = [&](int k) -> int {  // 0 ok, 1 the child has no such frame, 2 failure (reported)
+        Pending& p = slot(k);
         p.src = avs_get_frame(fi->child, k);
-        if (!p.src) break;
+        if (!p.src) return 1;
         p.dst = avs_new_video_frame_p(fi->env, &fi->vi, p.src);
         const void* sp[4];
         void* dp[4];
         int spitch[4], dpitch[4];
         plane_pointers(&fi->vi, p.src, p.dst, sp, spitch, dp, dpitch);
-        if (jinc_filter_submit(inst->filter, sp, spitch, dp, dpitch, &p.ticket) != JINC_OK) {
-            AVS_VideoFrame* dst = p.dst;
-            AVS_VideoFrame* src = p.src;
-            p = Pending{};
-            return report(fi, inst, src, dst);
-        }
+        if (jinc_filter_submit(inst->filter, sp, spitch, dp, dpitch, &p.ticket) != JINC_OK) return 2;
         p.frame = k;
+        return 0;
+    };
+    auto failed = [&](int k) {
+        Pending& p = slot(k);
+        AVS_VideoFrame *dst = p.dst, *src = p.src;
+        p = Pending{};
+        return report(fi, inst, src, dst);
+    };
+    if (inst->resubmit >= 0) {
+        const int k = inst->resubmit, rc = submit(k);
+        inst->resubmit = -1;
+        if (rc == 2) return failed(k);
+    }
+    for (int k = std::max(inst->next_submit, inst->base); k <= std::min(inst->base + depth - 1, last); ++k) {
+        if (slot(k).frame == k) {  // still in flight from before a jump
+            inst->next_submit = k + 1;
+            continue;
+        }
+        const int rc = submit(k);
+        if (rc == 1) break;
+        if (rc == 2) return failed(k);
         inst->next_submit = k + 1;
     }
     if (inst->next_submit > last) jinc_filter_flush(inst->filter);  // end of the clip: the last frames leave without company
+    Pending& want = slot(n);
     if (want.frame != n) return nullptr;  // the child had no frame n
-    if (jinc_filter_wait(inst->filter, want.ticket) != JINC_OK) {
-        AVS_VideoFrame* dst = want.dst;
-        AVS_VideoFrame* src = want.src;
-        want = Pending{};
-        return report(fi, inst, src, dst);
-    }
+    if (jinc_filter_wait(inst->filter, want.ticket) != JINC_OK) return failed(n);
     AVS_VideoFrame* dst = want.dst;
     finish_frame(fi, inst, want.src, dst);
     want = Pending{};
+    while (inst->base < inst->next_submit && slot(inst->base).frame != inst->base) ++inst->base;
     return dst;
 }
 
@@ -151,9 +185,14 @@ AVS_VideoFrame* AVSC_CC jinc_get_frame(AVS_FilterInfo* fi, int n) {
     return inst->lookahead > 1 ? get_frame_lookahead(fi, inst, n) : get_frame_sync(fi, inst, n);
 }
 
-// ref :649-652: one instance per worker thread
-int AVSC_CC jinc_set_cache_hints(AVS_FilterInfo*, int cachehints, int) {
-    return cachehints == AVS_CACHE_GET_MTMODE ? 2 /* MT_MULTI_INSTANCE */ : 0;
+// ref :649-652: MT_MULTI_INSTANCE, one instance per worker thread -- the reference's answer, and this filter's at depth 1.
+// With look-ahead on, N instances under Prefetch(N) would each see every N-th frame or so and each prefetch the frames the
+// others compute; the answer is then MT_SERIALIZED: ONE instance sees the whole clip and keeps the GPU busy from its
+// window, the host's worker threads take turns at it (get_frame_lookahead says what that means for the order of requests).
+int AVSC_CC jinc_set_cache_hints(AVS_FilterInfo* fi, int cachehints, int) {
+    if (cachehints != AVS_CACHE_GET_MTMODE) return 0;
+    const Instance* inst = static_cast<const Instance*>(fi->user_data);
+    return inst && inst->lookahead > 1 ? 3 /* MT_SERIALIZED */ : 2 /* MT_MULTI_INSTANCE */;
 }
 
 void AVSC_CC jinc_free(AVS_FilterInfo* fi) {  // ref :632-647
@@ -251,13 +290,30 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
     if (const char* e = std::getenv("JINCRESIZE_CHROMALOC"))
         if (std::strcmp(e, "siting") == 0) jinc_filter_set_chroma_location_mode(filter, JINC_CHROMA_LOCATION_BY_SITING);
     inst->chroma_location = jinc_filter_chroma_location(filter);
+    // JINCRESIZE_SIMD_ORDER: by default every frame is the reference's opt=0 result, whatever `opt` says (the parity
+    // target).  "auto" reproduces what the reference binary would have computed for this call on this host instead: the
+    // summation order of the path its ladder picks (ref :897-899: opt=3 -> AVX-512; opt=2, or opt<0 on a CPU with AVX2 ->
+    // AVX2; opt=1, or opt<0 with SSE4.1 -> SSE4.1; else the C path).  "1" / "2" / "3" force one order.  Slow kernel.
+    if (const char* e = std::getenv("JINCRESIZE_SIMD_ORDER")) {
+        int order = 0;
+        if (std::strcmp(e, "auto") == 0) {
+            const int opt = (a.defined & JINC_ARG_OPT) ? a.opt : -1;
+            order = opt == 3 ? 3 : ((a.cpu_has_avx2 && opt < 0) || opt == 2) ? 2 : ((a.cpu_has_sse41 && opt < 0) || opt == 1) ? 1 : 0;
+        } else {
+            order = std::max(0, std::min(3, std::atoi(e)));
+        }
+        if (order) jinc_filter_set_simd_order(filter, order);
+    }
     if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("JINCRESIZE_GROUP")) inst->group = std::max(0, std::min(inst->lookahead, std::atoi(e)));
+    // JINCRESIZE_PIN_FRAMES=1: the host's frame buffers are pinned in place (process-wide registry in the library: the
+    // instances of a script share the host's frame pool) so that copies are asynchronous and results travel by the shader
+    if (const char* e = std::getenv("JINCRESIZE_PIN_FRAMES")) inst->pin_frames = std::atoi(e) != 0;
     if (inst->lookahead > 1) {
-        const char* reg = std::getenv("JINCRESIZE_PIN_FRAMES");
-        if (jinc_filter_set_pipeline_group(filter, inst->lookahead, inst->group, reg && std::atoi(reg) != 0) != JINC_OK) inst->lookahead = 1;
+        if (jinc_filter_set_pipeline_group(filter, inst->lookahead, inst->group, inst->pin_frames) != JINC_OK) inst->lookahead = 1;
         inst->ring.resize(static_cast<size_t>(inst->lookahead));
     }
+    if (inst->lookahead == 1 && inst->pin_frames) jinc_filter_set_pipeline(filter, 1, 1);
 
     jinc_video_info out_vi;
     jinc_filter_output_info(filter, &out_vi);  // ref :791-792

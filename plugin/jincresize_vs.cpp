@@ -178,6 +178,18 @@ void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* c
     if (const char* e = std::getenv("JINCRESIZE_CHROMALOC"))
         if (std::strcmp(e, "siting") == 0) jinc_filter_set_chroma_location_mode(filter, JINC_CHROMA_LOCATION_BY_SITING);
     d->chroma_location = jinc_filter_chroma_location(filter);
+    // JINCRESIZE_SIMD_ORDER=auto | 1 | 2 | 3: as in the AviSynth shell -- the summation order of the path the reference's
+    // ladder would pick for this `opt` on this CPU (ref :897-899) instead of the opt=0 result; default off
+    if (const char* e = std::getenv("JINCRESIZE_SIMD_ORDER")) {
+        int order = 0;
+        if (std::strcmp(e, "auto") == 0) {
+            const int opt = (final_args.defined & JINC_ARG_OPT) ? final_args.opt : -1;
+            order = opt == 3 ? 3 : ((a.cpu_has_avx2 && opt < 0) || opt == 2) ? 2 : ((a.cpu_has_sse41 && opt < 0) || opt == 1) ? 1 : 0;
+        } else {
+            order = std::max(0, std::min(3, std::atoi(e)));
+        }
+        if (order) jinc_filter_set_simd_order(filter, order);
+    }
     d->planes = vi->format.numPlanes;
     d->vi = *vi;
     jinc_video_info out_vi;

