@@ -89,23 +89,85 @@ jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end);
 // ewa_periodic_quad_kernel's coefficient pairs for 2x up-scales whose two phases per axis share their window origin
 // (filter sizes 7 and 9): quad[ly][q][8 or 10 pairs][p] = (set(p = 0, q), set(p = 1, q))[ly][lx]; a kernel row of one q is 16
 // dwords (fs 7: one s_load_dwordx16, the eighth pair is padding) or 20 (fs 9), the two q of a kernel row are adjacent.
-void attach_quad(const jinc::PlanePlan& p, DeviceTable& t) {
-    jinc::PeriodicArgs& pa = t.periodic;
-    if (!t.use_periodic || (p.fs != 7 && p.fs != 9) || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] ||
+// `sets`: the four phase sets, FS x FS floats each, phase q * 2 + p (the plan's, or their trimmed copies).
+void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vector<const float*>& sets) {
+    if (!t.use_periodic || (FS != 6 && FS != 7 && FS != 9) || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] ||
         pa.start_y[0] != pa.start_y[1])
         return;
-    const int FS = p.fs, PR = FS == 7 ? 8 : 10;  // pairs per (kernel row, q), padded: 16 / 20 dwords
+    const int PR = FS == 9 ? 10 : 8;  // pairs per (kernel row, q), padded: 16 / 20 dwords
     std::vector<float> q(static_cast<size_t>(2) * FS * PR * 2, 0.f);
     for (int qy = 0; qy < 2; ++qy)
         for (int ly = 0; ly < FS; ++ly)
             for (int lx = 0; lx < FS; ++lx)
                 for (int px = 0; px < 2; ++px)
-                    q[((static_cast<size_t>(ly) * 2 + qy) * PR + lx) * 2 + px] = p.set_ptr(pa.set[qy * 2 + px])[ly * FS + lx];
+                    q[((static_cast<size_t>(ly) * 2 + qy) * PR + lx) * 2 + px] = sets[static_cast<size_t>(qy * 2 + px)][ly * FS + lx];
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, q.size() * sizeof(float)), "hipMalloc(quad coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table
     hip_check(hipMemcpy(dev, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice), "quad coefficient upload");
     pa.quad = static_cast<const float*>(dev);
+}
+
+// Trimmed support of the periodic interior (integer planes).  The reference's window is filter_size x filter_size taps, but
+// the EWA disc does not fill it: taps beyond the radius carry the coefficient 0.0f (LUT index >= samples, ref :277-281), for
+// the 2x up-scale with tap 3 the whole first kernel row and column of all four phase sets.  A tap whose coefficient is zero
+// contributes float(sample) * 0 = +-0 to a chain that starts at +0 and therefore is never -0: r + (+-0) == r bit for bit, so
+// leaving the tap out is exact -- for FINITE samples, which is why this is done for 8 ... 16-bit planes only (a float
+// sample may be an infinity or a NaN, whose product with 0 is a NaN the reference propagates).  Here: the bounding box of
+// the non-zero coefficients over the interior's phase sets, squared up; the kernels of the periodic family then run with
+// filter size trim_fs on copies of the sets cut to the box, window origins moved by the box's corner.
+void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
+    t.trim_fs = 0;
+    if (!t.use_periodic || !integer_samples) return;
+    static const bool off = [] {
+        const char* e = std::getenv("JINC_TRIM");  // A/B knob: JINC_TRIM=0 keeps the full window
+        return e && std::atoi(e) == 0;
+    }();
+    if (off) return;
+    const jinc::PeriodicArgs& pa = t.periodic;
+    const int fs = p.fs, nphase = pa.px * pa.py;
+    int r0 = fs, r1 = -1, c0 = fs, c1 = -1;
+    for (int ph = 0; ph < nphase; ++ph) {
+        const float* s = p.set_ptr(pa.set[ph]);
+        for (int ly = 0; ly < fs; ++ly)
+            for (int lx = 0; lx < fs; ++lx)
+                if (s[ly * fs + lx] != 0.f) r0 = std::min(r0, ly), r1 = std::max(r1, ly), c0 = std::min(c0, lx), c1 = std::max(c1, lx);
+    }
+    if (r1 < 0) return;  // nothing but zeros: leave it to the full window
+    const int n = std::max(3, std::max(r1 - r0 + 1, c1 - c0 + 1));
+    if (n >= fs) return;
+    r0 = std::min(r0, fs - n);
+    c0 = std::min(c0, fs - n);
+    const int row = (n + 3) & ~3;  // floats per coefficient row on the device, as upload_table
+    std::vector<float> cut(static_cast<size_t>(nphase) * n * row, 0.f), dense(static_cast<size_t>(nphase) * n * n, 0.f);
+    for (int ph = 0; ph < nphase; ++ph) {
+        const float* s = p.set_ptr(pa.set[ph]);
+        for (int ly = 0; ly < n; ++ly)
+            for (int lx = 0; lx < n; ++lx) {
+                const float c = s[(r0 + ly) * fs + (c0 + lx)];
+                cut[(static_cast<size_t>(ph) * n + ly) * row + lx] = c;
+                dense[(static_cast<size_t>(ph) * n + ly) * n + lx] = c;
+            }
+    }
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, cut.size() * sizeof(float)), "hipMalloc(trimmed coefficient sets)");
+    t.lane_blobs.push_back(dev);  // freed with the table
+    hip_check(hipMemcpy(dev, cut.data(), cut.size() * sizeof(float), hipMemcpyHostToDevice), "trimmed coefficient upload");
+    jinc::PeriodicArgs tr = pa;
+    tr.coeffs = static_cast<const float*>(dev);
+    tr.quad = nullptr;
+    for (int ph = 0; ph < nphase; ++ph) tr.set[ph] = ph;
+    for (int q = 0; q < pa.px; ++q) tr.start_x[q] = pa.start_x[q] + c0;
+    for (int q = 0; q < pa.py; ++q) tr.start_y[q] = pa.start_y[q] + r0;
+    tr.min_sx = pa.min_sx + c0;
+    tr.min_sy = pa.min_sy + r0;
+    t.periodic_trim = tr;
+    t.trim_fs = n;
+    if (nphase == 4) {
+        std::vector<const float*> sets;
+        for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * n * n);
+        attach_quad(t, t.periodic_trim, n, sets);
+    }
 }
 
 // Decides how the output plane is split between the periodic kernel and the gather kernel.
@@ -507,7 +569,12 @@ void init_device(jinc_filter& f, int device) {
     for (size_t i = 0; i < f.plans.size(); ++i) {
         upload_table(f.plans[i], f.tables[i], f.stream);
         plan_launches(f.plans[i], f.tables[i]);
-        attach_quad(f.plans[i], f.tables[i]);
+        if (f.tables[i].use_periodic && f.tables[i].periodic.px * f.tables[i].periodic.py == 4) {
+            std::vector<const float*> sets;
+            for (int ph = 0; ph < 4; ++ph) sets.push_back(f.plans[i].set_ptr(f.tables[i].periodic.set[ph]));
+            attach_quad(f.tables[i], f.tables[i].periodic, f.plans[i].fs, sets);
+        }
+        trim_periodic(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
         plan_quasi(f.plans[i], f.tables[i]);
         plan_direct(f.plans[i], f.tables[i]);
         plan_runs(f.plans[i], f.tables[i]);

@@ -54,6 +54,10 @@ struct Rules {
     static constexpr long long kHalfTileMaxWorkgroups = 6144;
     // fs-9 quad form (ewa_periodic_quad9_kernel) below this many full-tile workgroups per launch (C4: one frame per call)
     static constexpr long long kQuad9MaxWorkgroups = 4096;
+    // two-periods-per-lane quad form on the trimmed 6 x 6 support from this many half-height workgroups per launch on
+    static constexpr long long kQuad2MinWorkgroups = 256;
+    // ... and its half-height tiles (24 period-rows) below this many full-tile workgroups per launch
+    static constexpr long long kQuad2HalfTileMaxWorkgroups = 3072;
     // fs-7 quad form from this many periods (2 x 2 pixels each) per plane on: 1080p -> 4K has 2.05 M, 360p -> 720p 0.22 M
     static constexpr long long kQuadMinPeriods = 1000000;
     // workgroups a quasi-periodic launch aims for when it splits a tile's phases (fs 9 tiles cost more to stage)
@@ -257,10 +261,20 @@ struct Choice {
         return !wants_direct(t, i);
     }
     // quad form of the periodic kernel (2x up-scales whose phases share their window origin), where it measured ahead
+    // The periodic family on the trimmed support (integer planes whose phase sets have a zero rim; device_plan.cpp
+    // trim_periodic): the automatic choice wherever it exists; kernel modes 5 / 6 (the fs-7 packed A/B variant) and 15
+    // (= the automatic choice on the full window, for A/B and tests: jinc_filter::full_window) keep the reference's window.
+    bool trimmed(const DeviceTable& t) const { return t.trim_fs > 0 && !f.full_window && f.kernel_mode != 5 && f.kernel_mode != 6; }
+    const jinc::PeriodicArgs& periodic_args(const DeviceTable& t) const { return trimmed(t) ? t.periodic_trim : t.periodic; }
+    int periodic_fs(const DeviceTable& t) const { return trimmed(t) ? t.trim_fs : t.plan.fs; }
     bool quad_chosen(const DeviceTable& t) const {
-        if (!t.periodic.quad) return false;
+        if (!periodic_args(t).quad) return false;
         if (f.kernel_mode == 13) return true;
         if (f.kernel_mode != 0) return false;
+        if (periodic_fs(t) == 6) {  // two periods per lane on the 6 x 6 support: tiles of 128 x 48 periods (24 rows on small calls)
+            const long long wgs6 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 23) / 24) * nframes;
+            return wgs6 >= Rules::kQuad2MinWorkgroups;
+        }
         const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
         // (fs 7: large planes only -- on 1280 x 720 the border kernels beside the denser interior become the step's tail:
         // C1 at 256 frames 492 -> 465 Gpix/s)
@@ -432,10 +446,10 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
     const bool periodic = !direct && !quasi && c.wants_periodic(t);
     t.last_kernel = direct     ? "ewa_direct_kernel"
                     : quasi    ? "ewa_quasi_kernel"
-                    : periodic ? (c.quad_chosen(t) ? "ewa_periodic_quad_kernel"
+                    : periodic ? (c.quad_chosen(t) ? (c.periodic_fs(t) == 6 ? "ewa_periodic_quad2_kernel" : "ewa_periodic_quad_kernel")
                                   : (f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
-                                  : (f.kernel_mode == 3 || (t.plan.fs != 7 && t.plan.fs != 9)) ? "ewa_periodic_rows_kernel"
-                                                                                                : "ewa_periodic_kernel")
+                                  : (f.kernel_mode == 3 || c.periodic_fs(t) < 6 || c.periodic_fs(t) > 9) ? "ewa_periodic_rows_kernel"
+                                                                                                          : "ewa_periodic_kernel")
                                : "ewa_gather_kernel";
     if (direct || periodic || quasi) {
         // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
@@ -504,17 +518,24 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 // Small calls (single frames, short batches) take the window kernels' half-height tiles: twice the
                 // workgroups for a launch that does not fill the chip (C2, one frame: 600 workgroups on 1536 slots,
                 // kernel 27.2 -> 22.3 us; 4 frames: 323 -> 354 Gpix/s); long batches keep the full tiles (+2 %).
-                if (f.kernel_mode == 0 && (t.plan.fs == 7 || t.plan.fs == 9)) {
-                    const int rows = t.plan.fs * (t.plan.fs == 7 ? 8 : 9);  // period-rows of a full tile
+                const int pfs = c.periodic_fs(t);
+                if (f.kernel_mode == 0 && pfs >= 6 && pfs <= 9) {
+                    const int rows = pfs * (pfs <= 7 ? 8 : 9);  // period-rows of a full tile
                     const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + rows - 1) / rows) * nframes;
                     if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
                 }
                 if (quad) {
-                    const long long quad_wgs = static_cast<long long>((t.periodic.ni + 63) / 64) *
-                                               ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
-                    if (quad_wgs < Rules::kHalfTileMaxWorkgroups) variant = 6;
+                    const int cols = pfs == 6 ? 128 : 64;  // periods per tile row
+                    const long long quad_wgs = static_cast<long long>((t.periodic.ni + cols - 1) / cols) * ((t.periodic.nj + 8 * pfs - 1) / (8 * pfs)) * nframes;
+                    if (quad_wgs < (pfs == 6 ? Rules::kQuad2HalfTileMaxWorkgroups : Rules::kHalfTileMaxWorkgroups)) variant = 6;
+                    static const int force_rg = [] {  // A/B knob: JINC_QUAD_RG=8 / 4 forces full / half-height tiles of the quad forms
+                        const char* e = std::getenv("JINC_QUAD_RG");
+                        return e ? std::atoi(e) : 0;
+                    }();
+                    if (force_rg == 8) variant = 5;
+                    if (force_rg == 4) variant = 6;
                 }
-                return jinc::launch_periodic(t.periodic, t.plan.fs, io, s, variant);
+                return jinc::launch_periodic(c.periodic_args(t), pfs, io, s, variant);
             });
     } else {
         timed(f.ev_gather, plane_stream, "gather kernel launch",

@@ -370,12 +370,19 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
     if (t.use_runs && f->direct_premise && (m == 14 || (m == 0 && t.plan.fs >= 9))) return "ewa_direct_runs_kernel";
     if (quasi) return "ewa_quasi_kernel";
     if (periodic) {
-        const int fs = t.plan.fs;
-        if (m == 5 || m == 6) return fs == 7 ? "ewa_periodic_pk_kernel" : "ewa_periodic_kernel";
-        if (m == 3 || (fs != 7 && fs != 9)) return "ewa_periodic_rows_kernel";
+        const int fs = (t.trim_fs > 0 && !f->full_window && m != 5 && m != 6) ? t.trim_fs : t.plan.fs;
+        if (m == 5 || m == 6) return t.plan.fs == 7 ? "ewa_periodic_pk_kernel" : "ewa_periodic_kernel";
+        if (m == 3 || fs < 6 || fs > 9) return "ewa_periodic_rows_kernel";
         return "ewa_periodic_kernel";
     }
     return "ewa_gather_kernel";
+}
+
+int jinc_filter_periodic_support(const jinc_filter* f, int table) {
+    if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return 0;
+    const DeviceTable& t = f->tables[table];
+    if (!t.use_periodic) return 0;
+    return t.trim_fs > 0 && !f->full_window ? t.trim_fs : t.plan.fs;
 }
 
 int jinc_filter_set_simd_order(jinc_filter* f, int order) {
@@ -519,8 +526,9 @@ int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 14) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
-    f->kernel_mode = mode;
+    if (!f || mode < 0 || mode > 15) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    f->full_window = mode == 15;  // 15 = the automatic choice, but on the reference's full window (no trimmed support)
+    f->kernel_mode = mode == 15 ? 0 : mode;
     return JINC_OK;
 }
 

@@ -44,6 +44,10 @@ struct DeviceTable {
     jinc::DevicePlan plan;
     bool use_periodic = false;
     jinc::PeriodicArgs periodic;
+    // The same interior on the TRIMMED support (integer planes only; device_plan.cpp trim_periodic): trim_fs x trim_fs taps
+    // per sample, the bounding box of the phase sets' non-zero coefficients; 0 = the sets have no zero rim (or float samples).
+    int trim_fs = 0;
+    jinc::PeriodicArgs periodic_trim;
     bool use_quasi = false;  // quasi-periodic interior kernel (affine window origins, drifting classes)
     jinc::QuasiArgs quasi;
     jinc::RectList border_rects;  // gather work when the periodic kernel covers the interior
@@ -163,6 +167,7 @@ struct jinc_filter {
     jinc::JincLut lut;
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
+    bool full_window = false;  // kernel mode 15: no trimmed support (the reference's full window everywhere)
     int border_strips = -1;  // border frame of exactly periodic plans: -1 by call size (dispatch.cpp Rules), 1 strip kernels, 2 rows only, 0 gather kernel
     bool direct_premise = false;  // buffer_range_check_covers_soffset(device) == 1
     int simd_order = 0;  // 0: opt=0 results (default); 1 / 2 / 3: summation order of the reference's SSE4.1 / AVX2 / AVX-512 path

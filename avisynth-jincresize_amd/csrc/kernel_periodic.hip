@@ -701,6 +701,208 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
 }
 
 // ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, quad form on a trimmed 6 x 6 support, two periods per lane
+// ------------------------------------------------------------------------------------------------
+// Integer planes whose coefficient sets carry exact zeros along the window's edge run on the trimmed support (host:
+// device_plan.cpp, trim_periodic): the 2x up-scale with tap 3 has filter size 7, but the first kernel row and column of all
+// four phase sets are 0.0f (the EWA disc of radius 3.24 spans six samples at these phases), and a tap whose coefficient is
+// zero adds +0 to a chain that is never -0 -- leaving it out is exact for finite samples, which integer samples are.
+// 36 taps per sample instead of 49.
+// The lane mapping changes with it: a lane owns TWO horizontally adjacent periods -- 4 x 2 output samples from ONE
+// 6 x 7 register window (the periods' windows are one source column apart).  Against ewa_periodic_quad_kernel, per output
+// sample: half the coefficient fetches (one SGPR pair feeds both periods: the scalar cache delivered two s_load_dwordx16
+// per 784 issue cycles and wave there, now two per 1152), window rows as four aligned ds_read_b64 per eight samples
+// instead of seven ds_read_b32 per four, four independent chains per lane interleaved two by two, and the four 8-bit
+// samples of a row leave as one dword store.  Every chain still meets its taps in (ly, lx) order, multiply and add un-fused.
+// Coefficient layout: as the fs-7 quad form, quad[ly][q][8 pairs][p] with pairs 6 and 7 unused.
+template <int RG>
+struct Quad2Cfg {
+    static constexpr int FS = 6;
+    static constexpr int kPeriodsPerLane = 2;
+    static constexpr int kTileCols = 64 * kPeriodsPerLane;  // periods per tile row
+    static constexpr int kTileRows = FS * RG;               // period-rows per tile
+    static constexpr int kLdsCols = kTileCols + FS;         // lane 63 reads columns 126 .. 133
+    static constexpr int kLdsPitch = 136;                   // even: every lane's row segment is 8-byte aligned
+    static constexpr int kLdsRows = kTileRows + FS - 1;
+};
+
+// One kernel row of one q for both periods of a lane: window pairs w0..w3 = source columns 0..7 of the row (period A
+// reads columns 0..5, period B columns 1..6), coefficient pairs c0..c5 = (p = 0, p = 1) of taps 0..5.
+__device__ __forceinline__ void quad2_row6(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c0, f32x2 c1, f32x2 c2,
+                                           f32x2 c3, f32x2 c4, f32x2 c5) {
+    f32x2 ta, tb;
+#define JINC_LO(T, W, C) "v_pk_mul_f32 " T ", " W ", " C " op_sel_hi:[0,1]\n\t"                 /* sample = low half of the pair */
+#define JINC_HI(T, W, C) "v_pk_mul_f32 " T ", " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\t"   /* sample = high half */
+#define JINC_ADD2 "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+    asm(JINC_LO("%2", "%4", "%8") JINC_HI("%3", "%4", "%8") JINC_ADD2      // tap 0: A column 0, B column 1
+        JINC_HI("%2", "%4", "%9") JINC_LO("%3", "%5", "%9") JINC_ADD2      // tap 1: A 1, B 2
+        JINC_LO("%2", "%5", "%10") JINC_HI("%3", "%5", "%10") JINC_ADD2    // tap 2: A 2, B 3
+        JINC_HI("%2", "%5", "%11") JINC_LO("%3", "%6", "%11") JINC_ADD2    // tap 3: A 3, B 4
+        JINC_LO("%2", "%6", "%12") JINC_HI("%3", "%6", "%12") JINC_ADD2    // tap 4: A 4, B 5
+        JINC_HI("%2", "%6", "%13") JINC_LO("%3", "%7", "%13")              // tap 5: A 5, B 6
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+        : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+#undef JINC_LO
+#undef JINC_HI
+#undef JINC_ADD2
+}
+
+// Window slot SLOT <- eight source columns of one tile row (four aligned ds_read_b64).
+template <int SLOT>
+__device__ __forceinline__ void quad2_load_row(f32x2 (&w)[24], const float* p) {
+    const f32x2* p2 = reinterpret_cast<const f32x2*>(p);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) w[4 * SLOT + m] = p2[m];
+}
+
+// One output row pair of both periods: acc[0] / acc[1] = period A / B at q = 0, acc[2] / acc[3] at q = 1.  Coefficient pairs of
+// kernel row ly + 1 are requested before the taps of row ly are issued, as in quad_pixel7.
+template <int U>
+__device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[24], const JINC_CONSTANT f32x2* quad) {
+    f32x2 ca[16], cb[16];
+    quad_fetch(ca, quad, 0);
+#define JINC_QUAD2_STEP(LY, CUR, NEXT)                                                                                        \
+    if constexpr (LY < 5) quad_fetch(NEXT, quad, LY + 1);                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                         \
+    quad_arrived(CUR);                                                                                                         \
+    {                                                                                                                          \
+        constexpr int S = 4 * ((U + LY) % 6);                                                                                  \
+        quad2_row6(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5]);        \
+        quad2_row6(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13]);    \
+    }                                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+    JINC_QUAD2_STEP(0, ca, cb)
+    JINC_QUAD2_STEP(1, cb, ca)
+    JINC_QUAD2_STEP(2, ca, cb)
+    JINC_QUAD2_STEP(3, cb, ca)
+    JINC_QUAD2_STEP(4, ca, cb)
+    JINC_QUAD2_STEP(5, cb, ca)
+#undef JINC_QUAD2_STEP
+}
+
+// The four (or, for the lane that holds the plane's last odd period, two) samples of one output row of a lane: one store.
+template <typename T>
+__device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset, uint32_t soffset, f32x2 a, f32x2 b, float peak, bool b_ok) {
+    if constexpr (std::is_same_v<T, float>) {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        if (b_ok) {
+            const u32x4 v = {__builtin_bit_cast(uint32_t, a.x), __builtin_bit_cast(uint32_t, a.y), __builtin_bit_cast(uint32_t, b.x),
+                             __builtin_bit_cast(uint32_t, b.y)};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rsrc, voffset, soffset, 0);
+        }
+    } else if constexpr (std::is_same_v<T, uint8_t>) {
+        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0u, 0u);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1u, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(b.x, 2u, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(b.y, 3u, w);
+        if (b_ok) __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, voffset, soffset, 0);
+        else __builtin_amdgcn_raw_buffer_store_b16(static_cast<uint16_t>(w), rsrc, voffset, soffset, 0);
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const uint32_t lo = round_sample(a.x, peak) | (round_sample(a.y, peak) << 16);
+        if (b_ok) {
+            const u32x2 v = {lo, round_sample(b.x, peak) | (round_sample(b.y, peak) << 16)};
+            __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voffset, soffset, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(lo, rsrc, voffset, soffset, 0);
+        }
+    }
+}
+
+template <typename T, int RG>
+__global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = Quad2Cfg<RG>;
+    constexpr int FS = Cfg::FS;
+    static_assert(RG % 4 == 0, "the four waves of a workgroup take RG / 4 row groups each");
+    __shared__ __attribute__((aligned(16))) float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * Cfg::kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + 4 * i;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+            }
+        }
+    }
+    __syncthreads();
+    const int ia = i0 + 2 * lane;  // the lane's first period
+    if (ia >= a.ni) return;        // no barrier below
+    const bool b_ok = ia + 1 < a.ni;
+
+    const JINC_CONSTANT f32x2* quad = (const JINC_CONSTANT f32x2*)(a.quad);
+    // both phases of an axis share the window origin, which is also the tile's (host: quad != nullptr only then)
+    const float* base = tile + 2 * lane;
+    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+    const uint32_t xoff = static_cast<uint32_t>(a.ix0 + 2 * ia) * static_cast<uint32_t>(sizeof(T));
+
+    constexpr int kGroupsPerWave = RG / 4;
+    const int g_first = wave * kGroupsPerWave;
+    if (j0 + g_first * FS >= a.nj) return;  // wave-uniform: bottom tiles
+    f32x2 win[24];
+    {
+        const float* wb = base + (g_first * FS) * Cfg::kLdsPitch;
+        quad2_load_row<0>(win, wb + 0 * Cfg::kLdsPitch);
+        quad2_load_row<1>(win, wb + 1 * Cfg::kLdsPitch);
+        quad2_load_row<2>(win, wb + 2 * Cfg::kLdsPitch);
+        quad2_load_row<3>(win, wb + 3 * Cfg::kLdsPitch);
+        quad2_load_row<4>(win, wb + 4 * Cfg::kLdsPitch);
+    }
+    for (int g = g_first; g < g_first + kGroupsPerWave; ++g) {
+        if (j0 + g * FS >= a.nj) break;  // wave-uniform
+        const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#define JINC_QUAD2_ROW(U)                                                                                          \
+    {                                                                                                              \
+        quad2_load_row<(U + FS - 1) % FS>(win, gbase + (U + FS - 1) * Cfg::kLdsPitch);                              \
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                            \
+        uint32_t zero;                                                                                              \
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
+        quad2_pixel6<U>(acc, win, quad + zero);                                                                     \
+        const int j = j0 + g * FS + U;                                                                              \
+        if (j < a.nj) {                                                                                             \
+            const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
+            store_quad_buf<T>(drsrc, xoff, so, acc[0], acc[1], io.peak, b_ok);                                      \
+            store_quad_buf<T>(drsrc, xoff, so + static_cast<uint32_t>(io.dst_pitch), acc[2], acc[3], io.peak, b_ok); \
+        }                                                                                                           \
+    }
+        JINC_QUAD2_ROW(0) JINC_QUAD2_ROW(1) JINC_QUAD2_ROW(2) JINC_QUAD2_ROW(3) JINC_QUAD2_ROW(4) JINC_QUAD2_ROW(5)
+#undef JINC_QUAD2_ROW
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Periodic interior kernel, row-streamed form (any filter size, used for fs > 9)
 // ------------------------------------------------------------------------------------------------
 // Same phase-uniform idea as ewa_periodic_kernel (one phase per wave => coefficients in SGPRs), but
@@ -886,6 +1088,14 @@ int launch_periodic_quad9_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream
     return static_cast<int>(hipGetLastError());
 }
 
+template <typename T, int RG>
+int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = Quad2Cfg<RG>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <typename T, int FS, int KC>
 int launch_rows_k(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = RowsCfg<FS, KC>;
@@ -905,6 +1115,8 @@ int launch_rows_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream)
 
 template <typename T>
 int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
+    if ((variant == 5 || variant == 6) && fs == 6 && pa.quad)  // trimmed support, two periods per lane: 5 = tiles of 8 row groups, 6 = of 4
+        return variant == 5 ? launch_periodic_quad2_t<T, 8>(pa, io, stream) : launch_periodic_quad2_t<T, 4>(pa, io, stream);
     if ((variant == 5 || variant == 6) && fs == 7 && pa.quad)  // quad form: 5 = tiles of 8 row groups, 6 = of 4 (small calls)
         return variant == 5 ? launch_periodic_quad_t<T, 8>(pa, io, stream) : launch_periodic_quad_t<T, 4>(pa, io, stream);
     if ((variant == 5 || variant == 6) && fs == 9 && pa.quad)
@@ -913,18 +1125,29 @@ int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStr
     if (variant == 4 && fs == 7) return launch_periodic_pk_t<T, 7, 8>(pa, io, stream);
     if (variant == 2 && fs == 7) return launch_periodic_t<T, 7, 4>(pa, io, stream);
     if (variant == 2 && fs == 9) return launch_periodic_t<T, 9, 6>(pa, io, stream);
+    if (variant == 2 && fs == 6) return launch_periodic_t<T, 6, 4>(pa, io, stream);
+    if (variant == 2 && fs == 8) return launch_periodic_t<T, 8, 5>(pa, io, stream);
     if (variant == 1) {
         if (fs == 7) return launch_rows_t<T, 7>(pa, io, stream);
         if (fs == 9) return launch_rows_t<T, 9>(pa, io, stream);
+        if (fs == 6) return launch_rows_t<T, 6>(pa, io, stream);
+        if (fs == 8) return launch_rows_t<T, 8>(pa, io, stream);
     }
-    switch (fs) {
+    switch (fs) {  // (even sizes: trimmed supports of integer planes, device_plan.cpp trim_periodic)
         case 3: return launch_rows_t<T, 3>(pa, io, stream);
+        case 4: return launch_rows_t<T, 4>(pa, io, stream);
         case 5: return launch_rows_t<T, 5>(pa, io, stream);
+        case 6: return launch_periodic_t<T, 6>(pa, io, stream);
         case 7: return launch_periodic_t<T, 7>(pa, io, stream);
+        case 8: return launch_periodic_t<T, 8>(pa, io, stream);
         case 9: return launch_periodic_t<T, 9>(pa, io, stream);
+        case 10: return launch_rows_t<T, 10>(pa, io, stream);
         case 11: return launch_rows_t<T, 11>(pa, io, stream);
+        case 12: return launch_rows_t<T, 12>(pa, io, stream);
         case 13: return launch_rows_t<T, 13>(pa, io, stream);
+        case 14: return launch_rows_t<T, 14>(pa, io, stream);
         case 15: return launch_rows_t<T, 15>(pa, io, stream);
+        case 16: return launch_rows_t<T, 16>(pa, io, stream);
         case 17: return launch_rows_t<T, 17>(pa, io, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }

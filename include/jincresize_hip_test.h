@@ -58,8 +58,15 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * 128 frames per workgroup; the automatic choice for whole groups of 128 frames, filter sizes 5 and 7) for the whole batch
  * wherever it is configured, 13 = the quad form of the periodic kernel (2x up-scales, filter sizes 7 and 9) wherever it is
  * configured, 14 = the runs form of the direct kernel (drifting plans cut into rectangles of one coefficient set each; the
- * automatic choice for drifting plans with filter sizes above 9) wherever the plan has runs. */
+ * automatic choice for drifting plans with filter sizes above 9) wherever the plan has runs, 15 = the automatic choice on the
+ * reference's full window: integer planes otherwise run the periodic kernels on the TRIMMED support (the bounding box of
+ * the phase sets' non-zero coefficients -- 6 x 6 of 7 x 7 for the 2x up-scale with tap 3; leaving out taps whose coefficient is
+ * 0.0f is exact for finite samples). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
+/* Taps per axis the periodic interior kernels of `table` execute under the current kernel mode: the plan's filter size, or
+ * the side of the trimmed support on integer planes (kernel mode 15 switches trimming off); 0 when the table has no
+ * periodic interior or the instance has no device. */
+JINC_API int jinc_filter_periodic_support(const jinc_filter *f, int table);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
 JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);
 /* Name of the kernel that computed the interior of `table` in the most recent frame call (the choice depends on the

@@ -71,7 +71,7 @@ def _id(c):
     return f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}" + (f"_{extra}" if extra else "")
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "gather"])
+@pytest.mark.parametrize("mode", [0, 1, 15], ids=["auto", "gather", "full_window"])
 @pytest.mark.parametrize("case", SMALL_CASES, ids=_id)
 def test_get_frame_matches_oracle(gpu_pkg, O, case, mode):
     fmt, sw, sh, tw, th, kw = case
@@ -302,7 +302,7 @@ def test_integer_conversion_ties(gpu_pkg):
     assert np.array_equal(gpu_pkg.debug_convert(f, np.float32, 0.0).view(np.uint32), f.view(np.uint32))
 
 
-@pytest.mark.parametrize("mode", [3, 4, 5, 6, 7, 9], ids=["rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi", "direct"])
+@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6, 7, 9, 13, 15], ids=["window", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi", "direct", "quad", "full_window"])
 @pytest.mark.parametrize("fmt,sw,sh,tw,th", [("Y8", 640, 360, 1280, 720), ("Y16", 333, 211, 666, 422),
                                              ("Y32", 200, 150, 400, 300), ("YUV420P8", 258, 130, 516, 260),
                                              ("Y8", 100, 80, 400, 320)])
@@ -695,6 +695,12 @@ def test_randomised_arguments(gpu_pkg, O, seed, gen):
         f.set_border_strips(1)
         assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + " border strips")
         f.set_border_strips(-1)
+        # the periodic family on the trimmed support (integer planes) in each of its forms -- window, rows, quad -- and on the
+        # reference's full window (15)
+        for mode in (2, 3, 13, 15):
+            f.set_kernel_mode(mode)
+            assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + f" kernel mode {mode}")
+        f.set_kernel_mode(0)
     if any(f.plan_info(t).quasi for t in range(f.num_tables)):
         for mode in (7, 8, 10, 14):  # 14: the direct kernel's runs form wherever the plan has runs (fs >= 9)
             f.set_kernel_mode(mode)
@@ -748,9 +754,9 @@ def test_device_entry_rejects_bad_layouts(gpu_pkg):
     f.close()
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13],
-                         ids=["gather", "window", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_waterfall", "direct",
-                              "quasi_lane_coefficients", "quad"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13, 15],
+                         ids=["auto", "gather", "window", "rows", "window_rg4", "packed_rg4", "packed_rg8", "quasi_exact", "quasi_waterfall", "direct",
+                              "quasi_lane_coefficients", "quad", "full_window"])
 def test_every_kernel_reproduces_the_reference_crc_at_full_size(gpu_pkg, O, mode):
     """C2 at full size through every kernel family: the crc32 of the reference's own opt=0 output."""
     k = next(x for x in KAT["outputs"] if x["name"] == "C2")
@@ -832,3 +838,58 @@ def test_quad_form_of_the_periodic_kernel(gpu_pkg, O, case, frames):
         for k in range(frames):
             assert_planes_equal(got[k], of.get_frame(srcs[k], threads=4), f.out_dims(), what=_id(case) + f" frame {k}")
     f.close()
+
+
+@pytest.mark.parametrize("fmt,sw,sh,tw,th,kw,full,trimmed", [
+    ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 7, 6),            # C2: the first kernel row and column of all four phase sets are 0.0f
+    ("YUV420P16", 640, 360, 1280, 720, dict(tap=8), 17, 16),      # C3's geometry in small
+    ("Y16", 320, 180, 640, 360, dict(tap=4), 9, 8),
+    ("Y32", 320, 180, 640, 360, dict(tap=3), 7, 7),               # float samples: never trimmed (0 x inf = NaN must propagate)
+    ("RGBPS", 320, 180, 640, 360, dict(tap=4, blur=0.98), 9, 9),
+], ids=["C2_u8", "tap8_u16", "tap4_u16", "tap3_f32", "C4_f32_small"])
+def test_trimmed_support_is_what_runs_on_integer_planes_only(gpu_pkg, O, fmt, sw, sh, tw, th, kw, full, trimmed):
+    """Integer planes run the periodic kernels on the bounding box of the phase sets' non-zero coefficients; float planes keep
+    the reference's window.  Kernel mode 15 switches the trimming off.  Both are the oracle's result."""
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+    assert f.plan_info(0).filter_size == full
+    assert f.periodic_support(0) == trimmed
+    f.set_kernel_mode(15)
+    assert f.periodic_support(0) == full
+    f.set_kernel_mode(0)
+    if sw <= 640:
+        src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=99)
+        want = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw)).get_frame(src, threads=8)
+        for mode in (0, 13, 15):
+            f.set_kernel_mode(mode)
+            assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=f"{fmt} mode {mode}")
+    f.close()
+
+
+def test_zero_coefficient_taps_meet_extreme_integer_samples(gpu_pkg, O):
+    """The trimmed support leaves out taps whose coefficient is 0.0f.  All-zero, all-peak and alternating planes (sums that
+    are exactly 0, exactly peak, and cancel) must come out as the oracle computes them with every tap in place."""
+    for fmt, peak in (("Y8", 255), ("Y16", 65535), ("Y10", 1023)):
+        sw, sh, tw, th = 96, 64, 192, 128
+        of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+        f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+        assert f.periodic_support(0) == 6
+        base = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=5)
+        for kind in ("zeros", "peak", "checker", "columns"):
+            src = [p.copy() for p in base]
+            a = src[0]
+            if kind == "zeros":
+                a[:] = 0
+            elif kind == "peak":
+                a[:] = peak
+            elif kind == "checker":
+                a[:] = 0
+                a[::2, ::2] = peak
+                a[1::2, 1::2] = peak
+            else:
+                a[:] = 0
+                a[:, ::3] = peak
+            want = of.get_frame(src, threads=4)
+            for mode in (0, 2, 13, 15):
+                f.set_kernel_mode(mode)
+                assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=f"{fmt} {kind} mode {mode}")
+        f.close()

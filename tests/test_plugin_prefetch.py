@@ -100,6 +100,7 @@ def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, 
     pkg.transport_counts(reset=True)
     assert host.mock_clip_mt_mode(clip) == 3   # MT_SERIALIZED: one instance, the worker threads take turns
     seen = set()
+    stale = pkg.last_call()   # the single synchronous calls above left their record behind
     stop = threading.Event()
 
     def watch():   # which launches serve the requests (process-wide record of the most recent kernel call)
@@ -119,7 +120,7 @@ def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, 
     assert all(c[1] == loc for c in crcs.values())
     calls = [host.mock_source_calls_of_frame(src, n) for n in range(nframes)]
     assert calls[0] == 2 and all(c == 1 for c in calls[1:]), [(n, c) for n, c in enumerate(calls) if c != 1][:10]   # frame 0: + the property probe
-    served = {(name, k) for name, k in seen if name}
+    served = {(name, k) for name, k in seen if name} - {stale}
     assert served and all(name.startswith(kernels) and k == 16 for name, k in served), served
     by_shader, by_dma, _ = pkg.transport_counts()
     assert (by_shader, by_dma) == (nframes, 0)   # pinned in place: every group left by the shader
