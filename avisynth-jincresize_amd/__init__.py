@@ -80,7 +80,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_chroma_location", "jinc_filter_set_chroma_location_mode", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_runs", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_filter_periodic_support", "jinc_filter_set_pipeline",
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
@@ -148,6 +148,8 @@ def lib():
         L.jinc_debug_set_direct_shape.argtypes = [C.c_int]
         L.jinc_filter_set_simd_order.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_periodic_support.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_periodic_taps.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.jinc_filter_periodic_taps.restype = C.c_double
         L.jinc_debug_transport_counts.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
         L.jinc_shard_device.argtypes = [C.c_int, C.c_int]
         L.jinc_batch_create.argtypes = [C.POINTER(VideoInfo), C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
@@ -511,6 +513,10 @@ class Filter:
     def periodic_support(self, table: int = 0) -> int:
         """Taps per axis the periodic interior kernels execute (trimmed support on integer planes), 0: no periodic interior."""
         return int(lib().jinc_filter_periodic_support(self._h, int(table)))
+
+    def periodic_taps(self, table: int = 0, rows_kernel: bool = False) -> float:
+        """Taps per output sample the periodic interior kernels execute (0: no periodic interior)."""
+        return float(lib().jinc_filter_periodic_taps(self._h, int(table), int(bool(rows_kernel))))
 
     def interior_kernel(self, table: int = 0) -> str:
         return lib().jinc_filter_interior_kernel(self._h, int(table)).decode()

@@ -112,13 +112,15 @@ void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vect
 // the EWA disc does not fill it: taps beyond the radius carry the coefficient 0.0f (LUT index >= samples, ref :277-281), for
 // the 2x up-scale with tap 3 the whole first kernel row and column of all four phase sets.  A tap whose coefficient is zero
 // contributes float(sample) * 0 = +-0 to a chain that starts at +0 and therefore is never -0: r + (+-0) == r bit for bit, so
-// leaving the tap out is exact -- for FINITE samples, which is why this is done for 8 ... 16-bit planes only (a float
-// sample may be an infinity or a NaN, whose product with 0 is a NaN the reference propagates).  Here: the bounding box of
+// leaving the tap out is exact -- for FINITE samples.  8 ... 16-bit samples always are; a float sample may be an infinity
+// or a NaN, whose product with 0 is a NaN the reference propagates: float planes take the trimmed support frame by frame,
+// where a scan of the call's source planes found nothing but finite samples (dispatch.cpp, kernel_scan.hip).  Here: the bounding box of
 // the non-zero coefficients over the interior's phase sets, squared up; the kernels of the periodic family then run with
 // filter size trim_fs on copies of the sets cut to the box, window origins moved by the box's corner.
 void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
     t.trim_fs = 0;
-    if (!t.use_periodic || !integer_samples) return;
+    t.trim_needs_finite = !integer_samples;  // float planes: only frames without infinities / NaNs (dispatch.cpp, kernel_scan.hip)
+    if (!t.use_periodic) return;
     static const bool off = [] {
         const char* e = std::getenv("JINC_TRIM");  // A/B knob: JINC_TRIM=0 keeps the full window
         return e && std::atoi(e) == 0;
@@ -149,12 +151,36 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
                 dense[(static_cast<size_t>(ph) * n + ly) * n + lx] = c;
             }
     }
+    // per phase and kernel row: the zero coefficients in front of and behind the row's span (the disc's chord), the smaller of
+    // the two counts -- the rows kernel leaves that many taps out on either side (kernel_periodic.hip rows_kernel_row)
+    std::vector<int32_t> row_trim(static_cast<size_t>(nphase) * 32, 0);
+    if (n <= 32)
+        for (int ph = 0; ph < nphase; ++ph)
+            for (int ly = 0; ly < n; ++ly) {
+                const float* r = &dense[(static_cast<size_t>(ph) * n + ly) * n];
+                int lead = 0, trail = 0;
+                while (lead < n && r[lead] == 0.f) ++lead;
+                while (trail < n - lead && r[n - 1 - trail] == 0.f) ++trail;
+                row_trim[static_cast<size_t>(ph) * 32 + ly] = std::min(5, std::min(std::min(lead, trail), (n - 1) / 2));
+            }
+    {   // taps per sample the rows kernel executes with these spans (reports): it offers 0 .. 5 (n >= 12) or 0 .. 2 (n >= 6) taps
+        // per side, none below
+        const int widest = n >= 12 ? 5 : n >= 6 ? 2 : 0;
+        double taps = 0;
+        for (int ph = 0; ph < nphase; ++ph)
+            for (int ly = 0; ly < n; ++ly) taps += n - 2 * std::min(widest, n <= 32 ? row_trim[static_cast<size_t>(ph) * 32 + ly] : 0);
+        t.trim_rows_taps = taps / nphase;
+    }
+    const size_t cut_bytes = align_up(cut.size() * sizeof(float), 256);
     void* dev = nullptr;
-    hip_check(hipMalloc(&dev, cut.size() * sizeof(float)), "hipMalloc(trimmed coefficient sets)");
+    hip_check(hipMalloc(&dev, cut_bytes + row_trim.size() * sizeof(int32_t)), "hipMalloc(trimmed coefficient sets)");
     t.lane_blobs.push_back(dev);  // freed with the table
     hip_check(hipMemcpy(dev, cut.data(), cut.size() * sizeof(float), hipMemcpyHostToDevice), "trimmed coefficient upload");
+    hip_check(hipMemcpy(static_cast<char*>(dev) + cut_bytes, row_trim.data(), row_trim.size() * sizeof(int32_t), hipMemcpyHostToDevice),
+              "row trim upload");
     jinc::PeriodicArgs tr = pa;
     tr.coeffs = static_cast<const float*>(dev);
+    tr.row_trim = reinterpret_cast<const int32_t*>(static_cast<char*>(dev) + cut_bytes);
     tr.quad = nullptr;
     for (int ph = 0; ph < nphase; ++ph) tr.set[ph] = ph;
     for (int q = 0; q < pa.px; ++q) tr.start_x[q] = pa.start_x[q] + c0;

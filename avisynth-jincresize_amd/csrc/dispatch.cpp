@@ -54,10 +54,12 @@ struct Rules {
     static constexpr long long kHalfTileMaxWorkgroups = 6144;
     // fs-9 quad form (ewa_periodic_quad9_kernel) below this many full-tile workgroups per launch (C4: one frame per call)
     static constexpr long long kQuad9MaxWorkgroups = 4096;
+    // float planes on the trimmed support (a scan of the source and two launches per plane) from this many taps per plane and call on
+    static constexpr double kFloatTrimMinTaps = 1.0e9;
     // two-periods-per-lane quad form on the trimmed 6 x 6 support from this many half-height workgroups per launch on
     static constexpr long long kQuad2MinWorkgroups = 256;
     // ... and its half-height tiles (24 period-rows) below this many full-tile workgroups per launch
-    static constexpr long long kQuad2HalfTileMaxWorkgroups = 3072;
+    static constexpr long long kQuad2HalfTileMaxWorkgroups = 12000;  // (C2 at 16 frames: 734 against 718 Gpix/s; at 64: 803 against 827)
     // fs-7 quad form from this many periods (2 x 2 pixels each) per plane on: 1080p -> 4K has 2.05 M, 360p -> 720p 0.22 M
     static constexpr long long kQuadMinPeriods = 1000000;
     // workgroups a quasi-periodic launch aims for when it splits a tile's phases (fs 9 tiles cost more to stage)
@@ -264,7 +266,13 @@ struct Choice {
     // The periodic family on the trimmed support (integer planes whose phase sets have a zero rim; device_plan.cpp
     // trim_periodic): the automatic choice wherever it exists; kernel modes 5 / 6 (the fs-7 packed A/B variant) and 15
     // (= the automatic choice on the full window, for A/B and tests: jinc_filter::full_window) keep the reference's window.
-    bool trimmed(const DeviceTable& t) const { return t.trim_fs > 0 && !f.full_window && f.kernel_mode != 5 && f.kernel_mode != 6; }
+    // Float planes take it frame by frame, where kernel_scan.hip found nothing but finite samples (two launches per plane and
+    // a pass over the source: calls of at least kFloatTrimMinTaps taps per plane).
+    bool trimmed(const DeviceTable& t) const {
+        if (t.trim_fs <= 0 || f.full_window || f.kernel_mode == 5 || f.kernel_mode == 6) return false;
+        if (!t.trim_needs_finite) return true;
+        return static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs * nframes >= Rules::kFloatTrimMinTaps || f.kernel_mode != 0;
+    }
     const jinc::PeriodicArgs& periodic_args(const DeviceTable& t) const { return trimmed(t) ? t.periodic_trim : t.periodic; }
     int periodic_fs(const DeviceTable& t) const { return trimmed(t) ? t.trim_fs : t.plan.fs; }
     bool quad_chosen(const DeviceTable& t) const {
@@ -534,6 +542,26 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     }();
                     if (force_rg == 8) variant = 5;
                     if (force_rg == 4) variant = 6;
+                }
+                if (c.trimmed(t) && t.trim_needs_finite) {
+                    // float plane: which frames hold nothing but finite samples?  Those run on the trimmed support; the others
+                    // (flag 1) on the reference's full window in a second launch that returns at once for the rest.
+                    if (f.finite_flags_frames < io.nframes) {
+                        if (f.finite_flags) (void)hipFree(f.finite_flags);
+                        f.finite_flags = nullptr, f.finite_flags_frames = 0;
+                        hip_check(hipMalloc(reinterpret_cast<void**>(&f.finite_flags), sizeof(uint32_t) * 4 * static_cast<size_t>(io.nframes)), "hipMalloc(finite flags)");
+                        f.finite_flags_frames = io.nframes;
+                    }
+                    uint32_t* flags = f.finite_flags + static_cast<size_t>(i) * f.finite_flags_frames;
+                    hip_check(hipMemsetAsync(flags, 0, sizeof(uint32_t) * io.nframes, s), "hipMemsetAsync(finite flags)");
+                    int rc = jinc::launch_finite_scan(io, t.plan.src_w, t.plan.src_h, flags, s);
+                    if (rc) return rc;
+                    jinc::PeriodicArgs fin = t.periodic_trim, rest = t.periodic;
+                    fin.frame_flags = rest.frame_flags = flags;
+                    fin.run_when = 0, rest.run_when = 1;
+                    rc = jinc::launch_periodic(fin, pfs, io, s, variant);
+                    if (rc) return rc;
+                    return jinc::launch_periodic(rest, t.plan.fs, io, s, 0);
                 }
                 return jinc::launch_periodic(c.periodic_args(t), pfs, io, s, variant);
             });

@@ -385,6 +385,14 @@ int jinc_filter_periodic_support(const jinc_filter* f, int table) {
     return t.trim_fs > 0 && !f->full_window ? t.trim_fs : t.plan.fs;
 }
 
+double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kernel) {
+    if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return 0;
+    const DeviceTable& t = f->tables[table];
+    if (!t.use_periodic) return 0;
+    if (t.trim_fs > 0 && !f->full_window) return rows_kernel ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
+    return static_cast<double>(t.plan.fs) * t.plan.fs;
+}
+
 int jinc_filter_set_simd_order(jinc_filter* f, int order) {
     if (!f || order < 0 || order > 3) return fail(JINC_ERR_INVALID_ARG, "JincResize: SIMD order must be 0..3.");
     f->simd_order = order;

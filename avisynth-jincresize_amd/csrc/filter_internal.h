@@ -47,6 +47,8 @@ struct DeviceTable {
     // The same interior on the TRIMMED support (integer planes only; device_plan.cpp trim_periodic): trim_fs x trim_fs taps
     // per sample, the bounding box of the phase sets' non-zero coefficients; 0 = the sets have no zero rim (or float samples).
     int trim_fs = 0;
+    double trim_rows_taps = 0;       // taps per sample ewa_periodic_rows_kernel executes on the trimmed support (per-row spans)
+    bool trim_needs_finite = false;  // float planes: the trimmed launch takes the frames whose samples are all finite
     jinc::PeriodicArgs periodic_trim;
     bool use_quasi = false;  // quasi-periodic interior kernel (affine window origins, drifting classes)
     jinc::QuasiArgs quasi;
@@ -168,6 +170,8 @@ struct jinc_filter {
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
     bool full_window = false;  // kernel mode 15: no trimmed support (the reference's full window everywhere)
+    uint32_t* finite_flags = nullptr;  // [4 planes][finite_flags_frames]: kernel_scan.hip's verdict per plane and frame (float planes)
+    int finite_flags_frames = 0;
     int border_strips = -1;  // border frame of exactly periodic plans: -1 by call size (dispatch.cpp Rules), 1 strip kernels, 2 rows only, 0 gather kernel
     bool direct_premise = false;  // buffer_range_check_covers_soffset(device) == 1
     int simd_order = 0;  // 0: opt=0 results (default); 1 / 2 / 3: summation order of the reference's SSE4.1 / AVX2 / AVX-512 path
@@ -206,6 +210,7 @@ struct jinc_filter {
                 if (t.blob) (void)hipFree(t.blob);
                 for (void* b : t.lane_blobs) (void)hipFree(b);
             }
+            if (finite_flags) (void)hipFree(finite_flags);
             jinc::host::release_pipeline(*this);  // (also returns this instance's references to pinned host ranges)
             for (auto* v : {&ev_periodic, &ev_gather})
                 for (auto& e : *v) {

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
 
     // The coefficients of the wave's first phase do not depend on the tile: request them (scalar loads) BEFORE the
     // staging loads and the barrier, so that their latency overlaps the staging instead of following it.
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
     {
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -534,6 +536,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const Periodi
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -624,6 +627,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -827,6 +831,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -932,8 +937,34 @@ struct RowsCfg {
     static constexpr int kThreads = 64 * kWaves;
 };
 
+// One kernel row of a rows item on the taps lx = TR .. FS-1-TR: the taps in front of and behind that span carry the
+// coefficient 0.0f in this kernel row of this phase (the EWA disc's chord; host: trim_periodic, row_trim) and are left out,
+// which is exact for the integer planes the trimmed support is built for.  TR = 0: every tap.
+template <int FS, int KC, int OFF, int TR>
+__device__ __forceinline__ void rows_kernel_row(float (&acc)[4][KC], const float* __restrict__ tile, const unsigned (&plane_off)[KC],
+                                                const JINC_CONSTANT float* crow) {
+    using Cfg = RowsCfg<FS, KC>;
+    constexpr int K = Cfg::K, R = Cfg::R, N = FS - 2 * TR;
+    static_assert(R == 4, "four chain rows per lane");
+    float c[N];
+#pragma unroll
+    for (int lx = 0; lx < N; ++lx) c[lx] = crow[TR + lx];
+#pragma unroll
+    for (int jj = 0; jj < R; ++jj) {
+        float seg[N + K - 1];
+#pragma unroll
+        for (int u = 0; u < N + K - 1; ++u)
+            seg[u] = tile[plane_off[(u + TR + OFF) % K] + (jj * Cfg::kPlane + (u + TR + OFF) / K)];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int lx = 0; lx < N; ++lx) acc[jj][k] = acc[jj][k] + seg[k + lx] * c[lx];
+    }
+}
+
 template <typename T, int FS, int KC, int OFF>
-__device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs, BufferRsrc drsrc,
+__device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs,
+                                          const JINC_CONSTANT int32_t* row_trim, BufferRsrc drsrc,
                                           int dst_pitch, float peak, int y0, int ystep, int rows_valid, unsigned x0,
                                           unsigned xstep, int cols_valid) {
     using Cfg = RowsCfg<FS, KC>;
@@ -954,19 +985,27 @@ __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsign
     }
 
     for (int ly = 0; ly < FS; ++ly) {
-        float c[FS];
-#pragma unroll
-        for (int lx = 0; lx < FS; ++lx) c[lx] = cs[ly * padded_row(FS) + lx];
-#pragma unroll
-        for (int jj = 0; jj < R; ++jj) {
-            float seg[FS + K - 1];
-#pragma unroll
-            for (int u = 0; u < FS + K - 1; ++u)
-                seg[u] = tile[plane_off[(u + OFF) % K] + (jj * Cfg::kPlane + (u + OFF) / K)];
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int lx = 0; lx < FS; ++lx) acc[jj][k] = acc[jj][k] + seg[k + lx] * c[lx];
+        const JINC_CONSTANT float* crow = cs + ly * padded_row(FS);
+        // taps this kernel row leaves out on either side (wave-uniform: the phase's, from the plan); spans are offered in
+        // steps of one tap up to five, a row whose zero flanks are wider takes the widest
+        const int tr = row_trim ? row_trim[ly] : 0;
+        if constexpr (FS >= 12) {
+            switch (tr) {
+                case 0: rows_kernel_row<FS, KC, OFF, 0>(acc, tile, plane_off, crow); break;
+                case 1: rows_kernel_row<FS, KC, OFF, 1>(acc, tile, plane_off, crow); break;
+                case 2: rows_kernel_row<FS, KC, OFF, 2>(acc, tile, plane_off, crow); break;
+                case 3: rows_kernel_row<FS, KC, OFF, 3>(acc, tile, plane_off, crow); break;
+                case 4: rows_kernel_row<FS, KC, OFF, 4>(acc, tile, plane_off, crow); break;
+                default: rows_kernel_row<FS, KC, OFF, 5>(acc, tile, plane_off, crow); break;
+            }
+        } else if constexpr (FS >= 6) {
+            switch (tr) {
+                case 0: rows_kernel_row<FS, KC, OFF, 0>(acc, tile, plane_off, crow); break;
+                case 1: rows_kernel_row<FS, KC, OFF, 1>(acc, tile, plane_off, crow); break;
+                default: rows_kernel_row<FS, KC, OFF, 2>(acc, tile, plane_off, crow); break;
+            }
+        } else {
+            rows_kernel_row<FS, KC, OFF, 0>(acc, tile, plane_off, crow);
         }
 #pragma unroll
         for (int m = 0; m < K; ++m) plane_off[m] += Cfg::kPlane;  // next kernel row
@@ -984,7 +1023,7 @@ __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsign
 }
 
 template <typename T, int FS, int KC>
-__global__ __launch_bounds__(512) void ewa_periodic_rows_kernel(const PeriodicArgs a, const PlaneIO io) {
+__global__ __launch_bounds__(512, 8) void ewa_periodic_rows_kernel(const PeriodicArgs a, const PlaneIO io) {
     using Cfg = RowsCfg<FS, KC>;
     constexpr int K = Cfg::K, R = Cfg::R;
     __shared__ float tile[K * Cfg::kPlaneStride];
@@ -996,6 +1035,7 @@ __global__ __launch_bounds__(512) void ewa_periodic_rows_kernel(const PeriodicAr
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
 
     {
         const int gx0 = a.min_sx + i0;
@@ -1049,10 +1089,11 @@ __global__ __launch_bounds__(512) void ewa_periodic_rows_kernel(const PeriodicAr
         const unsigned base = ((a.start_y[q] - a.min_sy) + ch * R) * Cfg::kPlane + lane;
         const int y0 = a.iy0 + a.py * j + q;
         const unsigned x0 = a.ix0 + a.px * (i0 + K * lane) + p;
+        const JINC_CONSTANT int32_t* row_trim = a.row_trim ? (const JINC_CONSTANT int32_t*)(a.row_trim) + ph * 32 : nullptr;
         if (a.start_x[p] - a.min_sx)
-            rows_item<T, FS, KC, 1>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+            rows_item<T, FS, KC, 1>(tile, base, cs, row_trim, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
         else
-            rows_item<T, FS, KC, 0>(tile, base, cs, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+            rows_item<T, FS, KC, 0>(tile, base, cs, row_trim, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
     }
 }
 

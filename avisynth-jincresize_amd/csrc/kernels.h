@@ -85,6 +85,14 @@ struct PeriodicArgs {
     // 2x up-scales whose phases share their window origin (ewa_periodic_quad_kernel): coefficient pairs
     // quad[ly][q][8 pairs][p] = (set(p=0,q), set(p=1,q))[ly][lx], or nullptr when the plan has no such form
     const float* quad = nullptr;
+    // trimmed support only (ewa_periodic_rows_kernel): row_trim[phase * 32 + ly] = taps kernel row ly of the phase leaves out on
+    // EITHER side (min of its leading and trailing zero coefficients, at most 5), or nullptr
+    const int32_t* row_trim = nullptr;
+    // float planes on the trimmed support: frame_flags[frame] (kernel_scan.hip: 1 = the frame's plane holds a non-finite
+    // sample) decides which of two launches computes a frame -- a launch returns at once for frames whose flag differs from
+    // run_when.  nullptr: every frame.
+    const uint32_t* frame_flags = nullptr;
+    uint32_t run_when = 0;
 };
 
 // Quasi-periodic interior: the window origins are affine per residue (output pixel (ix0 + px*i + p,
@@ -253,6 +261,8 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 bool periodic_supported(int fs, int px, int py, int sx, int sy);
 // variant: 0 = default choice per filter size, 1 = always the row-streamed kernel (A/B measurements)
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
+// kernel_scan.hip: flags[frame] = 1 where the frame's float source plane (w x h samples) holds an infinity or a NaN
+int launch_finite_scan(const PlaneIO& io, int w, int h, uint32_t* flags, void* stream);
 
 // Compatibility modes: the summation order of the reference's SIMD paths (kernel_simdorder.hip).  order 1 = SSE4.1,
 // 2 = AVX2, 3 = AVX-512; min_val = lower clamp of float source samples of this plane.

@@ -749,7 +749,20 @@ def main(argv=None):
         launches_per_step = max(1, dom_n // max(1, args.steps))
         kernel_ms_per_step = dom_ms / args.steps
         achieved_gbs = bytes_frame * B / (kernel_ms_per_step * 1e-3) / 1e9
-        valu_ops = 2.0 * fs * fs * samples_frame * B / (kernel_ms_per_step * 1e-3)
+        # operations the reference's chain holds per sample (2 fs^2) and operations the kernels EXECUTE: the periodic
+        # kernels leave out taps whose coefficient is exactly 0.0f (trimmed support; exact), so the
+        # VALU's utilisation is counted on what it really does, and the algorithmic figure is reported beside it
+        valu_ops_algorithmic = 2.0 * fs * fs * samples_frame * B / (kernel_ms_per_step * 1e-3)
+        taps_exec, taps_ref = 0.0, 0.0
+        for i, (w, h) in enumerate(ddims):
+            tbl = 1 if (flt.num_tables > 1 and i in (1, 2)) else 0
+            fs_t = flt.plan_info(tbl).filter_size
+            kname = flt.last_kernel(tbl)
+            taps = flt.periodic_taps(tbl, rows_kernel="rows" in kname) if kname.startswith("ewa_periodic") else 0.0
+            taps_exec += w * h * (taps or fs_t * fs_t)
+            taps_ref += w * h * fs_t * fs_t
+        valu_ops = 2.0 * taps_exec * B / (kernel_ms_per_step * 1e-3)
+        valu_ops_algorithmic = 2.0 * taps_ref * B / (kernel_ms_per_step * 1e-3)
         traffic = traffic_raw = None
         pmc_clock = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -793,6 +806,11 @@ def main(argv=None):
                          "binding_roof": "un-fused fp32 VALU (v_mul_f32+v_add_f32 per tap; FMA/MFMA would break bit-exactness)",
                          "valu_achieved_Tops": round(valu_ops / 1e12, 2), "valu_peak_Tops": VALU_UNFUSED_PEAK / 1e12,
                          "valu_frac": round(valu_ops / VALU_UNFUSED_PEAK, 4),
+                         # taps per sample: the reference's chain (fs^2) and what the kernels execute (zero-coefficient taps left out);
+                         # valu_* above and below count EXECUTED multiplies and adds, *_algorithmic the reference's 2 fs^2 per sample
+                         "taps_per_sample_reference": round(taps_ref / samples_frame, 2), "taps_per_sample_executed": round(taps_exec / samples_frame, 2),
+                         "valu_algorithmic_Tops": round(valu_ops_algorithmic / 1e12, 2),
+                         "valu_frac_algorithmic": round(valu_ops_algorithmic / VALU_UNFUSED_PEAK, 4),
                          # what the part sustains under this load: shader clock sampled beside the same steps in a second, untimed pass
                          # right after the timed one (median / min / max over 8 samplers = XCDs), the VALU peak at that clock and
                          # the fraction of it

@@ -33,7 +33,7 @@ def test_bench_under_torch_distributed_run_with_one_rank(gpu_pkg, config, extra)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert d["scaling"] == ("strong" if config == "C5" else "weak")
-    assert d["roofline"]["kernel"] in ("ewa_periodic_kernel", "ewa_periodic_quad_kernel") and d["roofline"]["frac"] > 0
+    assert d["roofline"]["kernel"] in ("ewa_periodic_kernel", "ewa_periodic_quad_kernel", "ewa_periodic_quad2_kernel") and d["roofline"]["frac"] > 0
     assert d["config"]["parallelism"].startswith("frames sharded over 1 GPU") and d["config"]["sync"] == "rccl"
 
 
