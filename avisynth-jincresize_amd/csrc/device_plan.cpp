@@ -473,6 +473,56 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     if (!t.strips_ok) t.border_rects.private_sets = t.border_rects.unit_stride = true;  // coefficients per lane
 }
 
+// The direct kernel's interior on the trimmed support (integer planes; see trim_periodic for why leaving out taps whose
+// coefficient is 0.0f is exact): the bounding box of the phase sets' non-zero coefficients, squared up.  The kernel takes
+// the filter size at run time, so this is a copy of the arguments with a smaller fs, window origins moved by the box's
+// corner and the sets cut to the box -- laid out like the plan's coefficient array, slack rows around it included (the row
+// walk fetches coefficient rows of the "neighbouring sets", never used; upload_table).
+void trim_direct(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
+    t.direct_trim_fs = 0;
+    if (!t.use_direct || !integer_samples) return;
+    static const bool off = [] {
+        const char* e = std::getenv("JINC_TRIM");
+        return e && std::atoi(e) == 0;
+    }();
+    if (off) return;
+    const jinc::DirectArgs& da = t.direct;
+    const int fs = p.fs, nphase = da.px * da.py;
+    int r0 = fs, r1 = -1, c0 = fs, c1 = -1;
+    for (int ph = 0; ph < nphase; ++ph) {
+        const float* s = p.set_ptr(da.set[ph]);
+        for (int ly = 0; ly < fs; ++ly)
+            for (int lx = 0; lx < fs; ++lx)
+                if (s[ly * fs + lx] != 0.f) r0 = std::min(r0, ly), r1 = std::max(r1, ly), c0 = std::min(c0, lx), c1 = std::max(c1, lx);
+    }
+    if (r1 < 0) return;
+    const int n = std::max(1, std::max(r1 - r0 + 1, c1 - c0 + 1));
+    if (n >= fs || !jinc::direct_supported(n, da.px, da.py, da.sx, da.sy)) return;
+    r0 = std::min(r0, fs - n);
+    c0 = std::min(c0, fs - n);
+    const int row = (n + 3) & ~3;
+    const size_t slack_floats = static_cast<size_t>(jinc::kDirectCoeffSlackRows) * row + 64;
+    std::vector<float> cut(2 * slack_floats + static_cast<size_t>(nphase) * n * row, 0.f);
+    for (int ph = 0; ph < nphase; ++ph) {
+        const float* s = p.set_ptr(da.set[ph]);
+        for (int ly = 0; ly < n; ++ly)
+            for (int lx = 0; lx < n; ++lx) cut[slack_floats + (static_cast<size_t>(ph) * n + ly) * row + lx] = s[(r0 + ly) * fs + (c0 + lx)];
+    }
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, cut.size() * sizeof(float)), "hipMalloc(trimmed coefficient sets of the direct kernel)");
+    t.lane_blobs.push_back(dev);
+    hip_check(hipMemcpy(dev, cut.data(), cut.size() * sizeof(float), hipMemcpyHostToDevice), "trimmed coefficient upload");
+    jinc::DirectArgs tr = da;
+    tr.coeffs = static_cast<const float*>(dev) + slack_floats;
+    tr.fs = n;
+    tr.coeff_row = row;
+    for (int ph = 0; ph < nphase; ++ph) tr.set[ph] = ph;
+    for (int k = 0; k < da.px; ++k) tr.start_x[k] = da.start_x[k] + c0;
+    for (int k = 0; k < da.py; ++k) tr.start_y[k] = da.start_y[k] + r0;
+    t.direct_trim = tr;
+    t.direct_trim_fs = n;
+}
+
 }  // namespace
 
 // kernel_direct.hip passes the row offset of its segment fetches as the buffer instructions' scalar offset and relies
@@ -603,6 +653,7 @@ void init_device(jinc_filter& f, int device) {
         trim_periodic(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
         plan_quasi(f.plans[i], f.tables[i]);
         plan_direct(f.plans[i], f.tables[i]);
+        trim_direct(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
         plan_runs(f.plans[i], f.tables[i]);
         {   // every interior variant of a table must cover the same extent: the border frame is laid out once
             const DeviceTable& t = f.tables[i];

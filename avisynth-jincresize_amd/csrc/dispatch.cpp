@@ -488,7 +488,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         }
         if (direct)
             timed(f.ev_periodic, plane_stream, "direct periodic kernel launch", [&](hipStream_t s) {
-                jinc::DirectArgs da = t.direct;
+                jinc::DirectArgs da = (t.direct_trim_fs > 0 && !f.full_window) ? t.direct_trim : t.direct;
                 da.src_bytes = direct_src_bytes(
                     src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
                 return jinc::launch_direct(da, io, s);

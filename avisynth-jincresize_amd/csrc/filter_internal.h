@@ -55,6 +55,8 @@ struct DeviceTable {
     jinc::RectList border_rects;  // gather work when the periodic kernel covers the interior
     bool use_direct = false;      // exactly periodic, any filter size / source step (kernel_direct.hip)
     jinc::DirectArgs direct;      // interior
+    int direct_trim_fs = 0;       // > 0: the same interior on the trimmed support (integer planes; device_plan.cpp trim_direct)
+    jinc::DirectArgs direct_trim;
     jinc::DirectArgs row_strips;  // border rows of the same plan over the interior's columns (any interior kernel)
     bool use_runs = false;        // drifting plan cut into rectangles of one coefficient set each: the direct kernel's runs form
     jinc::DirectArgs runs;

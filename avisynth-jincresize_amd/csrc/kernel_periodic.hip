@@ -789,15 +789,11 @@ __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[2
 template <typename T>
 __device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset, uint32_t soffset, f32x2 a, f32x2 b, float peak, bool b_ok) {
     if constexpr (std::is_same_v<T, float>) {
+        // two 8-byte stores: the samples start at a 4-byte boundary (odd interior origin), and a 16-byte store that is not
+        // 16-byte aligned does not write its four dwords where they belong (measured: dwords 1 and 3 took the values of 0 and 2)
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        if (b_ok) {
-            const u32x4 v = {__builtin_bit_cast(uint32_t, a.x), __builtin_bit_cast(uint32_t, a.y), __builtin_bit_cast(uint32_t, b.x),
-                             __builtin_bit_cast(uint32_t, b.y)};
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, voffset, soffset, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rsrc, voffset, soffset, 0);
-        }
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, a), rsrc, voffset, soffset, 0);
+        if (b_ok) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, b), rsrc, voffset + 8u, soffset, 0);
     } else if constexpr (std::is_same_v<T, uint8_t>) {
         uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(a.x, 0u, 0u);
         w = __builtin_amdgcn_cvt_pk_u8_f32(a.y, 1u, w);
