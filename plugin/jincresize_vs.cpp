@@ -25,11 +25,20 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "jincresize_hip.h"
 
 namespace {
+
+struct Pending {  // one frame in flight in the look-ahead ring
+    const VSFrame* src = nullptr;
+    VSFrame* dst = nullptr;
+    long long ticket = -1;
+    int frame = -1;
+};
 
 struct Instance {
     VSNode* node = nullptr;
@@ -37,16 +46,117 @@ struct Instance {
     jinc_filter* filter = nullptr;
     int chroma_location = -1;    // value written to _ChromaLocation, -1: format without sub-sampled chroma
     int planes = 0;
+    // look-ahead (JINCRESIZE_LOOKAHEAD > 1): the frames of a window [base, base + lookahead) in flight, as in the AviSynth shell
+    int lookahead = 1, group = 0;
+    std::vector<Pending> ring;   // slot k % lookahead holds frame k while it is in the window
+    int base = 0, next_submit = 0, resubmit = -1;
+    std::mutex mutex;
 };
+
+void plane_pointers(const VSAPI* vsapi, const Instance* d, const VSFrame* src, VSFrame* dst, const void* sp[4], int spitch[4], void* dp[4],
+                    int dpitch[4]) {
+    for (int i = 0; i < 4; ++i) {
+        sp[i] = nullptr, dp[i] = nullptr, spitch[i] = 0, dpitch[i] = 0;
+        if (i >= d->planes) continue;
+        sp[i] = vsapi->getReadPtr(src, i);
+        spitch[i] = static_cast<int>(vsapi->getStride(src, i));
+        dp[i] = vsapi->getWritePtr(dst, i);
+        dpitch[i] = static_cast<int>(vsapi->getStride(dst, i));
+    }
+}
+
+// Look-ahead form: in arInitial frame n asks for the source frames n .. n + lookahead - 1 (VapourSynth's cache serves the
+// overlap between neighbouring requests); in arAllFramesReady -- which fmParallelRequests serialises, in whatever order the
+// frames become ready -- the window ring of the AviSynth shell (plugin/jincresize_avs.cpp get_frame_lookahead: any frame of
+// the window in any order without draining, a frame is dropped only when the window moves past it) submits what the window
+// still lacks from THIS call's frame context and waits for frame n only.  Every new submission k lies in n .. n + lookahead -
+// 1, which is what this context requested.  The pipeline coalesces the frames in flight into batch launches.
+const VSFrame* get_frame_lookahead(int n, Instance* d, VSFrameContext* frameCtx, VSCore* core, const VSAPI* vsapi) {
+    std::lock_guard<std::mutex> lock(d->mutex);
+    const int depth = d->lookahead;
+    const int last = d->vi.numFrames - 1;
+    auto slot = [&](int k) -> Pending& { return d->ring[static_cast<size_t>(k % depth)]; };
+    auto drop = [&](Pending& p) {
+        jinc_filter_wait(d->filter, p.ticket);
+        vsapi->freeFrame(p.src);
+        vsapi->freeFrame(p.dst);
+        p = Pending{};
+    };
+    auto move_window = [&](int base) {
+        for (Pending& p : d->ring)
+            if (p.frame >= 0 && (p.frame < base || p.frame >= base + depth)) drop(p);
+        d->base = base;
+    };
+    if (n < d->base || n >= d->base + depth) {
+        move_window(n);
+        d->next_submit = n;
+    } else if (slot(n).frame != n && n < d->next_submit) {
+        d->resubmit = n;
+    }
+    if (n - d->base > depth / 2) move_window(n - depth / 2);
+    while (d->base < n && slot(d->base).frame != d->base) ++d->base;
+
+    auto submit = [&](int k) -> int {  // 0 ok, 1 this context does not hold frame k, 2 failure (reported)
+        Pending& p = slot(k);
+        p.src = vsapi->getFrameFilter(k, d->node, frameCtx);
+        if (!p.src) return 1;
+        p.dst = vsapi->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, p.src, core);
+        const void* sp[4];
+        void* dp[4];
+        int spitch[4], dpitch[4];
+        plane_pointers(vsapi, d, p.src, p.dst, sp, spitch, dp, dpitch);
+        if (jinc_filter_submit(d->filter, sp, spitch, dp, dpitch, &p.ticket) != JINC_OK) return 2;
+        p.frame = k;
+        return 0;
+    };
+    auto failed = [&](int k) -> const VSFrame* {
+        Pending& p = slot(k);
+        vsapi->setFilterError(jinc_last_error(), frameCtx);
+        if (p.src) vsapi->freeFrame(p.src);
+        if (p.dst) vsapi->freeFrame(p.dst);
+        p = Pending{};
+        return nullptr;
+    };
+    if (d->resubmit >= 0) {
+        const int k = d->resubmit, rc = submit(k);
+        d->resubmit = -1;
+        if (rc == 2) return failed(k);
+    }
+    for (int k = std::max(d->next_submit, d->base); k <= std::min(std::min(d->base + depth - 1, n + depth - 1), last); ++k) {
+        if (slot(k).frame == k) {
+            d->next_submit = k + 1;
+            continue;
+        }
+        const int rc = submit(k);
+        if (rc == 1) break;
+        if (rc == 2) return failed(k);
+        d->next_submit = k + 1;
+    }
+    if (d->next_submit > last) jinc_filter_flush(d->filter);
+    Pending& want = slot(n);
+    if (want.frame != n) {
+        vsapi->setFilterError("JincResize: the source frame is not available.", frameCtx);
+        return nullptr;
+    }
+    if (jinc_filter_wait(d->filter, want.ticket) != JINC_OK) return failed(n);
+    VSFrame* dst = want.dst;
+    if (d->chroma_location >= 0) vsapi->mapSetInt(vsapi->getFramePropertiesRW(dst), "_ChromaLocation", d->chroma_location, maReplace);
+    vsapi->freeFrame(want.src);
+    want = Pending{};
+    while (d->base < d->next_submit && slot(d->base).frame != d->base) ++d->base;
+    return dst;
+}
 
 const VSFrame* VS_CC jinc_vs_get_frame(int n, int activationReason, void* instanceData, void**, VSFrameContext* frameCtx, VSCore* core,
                                        const VSAPI* vsapi) {
     Instance* d = static_cast<Instance*>(instanceData);
     if (activationReason == arInitial) {
-        vsapi->requestFrameFilter(n, d->node, frameCtx);
+        const int ahead = std::min(n + d->lookahead - 1, d->vi.numFrames - 1);
+        for (int k = n; k <= std::max(n, ahead); ++k) vsapi->requestFrameFilter(k, d->node, frameCtx);
         return nullptr;
     }
     if (activationReason != arAllFramesReady) return nullptr;
+    if (d->lookahead > 1) return get_frame_lookahead(n, d, frameCtx, core, vsapi);
     const VSFrame* src = vsapi->getFrameFilter(n, d->node, frameCtx);
     VSFrame* dst = vsapi->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);  // inherits the frame properties (ref :613)
     const void* sp[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -72,6 +182,12 @@ const VSFrame* VS_CC jinc_vs_get_frame(int n, int activationReason, void* instan
 
 void VS_CC jinc_vs_free(void* instanceData, VSCore*, const VSAPI* vsapi) {  // ref :632-647
     Instance* d = static_cast<Instance*>(instanceData);
+    for (Pending& p : d->ring) {
+        if (p.frame < 0) continue;
+        jinc_filter_wait(d->filter, p.ticket);
+        vsapi->freeFrame(p.src);
+        vsapi->freeFrame(p.dst);
+    }
     jinc_filter_free(d->filter);
     vsapi->freeNode(d->node);
     delete d;
@@ -196,9 +312,21 @@ void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* c
     jinc_filter_output_info(filter, &out_vi);  // ref :791-792
     d->vi.width = out_vi.width;
     d->vi.height = out_vi.height;
-    VSFilterDependency deps[1] = {{node, rpStrictSpatial}};  // frame n of the output needs frame n of the input, nothing else
-    vsapi->createVideoFilter(out, alias_taps ? "JincAliasResize" : "JincResize", &d->vi, jinc_vs_get_frame, jinc_vs_free, fmUnordered, deps, 1, d,
-                             core);
+    // JINCRESIZE_LOOKAHEAD / JINCRESIZE_GROUP / JINCRESIZE_PIN_FRAMES: as in the AviSynth shell
+    if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) d->lookahead = std::max(1, std::min(256, std::atoi(e)));
+    if (const char* e = std::getenv("JINCRESIZE_GROUP")) d->group = std::max(0, std::min(d->lookahead, std::atoi(e)));
+    const char* pin = std::getenv("JINCRESIZE_PIN_FRAMES");
+    const bool pin_frames = pin && std::atoi(pin) != 0;
+    if (d->lookahead > 1) {
+        if (jinc_filter_set_pipeline_group(filter, d->lookahead, d->group, pin_frames) != JINC_OK) d->lookahead = 1;
+        d->ring.resize(static_cast<size_t>(d->lookahead));
+    }
+    if (d->lookahead == 1 && pin_frames) jinc_filter_set_pipeline(filter, 1, 1);
+    // depth 1: frame n of the output needs frame n of the input, nothing else; look-ahead asks for n .. n + depth - 1.
+    // fmParallelRequests: arInitial from any thread, arAllFramesReady one call at a time (the instance is single-threaded).
+    VSFilterDependency deps[1] = {{node, d->lookahead > 1 ? rpGeneral : rpStrictSpatial}};
+    vsapi->createVideoFilter(out, alias_taps ? "JincAliasResize" : "JincResize", &d->vi, jinc_vs_get_frame, jinc_vs_free,
+                             d->lookahead > 1 ? fmParallelRequests : fmUnordered, deps, 1, d, core);
 }
 
 }  // namespace

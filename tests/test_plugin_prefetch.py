@@ -154,7 +154,7 @@ def test_depth_one_instances_share_the_frame_pool_and_keep_the_shader_transport(
         assert err is None, err
         assert host.mock_clip_mt_mode(clip) == 2
         clips.append(clip)
-    pkg.transport_counts(reset=True)
+    ranges_before = pkg.transport_counts(reset=True)[2]
     crcs, errors, _ = pull_with_threads(host, h, clips, nframes, fmt.planes, np.uint8, nthreads, lambda t, n: clips[t])
     assert not errors, errors
     wrong = [n for n in range(nframes) if crcs.get(n, (None,))[0] != want[n]]
@@ -166,5 +166,5 @@ def test_depth_one_instances_share_the_frame_pool_and_keep_the_shader_transport(
         host.mock_clip_release(clip)
     host.mock_source_release(src)
     assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
-    assert pkg.transport_counts()[2] == 0     # the last instance to go unregistered what the registry had pinned
+    assert pkg.transport_counts()[2] == ranges_before     # the last instance to go unregistered what these four had pinned
     h.close()

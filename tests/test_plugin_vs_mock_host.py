@@ -287,3 +287,54 @@ def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(vs, O, m
     assert node is None and err == "JincResize: invalid _ChromaLocation"
     vs.mockvs_node_release(src)
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,kernel", [
+    (("Y8", 1280, 720, 1754, 986, "JincResize", {}), "ewa_framelane"),             # no phase structure: groups of 16 on the frame-lane kernels
+    (("YUV420P8", 960, 540, 1920, 1080, "Jinc36Resize", {}), "ewa_periodic"),       # 2x: the periodic kernels' batch forms
+], ids=["A137", "2x_420"])
+def test_lookahead_in_the_vapoursynth_shell(vs, O, pkg, case, kernel, monkeypatch):
+    """JINCRESIZE_LOOKAHEAD=32 in the VapourSynth shell -- arInitial asks for n .. n + 31, arAllFramesReady
+    (fmParallelRequests: one call at a time, any order) feeds the same window ring as the AviSynth shell.  Frames pulled in
+    order, then out of order and again: each is that frame's single-call result (and the oracle's), launches are 16-frame
+    batches, nothing leaks."""
+    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "32")
+    monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
+    monkeypatch.delenv("JINCRESIZE_GROUP", raising=False)
+    fmt_name, sw, sh, tw, th, fn, named = case
+    fmt = O.FORMATS[fmt_name]
+    nframes = 64
+    frames = [O.lcg_frame(fmt, sw, sh, seed=41000 + n) for n in range(nframes)]
+    kw = dict(named)
+    kw.update({"Jinc36Resize": dict(tap=3)}.get(fn, {}))
+    single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **kw)
+    want = [single.get_frame(fr) for fr in frames]
+    single.close()
+    of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(kw))
+    c = Core(vs)
+    src = c.source(fmt, sw, sh, frames)
+    node, err = c.invoke(fn, src, tw, th, **named)
+    assert err is None, err
+    stale = pkg.last_call()
+    seen = set()
+    order = list(range(nframes)) + [40, 38, 39, 63, 5, 6, 4, 7]     # in order, then jumps and out-of-order neighbours
+    for n in order:
+        fr, err = c.get_frame(node, n)
+        assert err is None, err
+        seen.add(pkg.last_call())
+        got = [c.read_plane(fr, i, np.uint8) for i in range(fmt.planes)]
+        assert_planes_equal(got, want[n], fmt.plane_dims(tw, th), what=f"{fn} frame {n} grouped vs single")
+        if n in (0, 41):
+            assert_planes_equal(got, of.get_frame(frames[n], threads=8), fmt.plane_dims(tw, th), what=f"{fn} frame {n} vs oracle")
+        assert c.prop(fr, "_MockFrameNumber") == n
+        vs.mockvs_frame_release(fr)
+    served = {(name, k) for name, k in seen if name} - {stale}
+    # full groups of 16 on the batch kernel while the clip lasts; the jumps near its end launch short groups, which a plan
+    # without phase structure runs on the gather kernel (fewer than 16 frames)
+    assert any(name.startswith(kernel) and k == 16 for name, k in served), served
+    assert all(name.startswith(kernel) or k < 16 for name, k in served), served
+    vs.mockvs_node_release(node)
+    vs.mockvs_node_release(src)
+    assert c.live() == (0, 0)
+    c.close()
