@@ -674,6 +674,13 @@ void init_device(jinc_filter& f, int device) {
                 jinc::framelane_configure(f.plans[i], f.tables[i].border_rects, f.vi_in.component_size, 64, f.tables[i].fl_border);
             f.tables[i].fl_border.plan = f.tables[i].plan;
         }
+        // border columns (and corners) of exactly periodic plans in batches; window sizes of the frame-lane kernel's sliding-window
+        // form only (C2 841 -> 853 Gpix/s, C1 740 -> 767; 4K -> 1080p with fs 13 on the row-segment form 205 -> 196: round4/fl_cols_ab.log)
+        if (f.tables[i].use_direct && f.tables[i].column_rects.n > 0 && f.plans[i].fs <= 9) {
+            f.tables[i].use_fl_cols =
+                jinc::framelane_configure(f.plans[i], f.tables[i].column_rects, f.vi_in.component_size, 64, f.tables[i].fl_cols);
+            f.tables[i].fl_cols.plan = f.tables[i].plan;
+        }
         f.tables[i].use_framelane =
             jinc::framelane_configure(f.plans[i], f.tables[i].whole, f.vi_in.component_size, 64, f.tables[i].fl_whole);
         f.tables[i].fl_whole.plan = f.tables[i].plan;

@@ -54,6 +54,8 @@ struct Rules {
     static constexpr long long kHalfTileMaxWorkgroups = 6144;
     // fs-9 quad form (ewa_periodic_quad9_kernel) below this many full-tile workgroups per launch (C4: one frame per call)
     static constexpr long long kQuad9MaxWorkgroups = 4096;
+    // border columns of exactly periodic plans on the frame-lane kernel from this many frames per call on
+    static constexpr int kFlColsMinFrames = 64;
     // float planes on the trimmed support (a scan of the source and two launches per plane) from this many taps per plane and call on
     static constexpr double kFloatTrimMinTaps = 1.0e9;
     // two-periods-per-lane quad form on the trimmed 6 x 6 support from this many half-height workgroups per launch on
@@ -271,6 +273,9 @@ struct Choice {
     bool trimmed(const DeviceTable& t) const {
         if (t.trim_fs <= 0 || f.full_window || f.kernel_mode == 5 || f.kernel_mode == 6) return false;
         if (!t.trim_needs_finite) return true;
+        // (float planes at fs 7 are bound by their bytes, not by the VALU: C2's geometry on float RGB 174.2 Gpix/s on the trimmed
+        // quad form against 174.5 on the full window, a scan and a second launch on top -- round4/direct_trim_ab.log)
+        if (f.kernel_mode == 0 && t.trim_fs <= 6) return false;
         return static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs * nframes >= Rules::kFloatTrimMinTaps || f.kernel_mode != 0;
     }
     const jinc::PeriodicArgs& periodic_args(const DeviceTable& t) const { return trimmed(t) ? t.periodic_trim : t.periodic; }
@@ -466,7 +471,26 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             jinc::DirectArgs rs = t.row_strips;
             rs.src_bytes = direct_src_bytes(
                 src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
-            const bool colstrip = t.use_colstrip && f.border_strips != 2;
+            // In batches the border columns (full height: the corners with them) go to the frame-lane kernel: its lanes are 64
+            // frames, so a border pixel's private coefficient set is a scalar load and the taps run from registers -- the
+            // column-strip kernel reads LDS once per tap (C2 at 1024 frames: JINC_FL_COLS_FRAMES A/B, round4/fl_cols_ab.log).
+            static const int fl_cols_min_frames = [] {
+                const char* e = std::getenv("JINC_FL_COLS_FRAMES");  // A/B knob: 0 = never
+                return e ? std::atoi(e) : Rules::kFlColsMinFrames;
+            }();
+            const bool fl_cols = t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
+                                 (f.kernel_mode == 0 || f.kernel_mode == 13 || f.kernel_mode == 2);
+            if (fl_cols) {
+                auto aligned_to = [&](uintptr_t bytes) {
+                    return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
+                           (io.nframes <= 1 || io.dst_frame_stride % bytes == 0);
+                };
+                jinc::FrameLaneArgs fa = t.fl_cols;
+                fa.io = io;
+                fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
+                timed(f.ev_gather, border_stream, "border column frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            }
+            const bool colstrip = !fl_cols && t.use_colstrip && f.border_strips != 2;
             // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
             // last it would start when the interior kernel already holds every wave slot.  (Measured again in round 3 with
             // the corners last: no difference on any of eight configurations -- in a long batch the border kernels cost their
@@ -479,7 +503,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             if (colstrip) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
-            } else if (t.column_rects.n > 0) {
+            } else if (!fl_cols && t.column_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
             }

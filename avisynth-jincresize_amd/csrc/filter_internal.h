@@ -67,6 +67,8 @@ struct DeviceTable {
     jinc::ColStripArgs col_strips;
     jinc::RectList corner_rects;  // ... then only the corners are left for the gather kernel
     jinc::RectList column_rects;  // otherwise: left / right columns, full height, on the gather kernel
+    bool use_fl_cols = false;     // ... or, in batches, on the frame-lane kernel (lanes = frames: every pixel's set is a scalar load)
+    jinc::FrameLaneArgs fl_cols;
     std::vector<void*> lane_blobs;  // lane-major coefficient copies of the private-set rectangles (RectList::lane_coeffs)
     jinc::RectList whole;         // gather work when it does not
     bool use_framelane = false;   // frame-lane kernel configured for the whole plane (batches of frames, any plan)
@@ -131,6 +133,7 @@ struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-a
     bool adopted = false;   // pinned by the caller (jinc_filter_adopt_host_range): never unregistered or evicted here
     unsigned long long stamp = 0;
     long long ticket = -1;  // latest frame whose copies use this range (may still be in flight)
+    unsigned long long id = 0;  // the process-wide registry's entry this instance holds a reference to (0: adopted range)
 };
 
 struct FailedTickets {  // a group whose launch failed: every wait on one of its frames reports `error`

@@ -36,45 +36,79 @@ namespace {
 // valid on every device), instances take and return references, the last reference unregisters.  Ranges somebody ELSE
 // pinned (the host itself, another library) are recognised by asking for their device address and are never unregistered.
 struct SharedPin {
+    unsigned long long id = 0;
     char* base = nullptr;
     size_t bytes = 0;
     int refs = 0;
     bool owned = false;  // registered here (else: found pinned)
+    bool dead = false;   // unregistered early because it turned out stale (see shared_pin_acquire); kept until its references are back
 };
 std::mutex g_pin_mutex;
 std::vector<SharedPin> g_pins;
+unsigned long long g_pin_next_id = 1;
 std::atomic<long long> g_frames_by_shader{0}, g_frames_by_dma{0};  // how results left the device, process-wide (test header)
 
-// A reference to a registered range that contains [c, c + bytes), registering it if need be; false: not pinnable.
-bool shared_pin_acquire(char* c, size_t bytes, char** base, size_t* len) {
+// A reference to a live registered range that contains [c, c + bytes), registering it if need be; false: not pinnable.
+// STALE registrations: the host may free memory this registry still holds pinned (instances keep references for as long as
+// their caches do), and hand out the same addresses again in other sizes.  hipHostRegister refuses a range whose START lies
+// inside an existing registration; if that registration is one of ours and does not contain the new range, it can only be
+// stale -- two live buffers do not overlap -- so it is unregistered on the spot (marked dead: holders find out through
+// shared_pin_alive and let go) and the new range is registered in its place.  A range is taken for "pinned by somebody
+// else" only if NONE of our registrations touches it (two stale ranges under its ends with a hole between them would pass
+// the device-address probe and fault in the hole).
+bool shared_pin_acquire(char* c, size_t bytes, unsigned long long* id, char** base, size_t* len) {
     std::lock_guard<std::mutex> lock(g_pin_mutex);
     for (auto& e : g_pins)
-        if (c >= e.base && c + bytes <= e.base + e.bytes) {
+        if (!e.dead && c >= e.base && c + bytes <= e.base + e.bytes) {
             ++e.refs;
-            *base = e.base, *len = e.bytes;
+            *id = e.id, *base = e.base, *len = e.bytes;
             return true;
         }
     bool owned = true;
     if (hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
-        (void)hipGetLastError();  // e.g. registered by the host application: usable if both ends have a device address
-        void *d0 = nullptr, *d1 = nullptr;
-        if (hipHostGetDevicePointer(&d0, c, 0) != hipSuccess || hipHostGetDevicePointer(&d1, c + bytes - 1, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
+        (void)hipGetLastError();
+        bool retry = false, touches_ours = false;
+        for (auto& e : g_pins) {
+            if (e.dead || !e.owned) continue;
+            if (c >= e.base && c < e.base + e.bytes) {  // our registration under the new range's start, not containing it: stale
+                (void)hipHostUnregister(e.base);
+                (void)hipGetLastError();  // (it may already be gone with its memory: the sticky error must not meet the next launch)
+                e.dead = true;
+                retry = true;
+            } else if (c + bytes > e.base && c < e.base + e.bytes) {
+                touches_ours = true;
+            }
         }
-        owned = false;
+        bool ok = retry && hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (retry || touches_ours) return false;
+            void *d0 = nullptr, *d1 = nullptr;  // pinned by the host application itself?  Both ends must have a device address.
+            if (hipHostGetDevicePointer(&d0, c, 0) != hipSuccess || hipHostGetDevicePointer(&d1, c + bytes - 1, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            owned = false;
+        }
     }
-    g_pins.push_back({c, bytes, 1, owned});
-    *base = c, *len = bytes;
+    g_pins.push_back({g_pin_next_id++, c, bytes, 1, owned, false});
+    *id = g_pins.back().id, *base = c, *len = bytes;
     return true;
 }
 
-void shared_pin_release(char* base) {
+bool shared_pin_alive(unsigned long long id) {
+    std::lock_guard<std::mutex> lock(g_pin_mutex);
+    for (const auto& e : g_pins)
+        if (e.id == id) return !e.dead;
+    return false;
+}
+
+void shared_pin_release(unsigned long long id) {
     std::lock_guard<std::mutex> lock(g_pin_mutex);
     for (size_t i = 0; i < g_pins.size(); ++i)
-        if (g_pins[i].base == base) {
+        if (g_pins[i].id == id) {
             if (--g_pins[i].refs > 0) return;
-            if (g_pins[i].owned) (void)hipHostUnregister(base);
+            if (g_pins[i].owned && !g_pins[i].dead && hipHostUnregister(g_pins[i].base) != hipSuccess) (void)hipGetLastError();
             g_pins.erase(g_pins.begin() + static_cast<std::ptrdiff_t>(i));
             return;
         }
@@ -315,12 +349,18 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
 // may still be in flight is never unregistered under its transfer: its group is finished first.
 char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket) {
     char* c = const_cast<char*>(static_cast<const char*>(p));
-    for (auto& r : f.pinned)
-        if (c >= r.base && c + bytes <= r.base + r.bytes) {
-            r.stamp = ++f.pin_clock;
-            r.ticket = ticket;
-            return r.dev ? r.dev + (c - r.base) : nullptr;
+    for (size_t i = 0; i < f.pinned.size(); ++i) {
+        PinnedRange& r = f.pinned[i];
+        if (c < r.base || c + bytes > r.base + r.bytes) continue;
+        if (!r.adopted && !shared_pin_alive(r.id)) {  // the registry found the range stale and let go of it: so does this instance
+            shared_pin_release(r.id);
+            f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
+            break;
         }
+        r.stamp = ++f.pin_clock;
+        r.ticket = ticket;
+        return r.dev ? r.dev + (c - r.base) : nullptr;
+    }
     if (!f.register_host) return nullptr;  // only ranges the caller pinned are known: this one is pageable
     const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
     const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
@@ -335,18 +375,19 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
                 if (fr.ticket == f.pinned[lru].ticket) {
                     if (g.state == FrameGroup::Filling || g.state == FrameGroup::Launched) finish_group(f, g);
                 }
-        shared_pin_release(f.pinned[lru].base);
+        shared_pin_release(f.pinned[lru].id);
         f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(lru));
     }
     char* base = nullptr;
     size_t len = 0;
-    if (!shared_pin_acquire(c, bytes, &base, &len)) return nullptr;  // e.g. the range straddles memory somebody else has registered
+    unsigned long long id = 0;
+    if (!shared_pin_acquire(c, bytes, &id, &base, &len)) return nullptr;  // e.g. the range straddles memory somebody else has registered
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess) {
         (void)hipGetLastError();
         dev = nullptr;
     }
-    f.pinned.push_back({base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket});
+    f.pinned.push_back({base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket, id});
     return dev ? static_cast<char*>(dev) + (c - base) : nullptr;
 }
 
@@ -402,7 +443,7 @@ void adopt_host_range(jinc_filter& f, void* base, size_t bytes) {
     // Neighbours that continue each other in host AND device addresses become one range: a registrar that pins a frame
     // pool piece by piece (jinc_batch_process: 16 frames at a time, clipped to what is pinned already) hands over pieces,
     // and a plane that begins in one piece and ends in the next must still lie inside ONE range to travel by the shader.
-    PinnedRange nr{c, bytes, static_cast<char*>(dev), true, ++f.pin_clock, -1};
+    PinnedRange nr{c, bytes, static_cast<char*>(dev), true, ++f.pin_clock, -1, 0};
     for (bool merged = true; merged;) {
         merged = false;
         for (size_t i = 0; i < f.pinned.size(); ++i) {
@@ -440,7 +481,7 @@ void release_pipeline(jinc_filter& f) {
     }
     release_belts(f);
     for (auto& p : f.pinned)  // this instance's references to the process-wide registry; the last one unregisters
-        if (!p.adopted) shared_pin_release(p.base);
+        if (!p.adopted) shared_pin_release(p.id);
     f.pinned.clear();
 }
 
@@ -484,7 +525,7 @@ void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host
     f.register_host = register_host;
     if (!f.register_host) {  // ranges this instance pinned go; ranges the caller pinned stay known
         for (auto& p : f.pinned)
-            if (!p.adopted) shared_pin_release(p.base);
+            if (!p.adopted) shared_pin_release(p.id);
         f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(), [](const PinnedRange& r) { return !r.adopted; }), f.pinned.end());
     }
     ensure_belts(f);

@@ -6,6 +6,7 @@
 // compatibility with a real VapourSynth core.
 #include "VapourSynth4.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -41,6 +42,11 @@ struct VSFrame {
 struct VSCore {
     long live_frames = 0, live_nodes = 0;
     int stride_align = 64;
+    // Plane buffers of dead frames, kept for reuse by size for as long as the core lives -- as VapourSynth's own memory pool
+    // recycles frame buffers.  A filter that pins frame memory in place (JINCRESIZE_PIN_FRAMES) relies on exactly that: the
+    // host must not free pinned buffers while the filter instance lives.
+    std::multimap<size_t, std::vector<uint8_t>> pool;
+    long pool_reuses = 0;
 };
 
 struct VSFrameContext {
@@ -89,7 +95,16 @@ VSFrame* new_frame(VSCore* core, const VSVideoFormat& f, int w, int h) {
         fr->ph[p] = p ? h >> f.subSamplingH : h;
         const int a = core->stride_align;
         fr->stride[p] = (static_cast<ptrdiff_t>(fr->pw[p]) * f.bytesPerSample + a - 1) / a * a;
-        fr->buf[p].assign(static_cast<size_t>(fr->stride[p]) * fr->ph[p] + 64, 0xCD);
+        const size_t bytes = static_cast<size_t>(fr->stride[p]) * fr->ph[p] + 64;
+        auto it = core->pool.find(bytes);
+        if (it != core->pool.end()) {
+            fr->buf[p] = std::move(it->second);
+            core->pool.erase(it);
+            ++core->pool_reuses;
+            std::fill(fr->buf[p].begin(), fr->buf[p].end(), static_cast<uint8_t>(0xCD));
+        } else {
+            fr->buf[p].assign(bytes, 0xCD);
+        }
     }
     ++core->live_frames;
     return fr;
@@ -99,6 +114,11 @@ void frame_unref(const VSFrame* cf) {
     VSFrame* f = const_cast<VSFrame*>(cf);
     if (f && --f->refs == 0) {
         --g_core_of_api->live_frames;
+        for (int p = 0; p < 3; ++p)
+            if (!f->buf[p].empty()) {
+                const size_t bytes = f->buf[p].size();
+                g_core_of_api->pool.emplace(bytes, std::move(f->buf[p]));
+            }
         delete f;
     }
 }

@@ -401,6 +401,7 @@ def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, 
     single.close()
     of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(kw))
     h = Host(host)
+    host.mock_env_set_frame_pool(h.env, 4096)   # pinned in place: the host recycles frame buffers, it does not free them
     src = h.source(fmt, sw, sh, frames)
     clip, err = h.invoke(fn, src, tw, th, **named)
     assert err is None, err

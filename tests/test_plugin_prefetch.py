@@ -80,7 +80,7 @@ def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, 
     single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **named)
     of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(named))
     h = Host(host)
-    host.mock_env_set_frame_pool(h.env, 64)
+    host.mock_env_set_frame_pool(h.env, 4096)   # recycled, never freed while the instance lives (the contract of PIN_FRAMES)
     src = host.mock_source_new(h.env, sw, sh, fmt.bits, fmt.sample_bytes, fmt.planes, 1, int(fmt.rgb), fmt.sub_w, fmt.sub_h, nframes, -1, 64)
     want = {}
     for n in range(nframes):   # frame by frame: the source clip holds the frames, the expected results are kept as checksums
