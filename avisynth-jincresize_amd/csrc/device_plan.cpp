@@ -91,7 +91,7 @@ jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end);
 // dwords (fs 7: one s_load_dwordx16, the eighth pair is padding) or 20 (fs 9), the two q of a kernel row are adjacent.
 // `sets`: the four phase sets, FS x FS floats each, phase q * 2 + p (the plan's, or their trimmed copies).
 void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vector<const float*>& sets) {
-    if (!t.use_periodic || (FS != 6 && FS != 7 && FS != 9) || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] ||
+    if (!t.use_periodic || (FS != 6 && FS != 7 && FS != 8 && FS != 9) || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] ||
         pa.start_y[0] != pa.start_y[1])
         return;
     const int PR = FS == 9 ? 10 : 8;  // pairs per (kernel row, q), padded: 16 / 20 dwords

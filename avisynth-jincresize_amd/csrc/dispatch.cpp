@@ -58,6 +58,8 @@ struct Rules {
     static constexpr int kFlColsMinFrames = 64;
     // float planes on the trimmed support (a scan of the source and two launches per plane) from this many taps per plane and call on
     static constexpr double kFloatTrimMinTaps = 1.0e9;
+    // quad form on the trimmed 8 x 8 support (tap 4 at 2x) instead of the window kernel
+    static constexpr bool kQuad8 = true;
     // two-periods-per-lane quad form on the trimmed 6 x 6 support from this many half-height workgroups per launch on
     static constexpr long long kQuad2MinWorkgroups = 256;
     // ... and its half-height tiles (24 period-rows) below this many full-tile workgroups per launch
@@ -288,6 +290,13 @@ struct Choice {
             const long long wgs6 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 23) / 24) * nframes;
             return wgs6 >= Rules::kQuad2MinWorkgroups;
         }
+        if (periodic_fs(t) == 8) {  // one period per lane on the 8 x 8 support (tap 4 at 2x)
+            static const int knob = [] {
+                const char* e = std::getenv("JINC_QUAD8");  // A/B knob: 0 = window kernel, 1 = quad form (default: by measurement below)
+                return e ? std::atoi(e) : -1;
+            }();
+            return knob < 0 ? Rules::kQuad8 : knob != 0;
+        }
         const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
         // (fs 7: large planes only -- on 1280 x 720 the border kernels beside the denser interior become the step's tail:
         // C1 at 256 frames 492 -> 465 Gpix/s)
@@ -459,7 +468,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
     const bool periodic = !direct && !quasi && c.wants_periodic(t);
     t.last_kernel = direct     ? "ewa_direct_kernel"
                     : quasi    ? "ewa_quasi_kernel"
-                    : periodic ? (c.quad_chosen(t) ? (c.periodic_fs(t) == 6 ? "ewa_periodic_quad2_kernel" : "ewa_periodic_quad_kernel")
+                    : periodic ? (c.quad_chosen(t) ? (c.periodic_fs(t) == 6 ? "ewa_periodic_quad2_kernel" : c.periodic_fs(t) == 8 ? "ewa_periodic_quad8_kernel" : "ewa_periodic_quad_kernel")
                                   : (f.kernel_mode == 5 || f.kernel_mode == 6) && t.plan.fs == 7 ? "ewa_periodic_pk_kernel"
                                   : (f.kernel_mode == 3 || c.periodic_fs(t) < 6 || c.periodic_fs(t) > 9) ? "ewa_periodic_rows_kernel"
                                                                                                           : "ewa_periodic_kernel")

@@ -705,6 +705,159 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
 }
 
 // ------------------------------------------------------------------------------------------------
+// Periodic interior kernel, quad form on a trimmed 8 x 8 support (tap 4 at 2x: Jinc64Resize, C4)
+// ------------------------------------------------------------------------------------------------
+// The fs-7 quad form on eight taps per kernel row: every row starts on a register pair (no odd / even variants), the eight
+// coefficient pairs of a kernel row and q are exactly one s_load_dwordx16.  Against the window kernel on the same support:
+// half the VALU instructions, a quarter of the LDS reads, and -- what counts on float planes -- the two horizontally adjacent
+// samples of a lane leave as ONE store, so a wave's row is one contiguous run instead of every other sample of two.
+__device__ __forceinline__ void quad_row8(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c0, f32x2 c1, f32x2 c2, f32x2 c3, f32x2 c4,
+                                          f32x2 c5, f32x2 c6, f32x2 c7) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %6 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %2, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %13 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7));
+}
+
+template <int SLOT>
+__device__ __forceinline__ void quad_load_row8(f32x2 (&w)[32], const float* p) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        w[4 * SLOT + m].x = p[2 * m];
+        w[4 * SLOT + m].y = p[2 * m + 1];
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void quad_pixel8(f32x2& acc0, f32x2& acc1, const f32x2 (&w)[32], const JINC_CONSTANT f32x2* quad) {
+    f32x2 ca[16], cb[16];
+    quad_fetch(ca, quad, 0);
+#define JINC_QUAD8_STEP(LY, CUR, NEXT)                                                                                              \
+    if constexpr (LY < 7) quad_fetch(NEXT, quad, LY + 1);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    quad_arrived(CUR);                                                                                                               \
+    {                                                                                                                                \
+        constexpr int S = 4 * ((U + LY) % 8);                                                                                        \
+        quad_row8(acc0, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6], CUR[7]);         \
+        quad_row8(acc1, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14], CUR[15]);   \
+    }                                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);
+    JINC_QUAD8_STEP(0, ca, cb)
+    JINC_QUAD8_STEP(1, cb, ca)
+    JINC_QUAD8_STEP(2, ca, cb)
+    JINC_QUAD8_STEP(3, cb, ca)
+    JINC_QUAD8_STEP(4, ca, cb)
+    JINC_QUAD8_STEP(5, cb, ca)
+    JINC_QUAD8_STEP(6, ca, cb)
+    JINC_QUAD8_STEP(7, cb, ca)
+#undef JINC_QUAD8_STEP
+}
+
+template <typename T, int RG>
+__global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const PeriodicArgs a, const PlaneIO io) {
+    constexpr int FS = 8;
+    using Cfg = PeriodicCfg<FS, RG>;
+    static_assert(RG % 4 == 0, "the four waves of a workgroup take RG / 4 row groups each");
+    __shared__ float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
+        T staged[kRowsPerWave][kColsPerLane];
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            int gy = gy0 + wave + 4 * i;
+            gy = gy < a.src_h ? gy : a.src_h - 1;
+            const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                int gx = gx0 + lane + 64 * k;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                staged[i][k] = srow[gx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRowsPerWave; ++i) {
+            const int r = wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < kColsPerLane; ++k) {
+                const int c = lane + 64 * k;
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+            }
+        }
+    }
+    __syncthreads();
+    if ((i0 + lane) >= a.ni) return;  // no barrier below
+
+    const JINC_CONSTANT f32x2* quad = (const JINC_CONSTANT f32x2*)(a.quad);
+    const float* base = tile + (a.start_y[0] - a.min_sy) * Cfg::kLdsPitch + (a.start_x[0] - a.min_sx) + lane;
+    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+    const uint32_t xoff = static_cast<uint32_t>(a.ix0 + 2 * (i0 + lane)) * static_cast<uint32_t>(sizeof(T));
+
+    constexpr int kGroupsPerWave = RG / 4;
+    const int g_first = wave * kGroupsPerWave;
+    if (j0 + g_first * FS >= a.nj) return;  // wave-uniform: bottom tiles
+    f32x2 win[32];
+    {
+        const float* wb = base + (g_first * FS) * Cfg::kLdsPitch;
+        quad_load_row8<0>(win, wb + 0 * Cfg::kLdsPitch);
+        quad_load_row8<1>(win, wb + 1 * Cfg::kLdsPitch);
+        quad_load_row8<2>(win, wb + 2 * Cfg::kLdsPitch);
+        quad_load_row8<3>(win, wb + 3 * Cfg::kLdsPitch);
+        quad_load_row8<4>(win, wb + 4 * Cfg::kLdsPitch);
+        quad_load_row8<5>(win, wb + 5 * Cfg::kLdsPitch);
+        quad_load_row8<6>(win, wb + 6 * Cfg::kLdsPitch);
+    }
+    for (int g = g_first; g < g_first + kGroupsPerWave; ++g) {
+        if (j0 + g * FS >= a.nj) break;  // wave-uniform
+        const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#define JINC_QUAD8_ROW(U)                                                                                          \
+    {                                                                                                              \
+        quad_load_row8<(U + FS - 1) % FS>(win, gbase + (U + FS - 1) * Cfg::kLdsPitch);                              \
+        f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};                                                                 \
+        uint32_t zero;                                                                                              \
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
+        quad_pixel8<U>(acc0, acc1, win, quad + zero);                                                               \
+        const int j = j0 + g * FS + U;                                                                              \
+        if (j < a.nj) {                                                                                             \
+            const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
+            store_pair_buf<T>(drsrc, xoff, so, acc0, io.peak);                                                      \
+            store_pair_buf<T>(drsrc, xoff, so + static_cast<uint32_t>(io.dst_pitch), acc1, io.peak);                \
+        }                                                                                                           \
+    }
+        JINC_QUAD8_ROW(0) JINC_QUAD8_ROW(1) JINC_QUAD8_ROW(2) JINC_QUAD8_ROW(3) JINC_QUAD8_ROW(4) JINC_QUAD8_ROW(5) JINC_QUAD8_ROW(6) JINC_QUAD8_ROW(7)
+#undef JINC_QUAD8_ROW
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Periodic interior kernel, quad form on a trimmed 6 x 6 support, two periods per lane
 // ------------------------------------------------------------------------------------------------
 // Integer planes whose coefficient sets carry exact zeros along the window's edge run on the trimmed support (host:
@@ -1126,6 +1279,14 @@ int launch_periodic_quad9_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream
 }
 
 template <typename T, int RG>
+int launch_periodic_quad8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = PeriodicCfg<8, RG>;
+    dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_quad8_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <typename T, int RG>
 int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
@@ -1154,6 +1315,8 @@ template <typename T>
 int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
     if ((variant == 5 || variant == 6) && fs == 6 && pa.quad)  // trimmed support, two periods per lane: 5 = tiles of 8 row groups, 6 = of 4
         return variant == 5 ? launch_periodic_quad2_t<T, 8>(pa, io, stream) : launch_periodic_quad2_t<T, 4>(pa, io, stream);
+    if ((variant == 5 || variant == 6) && fs == 8 && pa.quad)  // trimmed 8 x 8 support: 5 = tiles of 8 row groups, 6 = of 4
+        return variant == 5 ? launch_periodic_quad8_t<T, 8>(pa, io, stream) : launch_periodic_quad8_t<T, 4>(pa, io, stream);
     if ((variant == 5 || variant == 6) && fs == 7 && pa.quad)  // quad form: 5 = tiles of 8 row groups, 6 = of 4 (small calls)
         return variant == 5 ? launch_periodic_quad_t<T, 8>(pa, io, stream) : launch_periodic_quad_t<T, 4>(pa, io, stream);
     if ((variant == 5 || variant == 6) && fs == 9 && pa.quad)

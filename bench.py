@@ -85,6 +85,8 @@ CONFIGS = {
     "T16": ("Y8", 1920, 1080, 3840, 2160, dict(tap=16), 16),  # tap 16: fs = 33 (1089 taps)
     "C2H": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=3), 128),  # C2's geometry on 16-bit 4:2:0 (luma and chroma both 2x, fs 7)
     "C2F": ("RGBPS", 1920, 1080, 3840, 2160, dict(tap=3), 64),       # ... and on float RGB
+    "C2T4": ("Y8", 1920, 1080, 3840, 2160, dict(tap=4), 256),        # Jinc64Resize at 2x: fs 9, support 8 x 8 on integer planes
+    "C2HT4": ("YUV420P16", 1920, 1080, 3840, 2160, dict(tap=4), 64),
 }
 
 

@@ -827,8 +827,7 @@ def test_quad_form_of_the_periodic_kernel(gpu_pkg, O, case, frames):
     f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, **kw)
     f.set_kernel_mode(13)
     # integer planes whose support trims to 6 x 6 take the two-periods-per-lane form; the others the one-period forms
-    # (an 8 x 8 support -- tap 4 on integer planes -- has no quad form: the window kernel on 64 taps)
-    quad_names = {6: ("ewa_periodic_quad2_kernel",), 8: ("ewa_periodic_kernel",)}.get(f.periodic_support(0), ("ewa_periodic_quad_kernel",))
+    quad_names = {6: ("ewa_periodic_quad2_kernel",), 8: ("ewa_periodic_quad8_kernel",)}.get(f.periodic_support(0), ("ewa_periodic_quad_kernel",))
     srcs = [O.lcg_frame(ofmt, sw, sh, seed=6100 + k) for k in range(frames)]
     if frames == 1:
         got = f.get_frame(srcs[0])
