@@ -58,6 +58,8 @@ struct Rules {
     static constexpr int kFlColsMinFrames = 64;
     // float planes on the trimmed support (a scan of the source and two launches per plane) from this many taps per plane and call on
     static constexpr double kFloatTrimMinTaps = 1.0e9;
+    // ... and its two-periods-per-lane form on integer planes from this many workgroups per launch on
+    static constexpr long long kQuad2x8MinWorkgroups = 4096;
     // quad form on the trimmed 8 x 8 support (tap 4 at 2x) instead of the window kernel
     static constexpr bool kQuad8 = true;
     // two-periods-per-lane quad form on the trimmed 6 x 6 support from this many half-height workgroups per launch on
@@ -575,6 +577,15 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     }();
                     if (force_rg == 8) variant = 5;
                     if (force_rg == 4) variant = 6;
+                    // 8 x 8 support on integer planes: two periods per lane (ewa_periodic_quad2x8_kernel) where the launch fills
+                    // the chip with its 128 x 32 tiles -- Jinc64 at 2x on 8-bit 483 -> 504 Gpix/s, 16-bit 4:2:0 253 -> 265; float
+                    // planes (C4) are level and stay with one period per lane (round4/quad2x8_ab.log)
+                    static const int two = [] {  // A/B knob: JINC_QUAD2X8 = 0 / 1
+                        const char* e = std::getenv("JINC_QUAD2X8");
+                        return e ? std::atoi(e) : -1;
+                    }();
+                    const long long wgs2 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 31) / 32) * nframes;
+                    if (pfs == 8 && (two >= 0 ? two != 0 : (sb < 4 && wgs2 >= Rules::kQuad2x8MinWorkgroups))) variant = 7;
                 }
                 if (c.trimmed(t) && t.trim_needs_finite) {
                     // float plane: which frames hold nothing but finite samples?  Those run on the trimmed support; the others

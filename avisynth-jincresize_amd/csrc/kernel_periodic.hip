@@ -1057,6 +1057,175 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two periods per lane on the trimmed 8 x 8 support (ewa_periodic_quad2x8_kernel): ewa_periodic_quad2_kernel's mapping for tap 4
+// ------------------------------------------------------------------------------------------------
+// A lane owns two adjacent periods = 4 x 2 output samples from one 8-row x 9-column register window (rows kept ten wide: five
+// register pairs, five aligned ds_read_b64 per row), four chains interleaved two by two, coefficient pairs shared by both
+// periods.  100 registers: five waves per SIMD.
+template <int RG>
+struct Quad2x8Cfg {
+    static constexpr int FS = 8;
+    static constexpr int kTileCols = 128;
+    static constexpr int kTileRows = FS * RG;
+    static constexpr int kLdsCols = kTileCols + FS;   // lane 63 reads columns 126 .. 135
+    static constexpr int kLdsPitch = 138;             // even
+    static constexpr int kLdsRows = kTileRows + FS - 1;
+};
+
+__device__ __forceinline__ void quad2_row8(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 w4, f32x2 c0, f32x2 c1,
+                                           f32x2 c2, f32x2 c3, f32x2 c4, f32x2 c5, f32x2 c6, f32x2 c7) {
+    f32x2 ta, tb;
+#define JINC_LO(T, W, C) "v_pk_mul_f32 " T ", " W ", " C " op_sel_hi:[0,1]\n\t"
+#define JINC_HI(T, W, C) "v_pk_mul_f32 " T ", " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define JINC_ADD2 "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+    asm(JINC_LO("%2", "%4", "%9") JINC_HI("%3", "%4", "%9") JINC_ADD2       // tap 0: A column 0, B column 1
+        JINC_HI("%2", "%4", "%10") JINC_LO("%3", "%5", "%10") JINC_ADD2     // tap 1: A 1, B 2
+        JINC_LO("%2", "%5", "%11") JINC_HI("%3", "%5", "%11") JINC_ADD2     // tap 2
+        JINC_HI("%2", "%5", "%12") JINC_LO("%3", "%6", "%12") JINC_ADD2     // tap 3
+        JINC_LO("%2", "%6", "%13") JINC_HI("%3", "%6", "%13") JINC_ADD2     // tap 4
+        JINC_HI("%2", "%6", "%14") JINC_LO("%3", "%7", "%14") JINC_ADD2     // tap 5
+        JINC_LO("%2", "%7", "%15") JINC_HI("%3", "%7", "%15") JINC_ADD2     // tap 6
+        JINC_HI("%2", "%7", "%16") JINC_LO("%3", "%8", "%16")               // tap 7: A 7, B 8
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+        : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7));
+#undef JINC_LO
+#undef JINC_HI
+#undef JINC_ADD2
+}
+
+template <int SLOT>
+__device__ __forceinline__ void quad2x8_load_row(f32x2 (&w)[40], const float* p) {
+    const f32x2* p2 = reinterpret_cast<const f32x2*>(p);
+#pragma unroll
+    for (int m = 0; m < 5; ++m) w[5 * SLOT + m] = p2[m];
+}
+
+template <int U>
+__device__ __forceinline__ void quad2_pixel8(f32x2 (&acc)[4], const f32x2 (&w)[40], const JINC_CONSTANT f32x2* quad) {
+    f32x2 ca[16], cb[16];
+    quad_fetch(ca, quad, 0);
+#define JINC_QUAD2X8_STEP(LY, CUR, NEXT)                                                                                                  \
+    if constexpr (LY < 7) quad_fetch(NEXT, quad, LY + 1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+    quad_arrived(CUR);                                                                                                                     \
+    {                                                                                                                                      \
+        constexpr int S = 5 * ((U + LY) % 8);                                                                                              \
+        quad2_row8(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6],   \
+                   CUR[7]);                                                                                                                \
+        quad2_row8(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13],       \
+                   CUR[14], CUR[15]);                                                                                                      \
+    }                                                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);
+    JINC_QUAD2X8_STEP(0, ca, cb)
+    JINC_QUAD2X8_STEP(1, cb, ca)
+    JINC_QUAD2X8_STEP(2, ca, cb)
+    JINC_QUAD2X8_STEP(3, cb, ca)
+    JINC_QUAD2X8_STEP(4, ca, cb)
+    JINC_QUAD2X8_STEP(5, cb, ca)
+    JINC_QUAD2X8_STEP(6, ca, cb)
+    JINC_QUAD2X8_STEP(7, cb, ca)
+#undef JINC_QUAD2X8_STEP
+}
+
+template <typename T, int RG>
+__global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const PeriodicArgs a, const PlaneIO io) {
+    using Cfg = Quad2x8Cfg<RG>;
+    constexpr int FS = Cfg::FS;
+    static_assert(RG % 4 == 0, "the four waves of a workgroup take RG / 4 row groups each");
+    __shared__ __attribute__((aligned(16))) float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int tile_x, tile_y;
+    swizzled_tile(tile_x, tile_y);
+    const int i0 = tile_x * Cfg::kTileCols;
+    const int j0 = tile_y * Cfg::kTileRows;
+    const size_t frame = blockIdx.z;
+    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    {   // stage the source tile as fp32, in two halves of the rows (all loads of a half in front of its LDS writes): the whole
+        // tile at once would hold more staged registers than the compute phase has
+        const int gx0 = a.min_sx + i0;
+        const int gy0 = a.min_sy + j0;
+        const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
+        constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
+        constexpr int kHalf = (kRowsPerWave + 1) / 2;
+        constexpr int kColsPerLane = (Cfg::kLdsPitch + 63) / 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            T staged[kHalf][kColsPerLane];
+#pragma unroll
+            for (int i = 0; i < kHalf; ++i) {
+                int gy = gy0 + wave + 4 * (h * kHalf + i);
+                gy = gy < a.src_h ? gy : a.src_h - 1;
+                const T* srow = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch);
+#pragma unroll
+                for (int k = 0; k < kColsPerLane; ++k) {
+                    int gx = gx0 + lane + 64 * k;
+                    gx = gx < a.src_w ? gx : a.src_w - 1;
+                    staged[i][k] = srow[gx];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < kHalf; ++i) {
+                const int r = wave + 4 * (h * kHalf + i);
+#pragma unroll
+                for (int k = 0; k < kColsPerLane; ++k) {
+                    const int c = lane + 64 * k;
+                    if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ia = i0 + 2 * lane;
+    if (ia >= a.ni) return;  // no barrier below
+    const bool b_ok = ia + 1 < a.ni;
+
+    const JINC_CONSTANT f32x2* quad = (const JINC_CONSTANT f32x2*)(a.quad);
+    const float* base = tile + 2 * lane;
+    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+    const uint32_t xoff = static_cast<uint32_t>(a.ix0 + 2 * ia) * static_cast<uint32_t>(sizeof(T));
+
+    constexpr int kGroupsPerWave = RG / 4;
+    const int g_first = wave * kGroupsPerWave;
+    if (j0 + g_first * FS >= a.nj) return;  // wave-uniform: bottom tiles
+    f32x2 win[40];
+    {
+        const float* wb = base + (g_first * FS) * Cfg::kLdsPitch;
+        quad2x8_load_row<0>(win, wb + 0 * Cfg::kLdsPitch);
+        quad2x8_load_row<1>(win, wb + 1 * Cfg::kLdsPitch);
+        quad2x8_load_row<2>(win, wb + 2 * Cfg::kLdsPitch);
+        quad2x8_load_row<3>(win, wb + 3 * Cfg::kLdsPitch);
+        quad2x8_load_row<4>(win, wb + 4 * Cfg::kLdsPitch);
+        quad2x8_load_row<5>(win, wb + 5 * Cfg::kLdsPitch);
+        quad2x8_load_row<6>(win, wb + 6 * Cfg::kLdsPitch);
+    }
+    for (int g = g_first; g < g_first + kGroupsPerWave; ++g) {
+        if (j0 + g * FS >= a.nj) break;  // wave-uniform
+        const float* gbase = base + (g * FS) * Cfg::kLdsPitch;
+#define JINC_QUAD2X8_ROW(U)                                                                                        \
+    {                                                                                                              \
+        quad2x8_load_row<(U + FS - 1) % FS>(win, gbase + (U + FS - 1) * Cfg::kLdsPitch);                            \
+        f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                            \
+        uint32_t zero;                                                                                              \
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
+        quad2_pixel8<U>(acc, win, quad + zero);                                                                     \
+        const int j = j0 + g * FS + U;                                                                              \
+        if (j < a.nj) {                                                                                             \
+            const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
+            store_quad_buf<T>(drsrc, xoff, so, acc[0], acc[1], io.peak, b_ok);                                      \
+            store_quad_buf<T>(drsrc, xoff, so + static_cast<uint32_t>(io.dst_pitch), acc[2], acc[3], io.peak, b_ok); \
+        }                                                                                                           \
+    }
+        JINC_QUAD2X8_ROW(0) JINC_QUAD2X8_ROW(1) JINC_QUAD2X8_ROW(2) JINC_QUAD2X8_ROW(3) JINC_QUAD2X8_ROW(4) JINC_QUAD2X8_ROW(5) JINC_QUAD2X8_ROW(6)
+        JINC_QUAD2X8_ROW(7)
+#undef JINC_QUAD2X8_ROW
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Periodic interior kernel, row-streamed form (any filter size, used for fs > 9)
 // ------------------------------------------------------------------------------------------------
 // Same phase-uniform idea as ewa_periodic_kernel (one phase per wave => coefficients in SGPRs), but
@@ -1287,6 +1456,14 @@ int launch_periodic_quad8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream
 }
 
 template <typename T, int RG>
+int launch_periodic_quad2x8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
+    using Cfg = Quad2x8Cfg<RG>;
+    dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <typename T, int RG>
 int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
@@ -1315,6 +1492,7 @@ template <typename T>
 int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStream_t stream, int variant) {
     if ((variant == 5 || variant == 6) && fs == 6 && pa.quad)  // trimmed support, two periods per lane: 5 = tiles of 8 row groups, 6 = of 4
         return variant == 5 ? launch_periodic_quad2_t<T, 8>(pa, io, stream) : launch_periodic_quad2_t<T, 4>(pa, io, stream);
+    if (variant == 7 && fs == 8 && pa.quad) return launch_periodic_quad2x8_t<T, 4>(pa, io, stream);  // two periods per lane
     if ((variant == 5 || variant == 6) && fs == 8 && pa.quad)  // trimmed 8 x 8 support: 5 = tiles of 8 row groups, 6 = of 4
         return variant == 5 ? launch_periodic_quad8_t<T, 8>(pa, io, stream) : launch_periodic_quad8_t<T, 4>(pa, io, stream);
     if ((variant == 5 || variant == 6) && fs == 7 && pa.quad)  // quad form: 5 = tiles of 8 row groups, 6 = of 4 (small calls)

@@ -964,3 +964,25 @@ def test_border_columns_of_periodic_plans_in_batches(gpu_pkg, O, fmt, sw, sh, tw
         if k in (0, 63, frames - 1):
             assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=4), f.out_dims(), what=f"{fmt} frame {k} vs oracle")
     f.close()
+
+
+@pytest.mark.parametrize("fmt", ["Y8", "Y16"])
+def test_jinc64_at_2x_in_batches_takes_two_periods_per_lane(gpu_pkg, O, fmt):
+    """1080p -> 4K with tap 4 on integer planes, nine frames per call: enough 128 x 32 tiles for ewa_periodic_quad2x8_kernel (two
+    periods per lane on the 8 x 8 support) to be the automatic choice.  Every frame against the full-window result (kernel mode
+    15), two of them against the oracle."""
+    torch = pytest.importorskip("torch")
+    from test_framelane_pair import _run_batch
+    sw, sh, tw, th, frames = 1920, 1080, 3840, 2160, 9
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, tap=4)
+    assert f.plan_info(0).filter_size == 9 and f.periodic_support(0) == 8
+    srcs = [O.lcg_frame(ofmt, sw, sh, seed=9900 + k) for k in range(frames)]
+    auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+    full = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 15)
+    of = O.OracleFilter(ofmt, sw, sh, tw, th, tap=4)
+    for k in range(frames):
+        assert_planes_equal(auto[k], full[k], f.out_dims(), what=f"{fmt} frame {k}: trimmed two-period form vs full window")
+        if k in (0, frames - 1):
+            assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=8), f.out_dims(), what=f"{fmt} frame {k} vs oracle")
+    f.close()
