@@ -514,9 +514,10 @@ class Filter:
         """Taps per axis the periodic interior kernels execute (trimmed support on integer planes), 0: no periodic interior."""
         return int(lib().jinc_filter_periodic_support(self._h, int(table)))
 
-    def periodic_taps(self, table: int = 0, rows_kernel: bool = False) -> float:
-        """Taps per output sample the periodic interior kernels execute (0: no periodic interior)."""
-        return float(lib().jinc_filter_periodic_taps(self._h, int(table), int(bool(rows_kernel))))
+    def periodic_taps(self, table: int = 0, rows_kernel=False) -> float:
+        """Taps per output sample the periodic interior kernels execute (0: no periodic interior); rows_kernel: False / True = window
+        and quad forms / rows kernel, 2 = the direct kernel's interior."""
+        return float(lib().jinc_filter_periodic_taps(self._h, int(table), int(rows_kernel)))
 
     def interior_kernel(self, table: int = 0) -> str:
         return lib().jinc_filter_interior_kernel(self._h, int(table)).decode()

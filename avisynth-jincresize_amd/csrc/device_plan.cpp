@@ -193,6 +193,23 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         std::vector<const float*> sets;
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * n * n);
         attach_quad(t, t.periodic_trim, n, sets);
+        if (n == 6 && t.periodic_trim.quad) {  // kernel rows whose first and last tap are zero for both p of a q: the chord in the box's edge rows
+            static const bool off = [] {
+                const char* e = std::getenv("JINC_QUAD_INNER");  // A/B knob
+                return e && std::atoi(e) == 0;
+            }();
+            uint32_t inner = 0;
+            for (int q = 0; q < 2 && !off; ++q)
+                for (int ly = 0; ly < n; ++ly) {
+                    bool zero = true;
+                    for (int px = 0; px < 2; ++px) {
+                        const float* r = sets[static_cast<size_t>(q * 2 + px)] + ly * n;
+                        zero = zero && r[0] == 0.f && r[n - 1] == 0.f;
+                    }
+                    if (zero) inner |= 1u << (2 * ly + q);
+                }
+            t.periodic_trim.quad_inner = inner;
+        }
     }
 }
 

@@ -388,6 +388,11 @@ int jinc_filter_periodic_support(const jinc_filter* f, int table) {
 double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kernel) {
     if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return 0;
     const DeviceTable& t = f->tables[table];
+    if (rows_kernel == 2) {  // the direct kernel's interior
+        if (!t.use_direct) return 0;
+        const int n = (t.direct_trim_fs > 0 && !f->full_window) ? t.direct_trim_fs : t.plan.fs;
+        return static_cast<double>(n) * n;
+    }
     if (!t.use_periodic) return 0;
     if (t.trim_fs > 0 && !f->full_window) return rows_kernel ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
     return static_cast<double>(t.plan.fs) * t.plan.fs;

@@ -905,6 +905,25 @@ __device__ __forceinline__ void quad2_row6(f32x2& acc_a, f32x2& acc_b, f32x2 w0,
 #undef JINC_ADD2
 }
 
+// The same kernel row where tap 0 and tap 5 carry zero coefficients for BOTH phases p of this q (the disc's chord in the box's
+// first / last row: host, PeriodicArgs::quad_inner): taps 1 .. 4 only.
+__device__ __forceinline__ void quad2_row6_inner(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 c1, f32x2 c2, f32x2 c3, f32x2 c4) {
+    f32x2 ta, tb;
+#define JINC_LO(T, W, C) "v_pk_mul_f32 " T ", " W ", " C " op_sel_hi:[0,1]\n\t"
+#define JINC_HI(T, W, C) "v_pk_mul_f32 " T ", " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define JINC_ADD2 "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+    asm(JINC_HI("%2", "%4", "%7") JINC_LO("%3", "%5", "%7") JINC_ADD2      // tap 1: A column 1, B column 2
+        JINC_LO("%2", "%5", "%8") JINC_HI("%3", "%5", "%8") JINC_ADD2      // tap 2: A 2, B 3
+        JINC_HI("%2", "%5", "%9") JINC_LO("%3", "%6", "%9") JINC_ADD2      // tap 3: A 3, B 4
+        JINC_LO("%2", "%6", "%10") JINC_HI("%3", "%6", "%10")              // tap 4: A 4, B 5
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+        : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+        : "v"(w0), "v"(w1), "v"(w2), "s"(c1), "s"(c2), "s"(c3), "s"(c4));
+#undef JINC_LO
+#undef JINC_HI
+#undef JINC_ADD2
+}
+
 // Window slot SLOT <- eight source columns of one tile row (four aligned ds_read_b64).
 template <int SLOT>
 __device__ __forceinline__ void quad2_load_row(f32x2 (&w)[24], const float* p) {
@@ -915,7 +934,7 @@ __device__ __forceinline__ void quad2_load_row(f32x2 (&w)[24], const float* p) {
 
 // One output row pair of both periods: acc[0] / acc[1] = period A / B at q = 0, acc[2] / acc[3] at q = 1.  Coefficient pairs of
 // kernel row ly + 1 are requested before the taps of row ly are issued, as in quad_pixel7.
-template <int U>
+template <int U, uint32_t INNER>
 __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[24], const JINC_CONSTANT f32x2* quad) {
     f32x2 ca[16], cb[16];
     quad_fetch(ca, quad, 0);
@@ -925,8 +944,15 @@ __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[2
     quad_arrived(CUR);                                                                                                         \
     {                                                                                                                          \
         constexpr int S = 4 * ((U + LY) % 6);                                                                                  \
-        quad2_row6(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5]);        \
-        quad2_row6(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13]);    \
+        /* INNER: a compile-time mask (a run-time test here, however uniform, cost 8 % of the kernel: round4/quad_inner_ab.log) */ \
+        if constexpr ((INNER >> (2 * LY)) & 1u)                                                                                \
+            quad2_row6_inner(acc[0], acc[1], w[S], w[S + 1], w[S + 2], CUR[1], CUR[2], CUR[3], CUR[4]);                        \
+        else                                                                                                                   \
+            quad2_row6(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5]);    \
+        if constexpr ((INNER >> (2 * LY + 1)) & 1u)                                                                            \
+            quad2_row6_inner(acc[2], acc[3], w[S], w[S + 1], w[S + 2], CUR[9], CUR[10], CUR[11], CUR[12]);                     \
+        else                                                                                                                   \
+            quad2_row6(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13]); \
     }                                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
     JINC_QUAD2_STEP(0, ca, cb)
@@ -966,7 +992,11 @@ __device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset
     }
 }
 
-template <typename T, int RG>
+// INNER: bit 2 * ly + q set = taps 0 and 5 of kernel row ly are zero for both phases p of q and are not executed (the disc's chord
+// in the box's edge rows).  Instantiated for no such rows and for the pattern of the 2x up-scale with tap 3 at blur 1 (q = 0: the
+// last kernel row, q = 1: the first): the launcher takes the instantiation whose mask is a subset of the plan's.
+constexpr uint32_t kQuad2InnerTap3 = (1u << (2 * 5 + 0)) | (1u << (2 * 0 + 1));
+template <typename T, int RG, uint32_t INNER>
 __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const PeriodicArgs a, const PlaneIO io) {
     using Cfg = Quad2Cfg<RG>;
     constexpr int FS = Cfg::FS;
@@ -1043,7 +1073,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                            \
         uint32_t zero;                                                                                              \
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
-        quad2_pixel6<U>(acc, win, quad + zero);                                                                     \
+        quad2_pixel6<U, INNER>(acc, win, quad + zero);                                                              \
         const int j = j0 + g * FS + U;                                                                              \
         if (j < a.nj) {                                                                                             \
             const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
@@ -1467,7 +1497,10 @@ template <typename T, int RG>
 int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    if ((pa.quad_inner & kQuad2InnerTap3) == kQuad2InnerTap3)
+        hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, kQuad2InnerTap3>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    else
+        hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -85,6 +85,8 @@ struct PeriodicArgs {
     // 2x up-scales whose phases share their window origin (ewa_periodic_quad_kernel): coefficient pairs
     // quad[ly][q][8 pairs][p] = (set(p=0,q), set(p=1,q))[ly][lx], or nullptr when the plan has no such form
     const float* quad = nullptr;
+    // ewa_periodic_quad2_kernel: bit 2 * ly + q set = taps 0 and 5 of kernel row ly carry zero coefficients for both phases p of q
+    uint32_t quad_inner = 0;
     // trimmed support only (ewa_periodic_rows_kernel): row_trim[phase * 32 + ly] = taps kernel row ly of the phase leaves out on
     // EITHER side (min of its leading and trailing zero coefficients, at most 5), or nullptr
     const int32_t* row_trim = nullptr;
