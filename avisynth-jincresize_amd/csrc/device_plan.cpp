@@ -210,6 +210,26 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
                 }
             t.periodic_trim.quad_inner = inner;
         }
+        if (n == 8 && t.periodic_trim.quad) {  // 8 x 8 support: taps every (kernel row, q) leaves out per side for both p
+            static const bool off = [] {
+                const char* e = std::getenv("JINC_QUAD_INNER");
+                return e && std::atoi(e) == 0;
+            }();
+            uint32_t tr8 = 0;
+            for (int q = 0; q < 2 && !off; ++q)
+                for (int ly = 0; ly < n; ++ly) {
+                    int trim = 3;
+                    for (int px = 0; px < 2; ++px) {
+                        const float* r = sets[static_cast<size_t>(q * 2 + px)] + ly * n;
+                        int lead = 0, trail = 0;
+                        while (lead < n && r[lead] == 0.f) ++lead;
+                        while (trail < n && r[n - 1 - trail] == 0.f) ++trail;
+                        trim = std::min(trim, std::min(lead, trail));
+                    }
+                    tr8 |= static_cast<uint32_t>(trim) << (2 * (2 * ly + q));
+                }
+            t.periodic_trim.quad_trim8 = tr8;
+        }
     }
 }
 

@@ -394,7 +394,13 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
         return static_cast<double>(n) * n;
     }
     if (!t.use_periodic) return 0;
-    if (t.trim_fs > 0 && !f->full_window) return rows_kernel ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
+    if (rows_kernel == 3 && t.trim_fs == 6 && !f->full_window &&  // ewa_periodic_quad2_kernel: chord rows on four taps (half the samples each)
+        (t.periodic_trim.quad_inner & jinc::PeriodicArgs::kQuadInnerTap3) == jinc::PeriodicArgs::kQuadInnerTap3)
+        return 34.0;
+    if (rows_kernel == 3 && t.trim_fs == 8 && !f->full_window && t.periodic_trim.quad &&  // quad forms on the 8 x 8 support with the tap-4 pattern
+        jinc::quad8_pattern_fits(t.periodic_trim.quad_trim8, jinc::kQuad8TrimTap4Value))
+        return 56.0;
+    if (t.trim_fs > 0 && !f->full_window) return rows_kernel == 1 ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
     return static_cast<double>(t.plan.fs) * t.plan.fs;
 }
 

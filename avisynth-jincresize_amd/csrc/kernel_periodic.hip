@@ -734,6 +734,86 @@ __device__ __forceinline__ void quad_row8(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 
         : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6), "s"(c7));
 }
 
+// Kernel rows of the 8 x 8 support without their first and last t taps (t = 1: taps 1 .. 6, t = 2: taps 2 .. 5): rows in which those
+// taps carry zero coefficients for both phases p of a q -- the disc's chords near the box's top and bottom (compile-time
+// pattern TR8 of the quad kernels below; generated, like the full rows, as one asm statement each).
+__device__ __forceinline__ void quad_row8_t1(f32x2& acc, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c1, f32x2 c2, f32x2 c3, f32x2 c4, f32x2 c5, f32x2 c6) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %6 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %8 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %4, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %5, %11 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+}
+__device__ __forceinline__ void quad_row8_t2(f32x2& acc, f32x2 w1, f32x2 w2, f32x2 c2, f32x2 c3, f32x2 c4, f32x2 c5) {
+    f32x2 t;
+    asm("v_pk_mul_f32 %1, %2, %4 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %2, %5 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %6 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_mul_f32 %1, %3, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1"
+        : "+v"(acc), "=&v"(t)
+        : "v"(w1), "v"(w2), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+}
+__device__ __forceinline__ void quad2_row8_t1(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c1, f32x2 c2, f32x2 c3, f32x2 c4, f32x2 c5, f32x2 c6) {
+    f32x2 ta, tb;
+    asm("v_pk_mul_f32 %2, %4, %8 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %5, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %5, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %6, %11 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %6, %12 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %7, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %7, %13 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %7, %13 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+        : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+}
+__device__ __forceinline__ void quad2_row8_t2(f32x2& acc_a, f32x2& acc_b, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c2, f32x2 c3, f32x2 c4, f32x2 c5) {
+    f32x2 ta, tb;
+    asm("v_pk_mul_f32 %2, %4, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %4, %7 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %4, %8 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %5, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %5, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+        : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+        : "v"(w1), "v"(w2), "v"(w3), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+}
+
+// TR8: compile-time pattern of such rows, two bits per (kernel row ly, q) at bit 2 * (2 * ly + q).  Instantiated for "none" and
+// for the 2x up-scale with tap 4 (blur 1 and 0.98): q = 0 rows 0 / 6 / 7 leave out 1 / 1 / 2 taps per side, q = 1 rows 0 / 1 / 7
+// leave out 2 / 1 / 1 -- 56 instead of 64 taps per sample.  The launcher takes the pattern when the plan's rows allow at least it.
+constexpr uint32_t kQuad8TrimTap4 = kQuad8TrimTap4Value;
+constexpr int quad8_trim_of(uint32_t tr8, int ly, int q) { return static_cast<int>((tr8 >> (2 * (2 * ly + q))) & 3u); }
+
 template <int SLOT>
 __device__ __forceinline__ void quad_load_row8(f32x2 (&w)[32], const float* p) {
 #pragma unroll
@@ -743,7 +823,7 @@ __device__ __forceinline__ void quad_load_row8(f32x2 (&w)[32], const float* p) {
     }
 }
 
-template <int U>
+template <int U, uint32_t TR8>
 __device__ __forceinline__ void quad_pixel8(f32x2& acc0, f32x2& acc1, const f32x2 (&w)[32], const JINC_CONSTANT f32x2* quad) {
     f32x2 ca[16], cb[16];
     quad_fetch(ca, quad, 0);
@@ -753,8 +833,18 @@ __device__ __forceinline__ void quad_pixel8(f32x2& acc0, f32x2& acc1, const f32x
     quad_arrived(CUR);                                                                                                               \
     {                                                                                                                                \
         constexpr int S = 4 * ((U + LY) % 8);                                                                                        \
-        quad_row8(acc0, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6], CUR[7]);         \
-        quad_row8(acc1, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14], CUR[15]);   \
+        if constexpr (quad8_trim_of(TR8, LY, 0) == 2)                                                                                \
+            quad_row8_t2(acc0, w[S + 1], w[S + 2], CUR[2], CUR[3], CUR[4], CUR[5]);                                                  \
+        else if constexpr (quad8_trim_of(TR8, LY, 0) == 1)                                                                           \
+            quad_row8_t1(acc0, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6]);                  \
+        else                                                                                                                         \
+            quad_row8(acc0, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6], CUR[7]);     \
+        if constexpr (quad8_trim_of(TR8, LY, 1) == 2)                                                                                \
+            quad_row8_t2(acc1, w[S + 1], w[S + 2], CUR[10], CUR[11], CUR[12], CUR[13]);                                              \
+        else if constexpr (quad8_trim_of(TR8, LY, 1) == 1)                                                                           \
+            quad_row8_t1(acc1, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14]);             \
+        else                                                                                                                         \
+            quad_row8(acc1, w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14], CUR[15]); \
     }                                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);
     JINC_QUAD8_STEP(0, ca, cb)
@@ -768,7 +858,7 @@ __device__ __forceinline__ void quad_pixel8(f32x2& acc0, f32x2& acc1, const f32x
 #undef JINC_QUAD8_STEP
 }
 
-template <typename T, int RG>
+template <typename T, int RG, uint32_t TR8>
 __global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const PeriodicArgs a, const PlaneIO io) {
     constexpr int FS = 8;
     using Cfg = PeriodicCfg<FS, RG>;
@@ -844,7 +934,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const Period
         f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};                                                                 \
         uint32_t zero;                                                                                              \
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
-        quad_pixel8<U>(acc0, acc1, win, quad + zero);                                                               \
+        quad_pixel8<U, TR8>(acc0, acc1, win, quad + zero);                                                          \
         const int j = j0 + g * FS + U;                                                                              \
         if (j < a.nj) {                                                                                             \
             const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
@@ -995,7 +1085,7 @@ __device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset
 // INNER: bit 2 * ly + q set = taps 0 and 5 of kernel row ly are zero for both phases p of q and are not executed (the disc's chord
 // in the box's edge rows).  Instantiated for no such rows and for the pattern of the 2x up-scale with tap 3 at blur 1 (q = 0: the
 // last kernel row, q = 1: the first): the launcher takes the instantiation whose mask is a subset of the plan's.
-constexpr uint32_t kQuad2InnerTap3 = (1u << (2 * 5 + 0)) | (1u << (2 * 0 + 1));
+constexpr uint32_t kQuad2InnerTap3 = PeriodicArgs::kQuadInnerTap3;
 template <typename T, int RG, uint32_t INNER>
 __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const PeriodicArgs a, const PlaneIO io) {
     using Cfg = Quad2Cfg<RG>;
@@ -1131,7 +1221,7 @@ __device__ __forceinline__ void quad2x8_load_row(f32x2 (&w)[40], const float* p)
     for (int m = 0; m < 5; ++m) w[5 * SLOT + m] = p2[m];
 }
 
-template <int U>
+template <int U, uint32_t TR8>
 __device__ __forceinline__ void quad2_pixel8(f32x2 (&acc)[4], const f32x2 (&w)[40], const JINC_CONSTANT f32x2* quad) {
     f32x2 ca[16], cb[16];
     quad_fetch(ca, quad, 0);
@@ -1141,10 +1231,20 @@ __device__ __forceinline__ void quad2_pixel8(f32x2 (&acc)[4], const f32x2 (&w)[4
     quad_arrived(CUR);                                                                                                                     \
     {                                                                                                                                      \
         constexpr int S = 5 * ((U + LY) % 8);                                                                                              \
-        quad2_row8(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6],   \
-                   CUR[7]);                                                                                                                \
-        quad2_row8(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13],       \
-                   CUR[14], CUR[15]);                                                                                                      \
+        if constexpr (quad8_trim_of(TR8, LY, 0) == 2)                                                                                      \
+            quad2_row8_t2(acc[0], acc[1], w[S + 1], w[S + 2], w[S + 3], CUR[2], CUR[3], CUR[4], CUR[5]);                                   \
+        else if constexpr (quad8_trim_of(TR8, LY, 0) == 1)                                                                                 \
+            quad2_row8_t1(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6]);             \
+        else                                                                                                                               \
+            quad2_row8(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5],       \
+                       CUR[6], CUR[7]);                                                                                                    \
+        if constexpr (quad8_trim_of(TR8, LY, 1) == 2)                                                                                      \
+            quad2_row8_t2(acc[2], acc[3], w[S + 1], w[S + 2], w[S + 3], CUR[10], CUR[11], CUR[12], CUR[13]);                               \
+        else if constexpr (quad8_trim_of(TR8, LY, 1) == 1)                                                                                 \
+            quad2_row8_t1(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14]);        \
+        else                                                                                                                               \
+            quad2_row8(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13],   \
+                       CUR[14], CUR[15]);                                                                                                  \
     }                                                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
     JINC_QUAD2X8_STEP(0, ca, cb)
@@ -1158,7 +1258,7 @@ __device__ __forceinline__ void quad2_pixel8(f32x2 (&acc)[4], const f32x2 (&w)[4
 #undef JINC_QUAD2X8_STEP
 }
 
-template <typename T, int RG>
+template <typename T, int RG, uint32_t TR8>
 __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const PeriodicArgs a, const PlaneIO io) {
     using Cfg = Quad2x8Cfg<RG>;
     constexpr int FS = Cfg::FS;
@@ -1241,7 +1341,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                            \
         uint32_t zero;                                                                                              \
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
-        quad2_pixel8<U>(acc, win, quad + zero);                                                                     \
+        quad2_pixel8<U, TR8>(acc, win, quad + zero);                                                                \
         const int j = j0 + g * FS + U;                                                                              \
         if (j < a.nj) {                                                                                             \
             const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
@@ -1481,7 +1581,10 @@ template <typename T, int RG>
 int launch_periodic_quad8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = PeriodicCfg<8, RG>;
     dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    hipLaunchKernelGGL((ewa_periodic_quad8_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    if (quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4))
+        hipLaunchKernelGGL((ewa_periodic_quad8_kernel<T, RG, kQuad8TrimTap4>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    else
+        hipLaunchKernelGGL((ewa_periodic_quad8_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1489,7 +1592,10 @@ template <typename T, int RG>
 int launch_periodic_quad2x8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2x8Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    if (quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4))
+        hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, kQuad8TrimTap4>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    else
+        hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     return static_cast<int>(hipGetLastError());
 }
 

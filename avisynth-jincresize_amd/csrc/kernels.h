@@ -87,6 +87,10 @@ struct PeriodicArgs {
     const float* quad = nullptr;
     // ewa_periodic_quad2_kernel: bit 2 * ly + q set = taps 0 and 5 of kernel row ly carry zero coefficients for both phases p of q
     uint32_t quad_inner = 0;
+    static constexpr uint32_t kQuadInnerTap3 = (1u << (2 * 5 + 0)) | (1u << (2 * 0 + 1));  // the mask the kernel is instantiated for
+    // quad forms on the 8 x 8 support: taps kernel row ly of q leaves out per side (0 .. 3), two bits at 2 * (2 * ly + q)
+    uint32_t quad_trim8 = 0;
+    static const uint32_t kQuad8TrimTap4;  // the pattern the kernels are instantiated for (below)
     // trimmed support only (ewa_periodic_rows_kernel): row_trim[phase * 32 + ly] = taps kernel row ly of the phase leaves out on
     // EITHER side (min of its leading and trailing zero coefficients, at most 5), or nullptr
     const int32_t* row_trim = nullptr;
@@ -96,6 +100,19 @@ struct PeriodicArgs {
     const uint32_t* frame_flags = nullptr;
     uint32_t run_when = 0;
 };
+
+// Quad forms on the 8 x 8 support: per (kernel row ly, q) the taps left out per side, two bits at 2 * (2 * ly + q).  The pattern
+// the kernels are instantiated for is the 2x up-scale with tap 4 (blur 1 and 0.98): q = 0 rows 0 / 6 / 7 leave out 1 / 1 / 2 taps
+// per side, q = 1 rows 0 / 1 / 7 leave out 2 / 1 / 1 -- 56 instead of 64 taps per sample.
+constexpr uint32_t quad8_bits(int ly, int q, int t) { return static_cast<uint32_t>(t) << (2 * (2 * ly + q)); }
+constexpr uint32_t kQuad8TrimTap4Value = quad8_bits(0, 0, 1) | quad8_bits(6, 0, 1) | quad8_bits(7, 0, 2) | quad8_bits(0, 1, 2) |
+                                         quad8_bits(1, 1, 1) | quad8_bits(7, 1, 1);
+inline constexpr uint32_t PeriodicArgs::kQuad8TrimTap4 = kQuad8TrimTap4Value;
+inline bool quad8_pattern_fits(uint32_t plan, uint32_t pattern) {  // the plan leaves out at least what the pattern leaves out
+    for (int k = 0; k < 16; ++k)
+        if (((plan >> (2 * k)) & 3u) < ((pattern >> (2 * k)) & 3u)) return false;
+    return true;
+}
 
 // Quasi-periodic interior: the window origins are affine per residue (output pixel (ix0 + px*i + p,
 // iy0 + py*j + q) reads the source window at (start_x[p] + sx*i, start_y[q] + sy*j)) but the coefficient

@@ -760,7 +760,8 @@ def main(argv=None):
             tbl = 1 if (flt.num_tables > 1 and i in (1, 2)) else 0
             fs_t = flt.plan_info(tbl).filter_size
             kname = flt.last_kernel(tbl)
-            taps = (flt.periodic_taps(tbl, rows_kernel="rows" in kname) if kname.startswith("ewa_periodic")
+            taps = (flt.periodic_taps(tbl, rows_kernel=3) if kname in ("ewa_periodic_quad2_kernel", "ewa_periodic_quad8_kernel")
+                    else flt.periodic_taps(tbl, rows_kernel="rows" in kname) if kname.startswith("ewa_periodic")
                     else flt.periodic_taps(tbl, rows_kernel=2) if kname == "ewa_direct_kernel" else 0.0)
             taps_exec += w * h * (taps or fs_t * fs_t)
             taps_ref += w * h * fs_t * fs_t
