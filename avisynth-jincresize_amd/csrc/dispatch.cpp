@@ -590,13 +590,20 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 if (c.trimmed(t) && t.trim_needs_finite) {
                     // float plane: which frames hold nothing but finite samples?  Those run on the trimmed support; the others
                     // (flag 1) on the reference's full window in a second launch that returns at once for the rest.
+                    // (a ring of flag sets, one per call in turn like the fork / join events: calls queued on different streams
+                    // may overlap on the device, and a set must not be cleared under a launch that still reads it)
+                    constexpr int kFlagSets = jinc_filter::kForkEvents;
                     if (f.finite_flags_frames < io.nframes) {
-                        if (f.finite_flags) (void)hipFree(f.finite_flags);
+                        if (f.finite_flags) {
+                            hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize(finite flags)");  // launches of earlier calls may still read the old sets
+                            (void)hipFree(f.finite_flags);
+                        }
                         f.finite_flags = nullptr, f.finite_flags_frames = 0;
-                        hip_check(hipMalloc(reinterpret_cast<void**>(&f.finite_flags), sizeof(uint32_t) * 4 * static_cast<size_t>(io.nframes)), "hipMalloc(finite flags)");
+                        hip_check(hipMalloc(reinterpret_cast<void**>(&f.finite_flags), sizeof(uint32_t) * kFlagSets * 4 * static_cast<size_t>(io.nframes)),
+                                  "hipMalloc(finite flags)");
                         f.finite_flags_frames = io.nframes;
                     }
-                    uint32_t* flags = f.finite_flags + static_cast<size_t>(i) * f.finite_flags_frames;
+                    uint32_t* flags = f.finite_flags + (static_cast<size_t>(f.finite_flags_turn % kFlagSets) * 4 + static_cast<size_t>(i)) * f.finite_flags_frames;
                     hip_check(hipMemsetAsync(flags, 0, sizeof(uint32_t) * io.nframes, s), "hipMemsetAsync(finite flags)");
                     int rc = jinc::launch_finite_scan(io, t.plan.src_w, t.plan.src_h, flags, s);
                     if (rc) return rc;
@@ -646,6 +653,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
     const bool fork = c.any_border_frame() && c.wants_border_overlap();
     const bool plane_fork = c.wants_plane_fork(fork);
     const unsigned turn = f.fork_turn % jinc_filter::kForkEvents;
+    ++f.finite_flags_turn;  // (float planes on the trimmed support: a flag set of its own per call)
     if (fork || plane_fork) {  // side-stream work may start once everything already queued on `stream` is done
         ++f.fork_turn;
         hip_check(hipEventRecord(f.ev_fork[turn], stream), "hipEventRecord(fork)");

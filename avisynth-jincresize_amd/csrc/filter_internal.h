@@ -175,8 +175,9 @@ struct jinc_filter {
     std::vector<jinc::PlanePlan> plans;  // [0] luma / all planes, [1] chroma of subsampled formats
     int kernel_mode = 0;
     bool full_window = false;  // kernel mode 15: no trimmed support (the reference's full window everywhere)
-    uint32_t* finite_flags = nullptr;  // [4 planes][finite_flags_frames]: kernel_scan.hip's verdict per plane and frame (float planes)
+    uint32_t* finite_flags = nullptr;  // [kForkEvents sets][4 planes][finite_flags_frames]: kernel_scan.hip's verdict per plane and frame (float planes)
     int finite_flags_frames = 0;
+    unsigned finite_flags_turn = 0;  // which of the kForkEvents flag sets the current call uses (advanced once per call: dispatch.cpp enqueue)
     int border_strips = -1;  // border frame of exactly periodic plans: -1 by call size (dispatch.cpp Rules), 1 strip kernels, 2 rows only, 0 gather kernel
     bool direct_premise = false;  // buffer_range_check_covers_soffset(device) == 1
     int simd_order = 0;  // 0: opt=0 results (default); 1 / 2 / 3: summation order of the reference's SSE4.1 / AVX2 / AVX-512 path
