@@ -90,17 +90,19 @@ jinc::RectList border_frame(const jinc::PlanePlan& p, int x_end, int y_end);
 // (filter sizes 7 and 9): quad[ly][q][8 or 10 pairs][p] = (set(p = 0, q), set(p = 1, q))[ly][lx]; a kernel row of one q is 16
 // dwords (fs 7: one s_load_dwordx16, the eighth pair is padding) or 20 (fs 9), the two q of a kernel row are adjacent.
 // `sets`: the four phase sets, FS x FS floats each, phase q * 2 + p (the plan's, or their trimmed copies).
-void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vector<const float*>& sets) {
+// (FS rows of NX taps each; NX = 0: FS)
+void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vector<const float*>& sets, int NX = 0) {
+    if (NX == 0) NX = FS;
     if (!t.use_periodic || (FS != 6 && FS != 7 && FS != 8 && FS != 9) || pa.px != 2 || pa.py != 2 || pa.start_x[0] != pa.start_x[1] ||
         pa.start_y[0] != pa.start_y[1])
         return;
-    const int PR = FS == 9 ? 10 : 8;  // pairs per (kernel row, q), padded: 16 / 20 dwords
+    const int PR = NX == 9 ? 10 : 8;  // pairs per (kernel row, q), padded: 16 / 20 dwords
     std::vector<float> q(static_cast<size_t>(2) * FS * PR * 2, 0.f);
     for (int qy = 0; qy < 2; ++qy)
         for (int ly = 0; ly < FS; ++ly)
-            for (int lx = 0; lx < FS; ++lx)
+            for (int lx = 0; lx < NX; ++lx)
                 for (int px = 0; px < 2; ++px)
-                    q[((static_cast<size_t>(ly) * 2 + qy) * PR + lx) * 2 + px] = sets[static_cast<size_t>(qy * 2 + px)][ly * FS + lx];
+                    q[((static_cast<size_t>(ly) * 2 + qy) * PR + lx) * 2 + px] = sets[static_cast<size_t>(qy * 2 + px)][ly * NX + lx];
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, q.size() * sizeof(float)), "hipMalloc(quad coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table
@@ -119,6 +121,7 @@ void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vect
 // filter size trim_fs on copies of the sets cut to the box, window origins moved by the box's corner.
 void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
     t.trim_fs = 0;
+    t.trim_nx = 0;
     t.trim_needs_finite = !integer_samples;  // float planes: only frames without infinities / NaNs (dispatch.cpp, kernel_scan.hip)
     if (!t.use_periodic) return;
     static const bool off = [] {
@@ -136,6 +139,31 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
                 if (s[ly * fs + lx] != 0.f) r0 = std::min(r0, ly), r1 = std::max(r1, ly), c0 = std::min(c0, lx), c1 = std::max(c1, lx);
     }
     if (r1 < 0) return;  // nothing but zeros: leave it to the full window
+    // 6 rows x 7 columns (fs 7, four phases with one window origin): chroma planes sited as MPEG-2 at 2x -- the disc spans six
+    // source rows, and seven columns because the siting shifts it by an eighth of a sample.  Only the two-periods-per-lane quad
+    // form takes it (seven taps per kernel row: PeriodicArgs::quad_taps); every other kernel of the family keeps the full window.
+    if (fs == 7 && nphase == 4 && r1 - r0 + 1 == 6 && c1 - c0 + 1 == 7 && pa.px == 2 && pa.py == 2 && pa.start_x[0] == pa.start_x[1] &&
+        pa.start_y[0] == pa.start_y[1]) {
+        std::vector<float> dense(static_cast<size_t>(4) * 6 * 7, 0.f);
+        for (int ph = 0; ph < 4; ++ph)
+            for (int ly = 0; ly < 6; ++ly)
+                for (int lx = 0; lx < 7; ++lx) dense[(static_cast<size_t>(ph) * 6 + ly) * 7 + lx] = p.set_ptr(pa.set[ph])[(r0 + ly) * fs + lx];
+        jinc::PeriodicArgs tr = pa;
+        tr.coeffs = nullptr;  // (no kernel but the quad form reads this variant)
+        tr.quad = nullptr;
+        for (int q = 0; q < pa.py; ++q) tr.start_y[q] = pa.start_y[q] + r0;
+        tr.min_sy = pa.min_sy + r0;
+        tr.quad_taps = 7;
+        t.periodic_trim = tr;
+        std::vector<const float*> sets;
+        for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * 42);
+        attach_quad(t, t.periodic_trim, 6, sets, 7);
+        if (t.periodic_trim.quad) {
+            t.trim_fs = 6;
+            t.trim_nx = 7;
+        }
+        return;
+    }
     const int n = std::max(3, std::max(r1 - r0 + 1, c1 - c0 + 1));
     if (n >= fs) return;
     r0 = std::min(r0, fs - n);
@@ -189,6 +217,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     tr.min_sy = pa.min_sy + r0;
     t.periodic_trim = tr;
     t.trim_fs = n;
+    t.trim_nx = n;
     if (nphase == 4) {
         std::vector<const float*> sets;
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * n * n);

@@ -274,8 +274,14 @@ struct Choice {
     // (= the automatic choice on the full window, for A/B and tests: jinc_filter::full_window) keep the reference's window.
     // Float planes take it frame by frame, where kernel_scan.hip found nothing but finite samples (two launches per plane and
     // a pass over the source: calls of at least kFloatTrimMinTaps taps per plane).
+    // launches that fill the chip with the 128 x 24 tiles of the two-periods-per-lane quad form
+    bool quad2_fills(const DeviceTable& t) const {
+        return static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 23) / 24) * nframes >= Rules::kQuad2MinWorkgroups;
+    }
     bool trimmed(const DeviceTable& t) const {
         if (t.trim_fs <= 0 || f.full_window || f.kernel_mode == 5 || f.kernel_mode == 6) return false;
+        // the 6-row x 7-column support exists for the quad2 form only: where that form is not what runs, the full window
+        if (t.trim_nx != t.trim_fs && !(f.kernel_mode == 13 || (f.kernel_mode == 0 && quad2_fills(t)))) return false;
         if (!t.trim_needs_finite) return true;
         // (float planes at fs 7 are bound by their bytes, not by the VALU: C2's geometry on float RGB 174.2 Gpix/s on the trimmed
         // quad form against 174.5 on the full window, a scan and a second launch on top -- round4/direct_trim_ab.log)
@@ -288,10 +294,7 @@ struct Choice {
         if (!periodic_args(t).quad) return false;
         if (f.kernel_mode == 13) return true;
         if (f.kernel_mode != 0) return false;
-        if (periodic_fs(t) == 6) {  // two periods per lane on the 6 x 6 support: tiles of 128 x 48 periods (24 rows on small calls)
-            const long long wgs6 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 23) / 24) * nframes;
-            return wgs6 >= Rules::kQuad2MinWorkgroups;
-        }
+        if (periodic_fs(t) == 6) return quad2_fills(t);  // two periods per lane on the 6 x 6 (6 x 7) support: tiles of 128 x 48 periods (24 rows on small calls)
         if (periodic_fs(t) == 8) {  // one period per lane on the 8 x 8 support (tap 4 at 2x)
             static const int knob = [] {
                 const char* e = std::getenv("JINC_QUAD8");  // A/B knob: 0 = window kernel, 1 = quad form (default: by measurement below)

@@ -370,7 +370,7 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
     if (t.use_runs && f->direct_premise && (m == 14 || (m == 0 && t.plan.fs >= 9))) return "ewa_direct_runs_kernel";
     if (quasi) return "ewa_quasi_kernel";
     if (periodic) {
-        const int fs = (t.trim_fs > 0 && !f->full_window && m != 5 && m != 6) ? t.trim_fs : t.plan.fs;
+        const int fs = (t.trim_fs > 0 && t.trim_nx == t.trim_fs && !f->full_window && m != 5 && m != 6) ? t.trim_fs : t.plan.fs;
         if (m == 5 || m == 6) return t.plan.fs == 7 ? "ewa_periodic_pk_kernel" : "ewa_periodic_kernel";
         if (m == 3 || fs < 6 || fs > 9) return "ewa_periodic_rows_kernel";
         return "ewa_periodic_kernel";
@@ -394,13 +394,14 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
         return static_cast<double>(n) * n;
     }
     if (!t.use_periodic) return 0;
+    if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && !f->full_window) return 42.0;  // 6 rows x 7 columns
     if (rows_kernel == 3 && t.trim_fs == 6 && !f->full_window &&  // ewa_periodic_quad2_kernel: chord rows on four taps (half the samples each)
         (t.periodic_trim.quad_inner & jinc::PeriodicArgs::kQuadInnerTap3) == jinc::PeriodicArgs::kQuadInnerTap3)
         return 34.0;
     if (rows_kernel == 3 && t.trim_fs == 8 && !f->full_window && t.periodic_trim.quad &&  // quad forms on the 8 x 8 support with the tap-4 pattern
         jinc::quad8_pattern_fits(t.periodic_trim.quad_trim8, jinc::kQuad8TrimTap4Value))
         return 56.0;
-    if (t.trim_fs > 0 && !f->full_window) return rows_kernel == 1 ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
+    if (t.trim_fs > 0 && t.trim_nx == t.trim_fs && !f->full_window) return rows_kernel == 1 ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
     return static_cast<double>(t.plan.fs) * t.plan.fs;
 }
 

@@ -47,6 +47,7 @@ struct DeviceTable {
     // The same interior on the TRIMMED support (integer planes only; device_plan.cpp trim_periodic): trim_fs x trim_fs taps
     // per sample, the bounding box of the phase sets' non-zero coefficients; 0 = the sets have no zero rim (or float samples).
     int trim_fs = 0;
+    int trim_nx = 0;  // taps per kernel row of the trimmed support: trim_fs, or 7 with trim_fs 6 (6 rows x 7 columns: quad2 form only)
     double trim_rows_taps = 0;       // taps per sample ewa_periodic_rows_kernel executes on the trimmed support (per-row spans)
     bool trim_needs_finite = false;  // float planes: the trimmed launch takes the frames whose samples are all finite
     jinc::PeriodicArgs periodic_trim;

@@ -995,6 +995,35 @@ __device__ __forceinline__ void quad2_row6(f32x2& acc_a, f32x2& acc_b, f32x2 w0,
 #undef JINC_ADD2
 }
 
+// Seven taps per kernel row for both periods of a lane (the 6-row x 7-column support: chroma planes sited as MPEG-2 at 2x): period A
+// reads columns 0 .. 6, period B columns 1 .. 7 of the same four register pairs.
+__device__ __forceinline__ void quad2_row7(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c0, f32x2 c1, f32x2 c2, f32x2 c3, f32x2 c4, f32x2 c5, f32x2 c6) {
+    f32x2 ta, tb;
+    asm("v_pk_mul_f32 %2, %4, %8 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %4, %8 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %4, %9 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %9 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %5, %10 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %5, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %5, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %11 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %6, %12 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %12 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %6, %13 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %3, %7, %13 op_sel_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+        "v_pk_mul_f32 %2, %7, %14 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %7, %14 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3"
+        : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+        : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+}
+
 // The same kernel row where tap 0 and tap 5 carry zero coefficients for BOTH phases p of this q (the disc's chord in the box's
 // first / last row: host, PeriodicArgs::quad_inner): taps 1 .. 4 only.
 __device__ __forceinline__ void quad2_row6_inner(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 c1, f32x2 c2, f32x2 c3, f32x2 c4) {
@@ -1024,7 +1053,7 @@ __device__ __forceinline__ void quad2_load_row(f32x2 (&w)[24], const float* p) {
 
 // One output row pair of both periods: acc[0] / acc[1] = period A / B at q = 0, acc[2] / acc[3] at q = 1.  Coefficient pairs of
 // kernel row ly + 1 are requested before the taps of row ly are issued, as in quad_pixel7.
-template <int U, uint32_t INNER>
+template <int U, uint32_t INNER, int NT>
 __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[24], const JINC_CONSTANT f32x2* quad) {
     f32x2 ca[16], cb[16];
     quad_fetch(ca, quad, 0);
@@ -1035,6 +1064,10 @@ __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[2
     {                                                                                                                          \
         constexpr int S = 4 * ((U + LY) % 6);                                                                                  \
         /* INNER: a compile-time mask (a run-time test here, however uniform, cost 8 % of the kernel: round4/quad_inner_ab.log) */ \
+        if constexpr (NT == 7) { /* 6 rows x 7 columns: seven taps per kernel row */                                            \
+            quad2_row7(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6]); \
+            quad2_row7(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14]); \
+        } else {                                                                                                               \
         if constexpr ((INNER >> (2 * LY)) & 1u)                                                                                \
             quad2_row6_inner(acc[0], acc[1], w[S], w[S + 1], w[S + 2], CUR[1], CUR[2], CUR[3], CUR[4]);                        \
         else                                                                                                                   \
@@ -1043,6 +1076,7 @@ __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[2
             quad2_row6_inner(acc[2], acc[3], w[S], w[S + 1], w[S + 2], CUR[9], CUR[10], CUR[11], CUR[12]);                     \
         else                                                                                                                   \
             quad2_row6(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13]); \
+        }                                                                                                                      \
     }                                                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
     JINC_QUAD2_STEP(0, ca, cb)
@@ -1086,7 +1120,9 @@ __device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset
 // in the box's edge rows).  Instantiated for no such rows and for the pattern of the 2x up-scale with tap 3 at blur 1 (q = 0: the
 // last kernel row, q = 1: the first): the launcher takes the instantiation whose mask is a subset of the plan's.
 constexpr uint32_t kQuad2InnerTap3 = PeriodicArgs::kQuadInnerTap3;
-template <typename T, int RG, uint32_t INNER>
+// NT: taps per kernel row -- 6, or 7 for the 6-row x 7-column support (chroma planes sited as MPEG-2 at 2x: the disc spans six
+// source rows but, shifted by an eighth of a sample, seven columns; PeriodicArgs::quad_taps).
+template <typename T, int RG, uint32_t INNER, int NT = 6>
 __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const PeriodicArgs a, const PlaneIO io) {
     using Cfg = Quad2Cfg<RG>;
     constexpr int FS = Cfg::FS;
@@ -1163,7 +1199,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                            \
         uint32_t zero;                                                                                              \
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
-        quad2_pixel6<U, INNER>(acc, win, quad + zero);                                                              \
+        quad2_pixel6<U, INNER, NT>(acc, win, quad + zero);                                                          \
         const int j = j0 + g * FS + U;                                                                              \
         if (j < a.nj) {                                                                                             \
             const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
@@ -1603,7 +1639,9 @@ template <typename T, int RG>
 int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    if ((pa.quad_inner & kQuad2InnerTap3) == kQuad2InnerTap3)
+    if (pa.quad_taps == 7)
+        hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, 0u, 7>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    else if ((pa.quad_inner & kQuad2InnerTap3) == kQuad2InnerTap3)
         hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, kQuad2InnerTap3>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     else
         hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);

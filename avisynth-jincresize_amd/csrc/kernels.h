@@ -87,6 +87,7 @@ struct PeriodicArgs {
     const float* quad = nullptr;
     // ewa_periodic_quad2_kernel: bit 2 * ly + q set = taps 0 and 5 of kernel row ly carry zero coefficients for both phases p of q
     uint32_t quad_inner = 0;
+    int quad_taps = 0;  // ewa_periodic_quad2_kernel: taps per kernel row when they differ from the row count (7: the 6 x 7 support), else 0
     static constexpr uint32_t kQuadInnerTap3 = (1u << (2 * 5 + 0)) | (1u << (2 * 0 + 1));  // the mask the kernel is instantiated for
     // quad forms on the 8 x 8 support: taps kernel row ly of q leaves out per side (0 .. 3), two bits at 2 * (2 * ly + q)
     uint32_t quad_trim8 = 0;

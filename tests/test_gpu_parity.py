@@ -806,6 +806,10 @@ QUAD_CASES = [
     ("Y10", 320, 180, 640, 360, dict(tap=3)),
     ("Y32", 320, 180, 640, 360, dict(tap=3)),
     ("YUV420P8", 256, 144, 512, 288, dict(tap=3, cplace="mpeg1")),   # luma and chroma tables both 2x
+    ("YUV420P8", 256, 144, 512, 288, dict(tap=3, cplace="mpeg2")),   # chroma sited as MPEG-2: 6 rows x 7 columns, seven taps per kernel row
+    ("YUV420P16", 320, 180, 640, 360, dict(tap=3)),                  # (the default siting)
+    ("YUV422P10", 256, 144, 512, 288, dict(tap=3)),                  # 4:2:2: the chroma table is 2x in both axes here too
+    ("YUV420PS", 256, 144, 512, 288, dict(tap=3)),                   # float chroma on the 6 x 7 support behind the finite scan
     ("RGBPS", 160, 100, 320, 200, dict(tap=3, blur=0.95)),
     # fs 9 (tap 4): ewa_periodic_quad9_kernel
     ("Y8", 192, 108, 384, 216, dict(tap=4)),
@@ -985,4 +989,27 @@ def test_jinc64_at_2x_in_batches_takes_two_periods_per_lane(gpu_pkg, O, fmt):
         assert_planes_equal(auto[k], full[k], f.out_dims(), what=f"{fmt} frame {k}: trimmed two-period form vs full window")
         if k in (0, frames - 1):
             assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=8), f.out_dims(), what=f"{fmt} frame {k} vs oracle")
+    f.close()
+
+
+def test_chroma_sited_as_mpeg2_runs_on_six_rows_of_seven_taps(gpu_pkg, O):
+    """1080p -> 4K 4:2:0 with the default siting, 16 frames per call: the chroma table's disc spans six source rows and (shifted by an
+    eighth of a sample) seven columns; ewa_periodic_quad2_kernel takes that support with seven taps per kernel row.  Every frame
+    against the full window (kernel mode 15), two against the oracle."""
+    torch = pytest.importorskip("torch")
+    from test_framelane_pair import _run_batch
+    fmt, sw, sh, tw, th, frames = "YUV420P8", 1920, 1080, 3840, 2160, 16
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0)
+    assert f.periodic_support(0) == 6 and f.periodic_support(1) == 6
+    assert f.periodic_taps(1, rows_kernel=3) == 42.0 and f.periodic_taps(0, rows_kernel=3) == 34.0
+    srcs = [O.lcg_frame(ofmt, sw, sh, seed=7700 + k) for k in range(frames)]
+    auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+    assert f.last_kernel(1) == "ewa_periodic_quad2_kernel", f.last_kernel(1)
+    full = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 15)
+    of = O.OracleFilter(ofmt, sw, sh, tw, th)
+    for k in range(frames):
+        assert_planes_equal(auto[k], full[k], f.out_dims(), what=f"frame {k}: 6 x 7 support vs full window")
+        if k in (0, frames - 1):
+            assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=8), f.out_dims(), what=f"frame {k} vs oracle")
     f.close()
