@@ -164,19 +164,26 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         }
         return;
     }
-    const int n = std::max(3, std::max(r1 - r0 + 1, c1 - c0 + 1));
-    if (n >= fs) return;
-    r0 = std::min(r0, fs - n);
+    // n taps per kernel row x ny kernel rows.  The window and quad forms are square (n = ny = the larger side of the box); the
+    // rows kernel (n >= 10 or n <= 5) walks its kernel rows in a rolled loop and takes the row count at run time
+    // (PeriodicArgs::rows_ny), so there the box keeps its own height: chroma planes sited as MPEG-2 at 2x with tap 8 need all 17
+    // columns but only 16 rows.
+    int n = std::max(3, c1 - c0 + 1), ny = std::max(3, r1 - r0 + 1);
+    const bool rows_family = n >= 10 || n <= 5;
+    if (!(rows_family && ny < n)) n = ny = std::max(n, ny);
+    if (n >= fs && ny >= fs) return;
+    n = std::min(n, fs), ny = std::min(ny, fs);
+    r0 = std::min(r0, fs - ny);
     c0 = std::min(c0, fs - n);
     const int row = (n + 3) & ~3;  // floats per coefficient row on the device, as upload_table
-    std::vector<float> cut(static_cast<size_t>(nphase) * n * row, 0.f), dense(static_cast<size_t>(nphase) * n * n, 0.f);
+    std::vector<float> cut(static_cast<size_t>(nphase) * ny * row, 0.f), dense(static_cast<size_t>(nphase) * ny * n, 0.f);
     for (int ph = 0; ph < nphase; ++ph) {
         const float* s = p.set_ptr(pa.set[ph]);
-        for (int ly = 0; ly < n; ++ly)
+        for (int ly = 0; ly < ny; ++ly)
             for (int lx = 0; lx < n; ++lx) {
                 const float c = s[(r0 + ly) * fs + (c0 + lx)];
-                cut[(static_cast<size_t>(ph) * n + ly) * row + lx] = c;
-                dense[(static_cast<size_t>(ph) * n + ly) * n + lx] = c;
+                cut[(static_cast<size_t>(ph) * ny + ly) * row + lx] = c;
+                dense[(static_cast<size_t>(ph) * ny + ly) * n + lx] = c;
             }
     }
     // per phase and kernel row: the zero coefficients in front of and behind the row's span (the disc's chord), the smaller of
@@ -184,8 +191,8 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     std::vector<int32_t> row_trim(static_cast<size_t>(nphase) * 32, 0);
     if (n <= 32)
         for (int ph = 0; ph < nphase; ++ph)
-            for (int ly = 0; ly < n; ++ly) {
-                const float* r = &dense[(static_cast<size_t>(ph) * n + ly) * n];
+            for (int ly = 0; ly < ny; ++ly) {
+                const float* r = &dense[(static_cast<size_t>(ph) * ny + ly) * n];
                 int lead = 0, trail = 0;
                 while (lead < n && r[lead] == 0.f) ++lead;
                 while (trail < n - lead && r[n - 1 - trail] == 0.f) ++trail;
@@ -196,7 +203,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         const int widest = n >= 12 ? 5 : n >= 6 ? 2 : 0;
         double taps = 0;
         for (int ph = 0; ph < nphase; ++ph)
-            for (int ly = 0; ly < n; ++ly) taps += n - 2 * std::min(widest, n <= 32 ? row_trim[static_cast<size_t>(ph) * 32 + ly] : 0);
+            for (int ly = 0; ly < ny; ++ly) taps += n - 2 * std::min(widest, n <= 32 ? row_trim[static_cast<size_t>(ph) * 32 + ly] : 0);
         t.trim_rows_taps = taps / nphase;
     }
     const size_t cut_bytes = align_up(cut.size() * sizeof(float), 256);
@@ -215,10 +222,11 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     for (int q = 0; q < pa.py; ++q) tr.start_y[q] = pa.start_y[q] + r0;
     tr.min_sx = pa.min_sx + c0;
     tr.min_sy = pa.min_sy + r0;
+    tr.rows_ny = ny < n ? ny : 0;
     t.periodic_trim = tr;
     t.trim_fs = n;
     t.trim_nx = n;
-    if (nphase == 4) {
+    if (nphase == 4 && ny == n) {
         std::vector<const float*> sets;
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * n * n);
         attach_quad(t, t.periodic_trim, n, sets);

@@ -1448,7 +1448,7 @@ __device__ __forceinline__ void rows_kernel_row(float (&acc)[4][KC], const float
 
 template <typename T, int FS, int KC, int OFF>
 __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsigned base_off, const JINC_CONSTANT float* cs,
-                                          const JINC_CONSTANT int32_t* row_trim, BufferRsrc drsrc,
+                                          const JINC_CONSTANT int32_t* row_trim, int nrows, BufferRsrc drsrc,
                                           int dst_pitch, float peak, int y0, int ystep, int rows_valid, unsigned x0,
                                           unsigned xstep, int cols_valid) {
     using Cfg = RowsCfg<FS, KC>;
@@ -1468,7 +1468,7 @@ __device__ __forceinline__ void rows_item(const float* __restrict__ tile, unsign
         asm volatile("" : "+v"(plane_off[m]));
     }
 
-    for (int ly = 0; ly < FS; ++ly) {
+    for (int ly = 0; ly < nrows; ++ly) {  // (FS, or fewer on a support that is wider than tall: PeriodicArgs::rows_ny)
         const JINC_CONSTANT float* crow = cs + ly * padded_row(FS);
         // taps this kernel row leaves out on either side (wave-uniform: the phase's, from the plan); spans are offered in
         // steps of one tap up to five, a row whose zero flanks are wider takes the widest
@@ -1568,16 +1568,17 @@ __global__ __launch_bounds__(512, 8) void ewa_periodic_rows_kernel(const Periodi
         const int j = j0 + ch * R;  // first period-row of the chunk
         const int rows_valid = a.nj - j;
         if (rows_valid <= 0) continue;
+        const int nrows = a.rows_ny ? a.rows_ny : FS;
         const JINC_CONSTANT float* cs =
-            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (FS * padded_row(FS)));
+            (const JINC_CONSTANT float*)(a.coeffs + static_cast<size_t>(a.set[ph]) * (static_cast<size_t>(nrows) * padded_row(FS)));
         const unsigned base = ((a.start_y[q] - a.min_sy) + ch * R) * Cfg::kPlane + lane;
         const int y0 = a.iy0 + a.py * j + q;
         const unsigned x0 = a.ix0 + a.px * (i0 + K * lane) + p;
         const JINC_CONSTANT int32_t* row_trim = a.row_trim ? (const JINC_CONSTANT int32_t*)(a.row_trim) + ph * 32 : nullptr;
         if (a.start_x[p] - a.min_sx)
-            rows_item<T, FS, KC, 1>(tile, base, cs, row_trim, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+            rows_item<T, FS, KC, 1>(tile, base, cs, row_trim, nrows, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
         else
-            rows_item<T, FS, KC, 0>(tile, base, cs, row_trim, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
+            rows_item<T, FS, KC, 0>(tile, base, cs, row_trim, nrows, dframe, io.dst_pitch, io.peak, y0, a.py, rows_valid, x0, a.px, cols_valid);
     }
 }
 

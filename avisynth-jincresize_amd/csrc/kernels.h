@@ -95,6 +95,7 @@ struct PeriodicArgs {
     // trimmed support only (ewa_periodic_rows_kernel): row_trim[phase * 32 + ly] = taps kernel row ly of the phase leaves out on
     // EITHER side (min of its leading and trailing zero coefficients, at most 5), or nullptr
     const int32_t* row_trim = nullptr;
+    int rows_ny = 0;  // ewa_periodic_rows_kernel on a support with fewer kernel rows than taps per row: the row count (0: fs rows)
     // float planes on the trimmed support: frame_flags[frame] (kernel_scan.hip: 1 = the frame's plane holds a non-finite
     // sample) decides which of two launches computes a frame -- a launch returns at once for frames whose flag differs from
     // run_when.  nullptr: every frame.

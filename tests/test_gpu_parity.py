@@ -860,13 +860,16 @@ def test_trimmed_support_of_the_periodic_kernels(gpu_pkg, O, fmt, sw, sh, tw, th
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
     assert f.plan_info(0).filter_size == full
     assert f.periodic_support(0) == trimmed
+    if fmt == "YUV420P16":  # chroma sited as MPEG-2 (an eighth of a sample to the left): all 17 columns, but 16 kernel rows
+        assert f.periodic_support(1) == 17
+        assert f.periodic_taps(1, rows_kernel=True) <= 17 * 16 and f.periodic_taps(0, rows_kernel=True) <= 16 * 16
     f.set_kernel_mode(15)
     assert f.periodic_support(0) == full
     f.set_kernel_mode(0)
     if sw <= 640:
         src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=99)
         want = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw)).get_frame(src, threads=8)
-        for mode in (0, 13, 15):
+        for mode in (0, 3, 13, 15):
             f.set_kernel_mode(mode)
             assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=f"{fmt} mode {mode}")
     f.close()
