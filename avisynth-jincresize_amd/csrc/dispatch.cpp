@@ -22,6 +22,15 @@ struct Rules {
     // kFrameLaneMinFrames (16) frames, filter sizes above 9 from 24, drifting plans with more than 16 phases from 36,
     // drifting fs-9 / fs-7 plans with a source step of 2 from 48 / 64
     static constexpr int kFrameLaneMinFramesBigFs = 24;
+    // Groups of fewer than 64 frames on the frame-lane kernel's sub-group form (profiles/round4/fl_sub_ab.log, fl_small_ab.log):
+    // 16 / 8 / 4 / 2 sub-groups per wave (4 / 8 / 16 / 32 frames per workgroup) up to these frame counts, the 64-frame form
+    // above (1.37x at 48 frames: 267 against 244 Gpix/s; 5/6 down-scale 216 : 217; 1.5x with tap 4 184 : 191).  The form
+    // passes the gather kernel at 3 frames (1.37x: 1 frame 21 against 32 Gpix/s, 2: 41 : 43, 3: 58 : 48, 4: 72 : 51, 8: 128 : 57).
+    static constexpr int kFlSub16MaxFrames = 4;
+    static constexpr int kFlSub8MaxFrames = 8;
+    static constexpr int kFlSub4MaxFrames = 16;
+    static constexpr int kFlSub2MaxFrames = 32;
+    static constexpr int kFlSubMinFrames = 3;
     // (against the runs form of the direct kernel -- drifting plans with fs >= 9 -- the frame-lane kernel is never chosen:
     // round3/runs_vs_auto.txt, 128 frames, border frame on the frame-lane kernel: DVD -> 1080p with tap 4 169 against 159 Gpix/s,
     // 5/2 with tap 6 135.5 against 124.7, 1.5x with tap 8 at 256 frames 88.9 against 79.7, with tap 4 265 against 255)
@@ -244,13 +253,14 @@ struct Choice {
     // it for every plan and batch size.
     bool wants_framelane(const DeviceTable& t, int i) const {
         if (!t.use_framelane || f.kernel_mode == 1) return false;
-        if (f.kernel_mode == 11 || (f.kernel_mode == 12 && t.use_framelane_pair)) return true;
+        if (f.kernel_mode == 11 || f.kernel_mode == 16 || (f.kernel_mode == 12 && t.use_framelane_pair)) return true;
         if (f.kernel_mode != 0) return false;
         // batch sizes from which the frame-lane kernels (rate proportional to the filled lanes) pass the single-frame
         // kernels, measured (profiles/round2/fl_threshold.log): against the gather kernel 11 frames for 1.37x, 14 for the
         // 5/6 down-scale, 21 for 1.5x with tap 8 (row-segment form); against the quasi-periodic kernel 33 frames for DVD ->
         // 1080p (72 phases), 42 for 1.5x with tap 4, ~50 for 1.5x
-        if (nframes < (t.plan.fs > 9 ? Rules::kFrameLaneMinFramesBigFs : kFrameLaneMinFrames)) return false;
+        const bool sub_form = t.fl_whole.variant != 1 && jinc::framelane_sub_supported(t.plan.fs, 2, t.fl_whole.ty_shift);
+        if (nframes < (t.plan.fs > 9 ? Rules::kFrameLaneMinFramesBigFs : sub_form ? Rules::kFlSubMinFrames : kFrameLaneMinFrames)) return false;
         if (wants_periodic(t)) return false;
         if (f.kernel_mode == 0 && wants_runs(t, i)) return false;
         if (wants_quasi(t)) {
@@ -267,6 +277,26 @@ struct Choice {
                    nframes >= (t.plan.fs == 9 ? Rules::kFrameLaneMinFramesStep2Fs9 : Rules::kFrameLaneMinFramesStep2Fs7);
         }
         return !wants_direct(t, i);
+    }
+    // Sub-groups per wave for `n` < 64 frames on the frame-lane kernel (kernel_framelane_sub.hip: a wave's lanes are n frames x
+    // several output rows instead of 64 frames), or 0: the 64-frame form.  Kernel mode 16 forces the form, JINC_FL_SUB is the
+    // A/B knob (0: never, 2 / 4 / 8 / 16: that many sub-groups).
+    int fl_subgroups(const DeviceTable& t, int n) const {
+        static const int forced = [] {
+            const char* e = std::getenv("JINC_FL_SUB");
+            return e ? std::atoi(e) : -1;
+        }();
+        if (forced == 0 || t.fl_whole.variant == 1) return 0;
+        if (forced < 0 && (n >= 64 || f.kernel_mode == 11)) return 0;  // (the knob: batches of any size and kernel mode, for A/B)
+        int g = 0;
+        if (forced > 0)
+            g = forced;
+        else if (f.kernel_mode == 16)
+            g = n <= 4 ? 16 : n <= 8 ? 8 : n <= 16 ? 4 : 2;
+        else if (f.kernel_mode == 0)
+            g = n <= Rules::kFlSub16MaxFrames ? 16 : n <= Rules::kFlSub8MaxFrames ? 8 : n <= Rules::kFlSub4MaxFrames ? 4 : n <= Rules::kFlSub2MaxFrames ? 2 : 0;
+        while (g >= 2 && !jinc::framelane_sub_supported(t.plan.fs, g, t.fl_whole.ty_shift)) g /= 2;  // (tiles of fewer rows than sub-groups)
+        return g >= 2 ? g : 0;
     }
     // quad form of the periodic kernel (2x up-scales whose phases share their window origin), where it measured ahead
     // The periodic family on the trimmed support (integer planes whose phase sets have a zero rim; device_plan.cpp
@@ -415,7 +445,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         // what is left of the batch, and every batch below 128 frames, to the 64-frame form.  kernel_mode 12 (tests,
         // A/B): the frame-pair form for the whole batch, 11: the 64-frame form for the whole batch.
         int npair = 0;
-        if (t.use_framelane_pair && f.kernel_mode != 11)
+        if (t.use_framelane_pair && f.kernel_mode != 11 && f.kernel_mode != 16)
             npair = f.kernel_mode == 12 ? nframes : nframes / jinc::kFrameLanePairFrames * jinc::kFrameLanePairFrames;
         if (npair > 0) {
             jinc::FrameLaneArgs fa = t.fl_pair;
@@ -425,18 +455,34 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             t.last_kernel = "ewa_framelane_pair_kernel";
             timed(f.ev_periodic, plane_stream, "frame-pair kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_pair(fa, s); });
         }
-        if (npair < nframes) {
+        // What is left (fewer than 128 frames): whole groups of 64 on the 64-frame form; a remainder of up to 32 frames on the
+        // sub-group form (a wave = 4 / 8 / 16 / 32 frames x 16 / 8 / 4 / 2 output rows), which a batch of fewer than 64 frames
+        // is as a whole -- the rate of the 64-frame form is proportional to its filled lanes (1.37x, 16 frames: 94 -> 210 Gpix/s).
+        auto launch_part = [&](int first, int n, bool names_the_call) {
             jinc::FrameLaneArgs fa = t.fl_whole;
             fa.io = io;
-            fa.io.src = static_cast<const char*>(io.src) + static_cast<size_t>(npair) * io.src_frame_stride;
-            fa.io.dst = static_cast<char*>(io.dst) + static_cast<size_t>(npair) * io.dst_frame_stride;
-            fa.io.nframes = nframes - npair;
+            fa.io.src = static_cast<const char*>(io.src) + static_cast<size_t>(first) * io.src_frame_stride;
+            fa.io.dst = static_cast<char*>(io.dst) + static_cast<size_t>(first) * io.dst_frame_stride;
+            fa.io.nframes = n;
             fa.vec_store_ok = vec_ok;
-            if (npair == 0)
+            fa.subgroups = c.fl_subgroups(t, n);
+            if (fa.subgroups) {
+                if (names_the_call) t.last_kernel = "ewa_framelane_sub_kernel";
+                timed(f.ev_periodic, plane_stream, "frame-lane sub-group kernel launch", [&](hipStream_t s) { return jinc::launch_framelane_sub(fa, s); });
+                return;
+            }
+            if (names_the_call)
                 t.last_kernel = (fa.threads == 1024 && t.plan.fs == 7) ? "ewa_framelane_win1k_kernel"
                                 : (fa.variant != 1 && (t.plan.fs == 5 || t.plan.fs == 7 || t.plan.fs == 8 || t.plan.fs == 9))
                                     ? "ewa_framelane_win_kernel" : "ewa_framelane_kernel";
             timed(f.ev_periodic, plane_stream, "frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+        };
+        const int rest = nframes - npair;
+        if (rest >= 64 && rest % 64 != 0 && c.fl_subgroups(t, rest % 64)) {
+            launch_part(npair, rest / 64 * 64, npair == 0);
+            launch_part(npair + rest / 64 * 64, rest % 64, false);
+        } else if (rest > 0) {
+            launch_part(npair, rest, npair == 0);
         }
         return;
     }

@@ -546,7 +546,7 @@ int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
 }
 
 int jinc_filter_set_kernel_mode(jinc_filter* f, int mode) {
-    if (!f || mode < 0 || mode > 15) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
+    if (!f || mode < 0 || mode > 16) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad kernel mode.");
     f->full_window = mode == 15;  // 15 = the automatic choice, but on the reference's full window (no trimmed support)
     f->kernel_mode = mode == 15 ? 0 : mode;
     return JINC_OK;

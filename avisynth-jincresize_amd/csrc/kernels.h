@@ -265,12 +265,17 @@ struct FrameLaneArgs {
     int vec_store_ok = 0;     // bit 0: destination base, pitch and frame stride are multiples of 4 samples; bit 1: of 16 bytes
     int variant = 0;          // 0: automatic (sliding-window form for filter sizes 5, 7, 8, 9), 1: row-segment form always
     int pair = 0;             // 1: configured for the frame-pair form (128 frames per workgroup)
+    int subgroups = 0;        // ewa_framelane_sub_kernel: sub-groups per wave (2 / 4 / 8 = 32 / 16 / 8 frames per workgroup); set per launch
 };
 // Chooses the tile size for the rectangles `rects` of plane plan `p` (host arrays) so that every tile's source
 // footprint fits the LDS budget and is at most 64 columns wide; false if no tile size fits (huge filter footprints).
 struct PlanePlan;
 bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out);
 int launch_framelane(const FrameLaneArgs& args, void* stream);
+// Groups of fewer than 64 frames (kernel_framelane_sub.hip): a wave is args.subgroups sub-groups of 64 / subgroups lanes, each on
+// its own output row of the tile; filter sizes 5, 7, 8, 9 (the sliding-window form's) on a tile configuration of framelane_configure.
+bool framelane_sub_supported(int fs, int subgroups, int ty_shift);
+int launch_framelane_sub(const FrameLaneArgs& args, void* stream);
 // Frame-pair form: filter sizes 5 and 7 only (two windows per lane in 128 registers); false otherwise or if no tile fits.
 bool framelane_pair_configure(const PlanePlan& p, const RectList& rects, int sample_bytes, int nframes_hint, FrameLaneArgs& out);
 int launch_framelane_pair(const FrameLaneArgs& args, void* stream);

@@ -61,7 +61,9 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * automatic choice for drifting plans with filter sizes above 9) wherever the plan has runs, 15 = the automatic choice on the
  * reference's full window: integer planes otherwise run the periodic kernels on the TRIMMED support (the bounding box of
  * the phase sets' non-zero coefficients -- 6 x 6 of 7 x 7 for the 2x up-scale with tap 3; leaving out taps whose coefficient is
- * 0.0f is exact for finite samples). */
+ * 0.0f is exact for finite samples), 16 = the frame-lane kernel for every plan and batch size as 11, groups of fewer than 64
+ * frames in its sub-group form (a wave = 8 / 16 / 32 frames x 8 / 4 / 2 output rows; filter sizes 5, 7, 8, 9; the automatic
+ * choice for what a batch leaves below 64 frames). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
 /* Taps per axis the periodic interior kernels of `table` execute under the current kernel mode: the plan's filter size, or
  * the side of the trimmed support on integer planes (kernel mode 15 switches trimming off); 0 when the table has no

@@ -37,7 +37,7 @@ def test_no_fused_multiply_add_in_device_code(pkg):
     isa = "\n".join(open(p).read() for p in pkg.ISA_PATHS)
     kernels = re.findall(r"^(_ZN4jinc\S*kernel\S*):", isa, flags=re.M)
     for name in ("ewa_gather_kernel", "ewa_periodic_kernel", "ewa_periodic_rows_kernel", "ewa_periodic_pk_kernel", "ewa_periodic_quad_kernel", "ewa_periodic_quad2_kernel", "ewa_periodic_quad8_kernel", "ewa_periodic_quad2x8_kernel",
-                 "ewa_quasi_kernel", "ewa_framelane_kernel", "ewa_framelane_win_kernel", "ewa_framelane_win1k_kernel", "ewa_framelane_pair_kernel", "ewa_direct_kernel", "ewa_colstrip_kernel"):
+                 "ewa_quasi_kernel", "ewa_framelane_kernel", "ewa_framelane_win_kernel", "ewa_framelane_win1k_kernel", "ewa_framelane_sub_kernel", "ewa_framelane_pair_kernel", "ewa_direct_kernel", "ewa_colstrip_kernel"):
         assert any(name in k for k in kernels), name
     fused = re.findall(r"^\s+(v_fma_f32|v_fmac_f32|v_mad_f32|v_mac_f32|v_pk_fma_f32|v_fma_mix\w*|v_mfma\w*)\b", isa, flags=re.M)
     assert fused == [], f"fused ops in device code: {sorted(set(fused))}"
@@ -53,6 +53,50 @@ def test_no_fused_multiply_add_in_device_code(pkg):
     # fp32 denormals must be preserved (float_denorm_mode_32 = 3 in every kernel descriptor)
     modes = re.findall(r"\.amdhsa_float_denorm_mode_32\s+(\d+)", isa)
     assert modes and set(modes) == {"3"}
+
+
+def _vgprs(tok):
+    tok = tok.strip().rstrip(",")
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_dpp_reads_keep_their_distance_from_valu_writes(pkg):
+    """ewa_framelane_sub_kernel multiplies by a coefficient another lane holds (v_mul_f32_dpp ... row_newbcast / quad_perm, written
+    as inline assembly, which the compiler's hazard recogniser does not look into).  The hardware needs two wait states between a
+    VALU write of a register and a DPP read of it: in the listing no VALU instruction within the two instructions (or s_nop
+    states) in front of a DPP multiply may write that multiply's DPP operand.  (The operand comes straight from a vector load.)"""
+    path = [p for p in pkg.ISA_PATHS if p.endswith("kernel_framelane_sub-gfx950.s")][0]
+    if not os.path.exists(path):
+        pkg.build()
+    seen, hist = 0, []  # hist: (is VALU, registers written, wait states it provides)
+    for line in open(path):
+        t = line.split(";")[0].strip()
+        if not t or t.startswith("."):
+            continue
+        if t.endswith(":"):
+            hist = []
+            continue
+        parts = t.replace(",", " ").split()
+        op = parts[0]
+        if op == "v_mul_f32_dpp":
+            seen += 1
+            src, states = _vgprs(parts[2]), 0
+            for valu, written, n in reversed(hist):
+                if states >= 2:
+                    break
+                assert not (valu and written & src), f"VALU write of {sorted(written & src)} right in front of: {t}"
+                states += n
+        if op == "s_nop":
+            hist.append((False, set(), int(parts[1], 0) + 1))
+        else:
+            valu = op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane"))
+            hist.append((valu, _vgprs(parts[1]) if valu and len(parts) > 1 else set(), 1))
+        hist = hist[-6:]
+    assert seen > 1000  # every tap of every instantiation
 
 
 def test_product_does_not_reference_the_oracle():

@@ -85,7 +85,7 @@ def test_batches_of_frames(gpu_pkg, O, case):
         stream.synchronize()
         # (last_kernel names the kernel of the batch's last part: beyond whole groups of 128 frames a remainder of fewer than 16
         # frames is a call of its own under the normal rules -- for these plans the gather kernel)
-        small_rest = n > 128 and 0 < n % 128 < 16   # (automatic mode: n >= 24)
+        small_rest = n > 128 and 0 < n % 128 < 3   # (automatic mode: n >= 24; from 3 frames the sub-group form of the frame-lane kernel)
         assert f.last_kernel(0).startswith("ewa_gather" if small_rest else "ewa_framelane"), (n, f.last_kernel(0))
         for k in range(n):
             got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
@@ -170,7 +170,10 @@ def test_randomised_arguments_through_the_framelane_kernel(gpu_pkg, O, seed, gen
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=seed + 7 * k) for k in range(3 if seed % 4 == 0 else 1)]
     wants = [of.get_frame(fr, threads=4) for fr in frames]
     assert_planes_equal(f.get_frame(frames[0]), wants[0], f.out_dims(), what=what)
+    f.set_kernel_mode(16)  # the sub-group form (filter sizes 5, 7, 8, 9; the others stay on the 64-frame form)
+    assert_planes_equal(f.get_frame(frames[0]), wants[0], f.out_dims(), what=what + " sub-group form")
     if len(frames) > 1:
+        f.set_kernel_mode(11 if seed % 8 == 0 else 16)
         gfmt = gpu_pkg.FORMATS[fmt]
         np_dtype = frames[0][0].dtype
         sb = np.dtype(np_dtype).itemsize

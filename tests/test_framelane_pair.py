@@ -89,7 +89,7 @@ def test_single_frame_through_the_pair_form(gpu_pkg, O, case):
 
 def test_full_size_batch(gpu_pkg, O):
     """1280x720 -> 1754x986 (no phase structure), 128 + 3 frames: the pair form for the first 128, the rest under the normal
-    rules; all frames against the forced gather kernel, four of them against the oracle."""
+    rules (from 3 frames: lanes = 4 frames x 16 output rows); all frames against the forced gather kernel, four of them against the oracle."""
     torch = pytest.importorskip("torch")
     fmt, sw, sh, tw, th, n = "Y8", 1280, 720, 1754, 986, 131
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
@@ -105,8 +105,8 @@ def test_full_size_batch(gpu_pkg, O):
         f.process_device([src.data_ptr()], [src.stride(1)], [src.stride(0)], [dst.data_ptr()], [dst.stride(1)], [dst.stride(0)], n,
                          stream=stream.cuda_stream)
         stream.synchronize()
-        if mode == 0:  # 128 frames on the pair form, the remaining 3 as a call of their own (gather kernel: too few for lanes = frames)
-            assert f.last_kernel(0) == "ewa_gather_kernel", f.last_kernel(0)
+        if mode == 0:  # 128 frames on the pair form, the remaining 3 as a call of their own (the frame-lane kernel's sub-group form)
+            assert f.last_kernel(0) == "ewa_framelane_sub_kernel", f.last_kernel(0)
         outs.append(dst[:, :, :tw].cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     for k in (0, 63, 127, 130):

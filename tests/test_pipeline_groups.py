@@ -31,7 +31,7 @@ def _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs):
 
 
 @pytest.mark.parametrize("case,depth,group,kernels", [
-    (A137, 64, 0, "ewa_framelane_win"),   # automatic: groups of 32
+    (A137, 64, 0, "ewa_framelane_sub_kernel"),   # automatic: groups of 32 = two sub-groups of 32 frames per wave
     (A137, 64, 64, "ewa_framelane_win"),
     (N15T8, 64, 32, "ewa_direct_runs_kernel"),   # 1.5x with tap 8: since round 3 the runs form of the direct kernel, also in batches
 ], ids=["A137_auto", "A137_g64", "N15T8_g32"])
@@ -116,7 +116,8 @@ def test_submit_rejects_bad_planes_without_disturbing_the_group(gpu_pkg, O):
 @pytest.mark.parametrize("nframes", [129, 140, 256 + 17])
 def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframes):
     """128 k + r frames = whole groups of 128 on the frame-pair form + a call of r frames under the normal rules
-    (r < 16: the single-frame kernel of the plan, not a 64-lane launch for a few frames); results per frame unchanged."""
+    (r < 3: the single-frame kernel of the plan; up to 32: the frame-lane kernel's sub-group form -- never a 64-lane launch for
+    a few frames); results per frame unchanged."""
     torch = pytest.importorskip("torch")
     fmt, sw, sh, tw, th = "Y8", 160, 90, 219, 123
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
@@ -128,7 +129,8 @@ def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframe
     f.process_device([src.data_ptr()], [256], [sh * 256], [dst.data_ptr()], [256], [th * 256], nframes)
     torch.cuda.synchronize()
     r = nframes % 128
-    assert f.last_kernel(0).startswith("ewa_gather_kernel" if r < 16 else "ewa_framelane_win"), (r, f.last_kernel(0))
+    # (r = 1: gather kernel; 3 .. 32: the frame-lane kernel's sub-group form -- kernel_framelane_sub.hip)
+    assert f.last_kernel(0) == ("ewa_gather_kernel" if r < 3 else "ewa_framelane_sub_kernel"), (r, f.last_kernel(0))
     out = dst.cpu().numpy()
     for k in (0, 127, 128, nframes - 1, nframes // 2):
         want = of.get_frame([host[k]])

@@ -380,7 +380,7 @@ def test_lookahead_ring_sequential_and_seek(host, O, depth, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,group,kernel", [
-    (("Y8", 1280, 720, 1754, 986, "JincResize", {}), None, "ewa_framelane_win"),          # no phase structure, fs 7: groups of 16
+    (("Y8", 1280, 720, 1754, 986, "JincResize", {}), None, "ewa_framelane_sub_kernel"),   # no phase structure, fs 7: groups of 16 = four sub-groups per wave
     (("Y8", 1280, 720, 1920, 1080, "Jinc256Resize", {}), 32, "ewa_direct_runs_kernel"),   # 1.5x tap 8 (fs 17): one launch per group
 ], ids=["A137_lookahead32", "N15T8_lookahead32_group32"])
 def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, case, group, kernel, monkeypatch):
