@@ -74,6 +74,11 @@ CONFIGS = {
     "N25T6": ("Y16", 768, 432, 1920, 1080, dict(tap=6), 128),   # 5/2 with Jinc144 on 16-bit: fs 13, period 5, source step 2
     "A137": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 256),    # 1.37x: no phase structure at all (>= 128 frames: frame-pair kernel)
     "A1875": ("Y8", 1024, 576, 1920, 1080, dict(tap=3), 256),  # PAL -> 1080p, 15/8: period 15, source step 8
+    # what a host at look-ahead 32 hands over: groups of 16 frames (the frame-lane kernel's sub-group form, round 4), and 4 / 32 frames
+    "A137L16": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 16),
+    "A137L32": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 32),
+    "A137L4": ("Y8", 1280, 720, 1754, 986, dict(tap=3), 4),
+    "D169L16": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 16),
     "D169": ("Y8", 1920, 1080, 1600, 900, dict(tap=3), 256),   # 5/6 down-scale: drifting, period 5, source step 6, fs 8
     "D12": ("Y8", 3840, 2160, 1920, 1080, dict(tap=3), 128),   # 1/2 down-scale: fs = 13, period 1, source step 2
     "D12H": ("YUV420P16", 3840, 2160, 1920, 1080, dict(tap=3), 64),  # 4K 16-bit 4:2:0 -> 1080p

@@ -23,7 +23,7 @@ done
 cp profiles/$JINC_PROFILE_DIR/${tag}_* gpurun_out/$JINC_PROFILE_DIR/ 2>/dev/null
 fi
 [ "$part" = profiles ] && exit 0
-for c in ${JINC_LINE_CONFIGS:-C1 C2 C3 C4 C2T4 C2YUV C2H C2HT4 C2F N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A1875 N3T4 N3T8 N480T4 N480T6 N25T6}; do
+for c in ${JINC_LINE_CONFIGS:-C1 C2 C3 C4 C2T4 C2YUV C2H C2HT4 C2F N15 N3 U43 N480 N15T4 D23 D12 D12H D12F D13 D12T4 D12T8 D169 T6 T16 N15T8 A137 A137L32 A137L16 A137L4 A1875 D169L16 N3T4 N3T8 N480T4 N480T6 N25T6}; do
   timeout 120 python bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline --no-e2e 2>/dev/null | tail -1 > gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
   python profiles/bench_line.py < gpurun_out/$JINC_PROFILE_DIR/${tag}_bench_$c.json
 done

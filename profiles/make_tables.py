@@ -3,7 +3,7 @@
 import glob, json, os, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 rdir, tag = sys.argv[1], sys.argv[2]
-order = ["C2", "C1", "C3", "C4", "C2T4", "C2YUV", "C2H", "C2HT4", "C2F", "A137", "A1875", "N15", "N3", "U43", "N480", "N15T4", "N15T8", "D169", "D12", "D23", "D13", "D12H", "D12F",
+order = ["C2", "C1", "C3", "C4", "C2T4", "C2YUV", "C2H", "C2HT4", "C2F", "A137", "A137L32", "A137L16", "A137L4", "A1875", "D169L16", "N15", "N3", "U43", "N480", "N15T4", "N15T8", "D169", "D12", "D23", "D13", "D12H", "D12F",
          "D12T4", "D12T8", "T6", "T16", "N3T4", "N3T8", "N480T4", "N480T6", "N25T6"]
 new = False
 for c in order:
