@@ -63,8 +63,10 @@ struct Rules {
     static constexpr long long kHalfTileMaxWorkgroups = 6144;
     // fs-9 quad form (ewa_periodic_quad9_kernel) below this many full-tile workgroups per launch (C4: one frame per call)
     static constexpr long long kQuad9MaxWorkgroups = 4096;
-    // border columns of exactly periodic plans on the frame-lane kernel from this many frames per call on
-    static constexpr int kFlColsMinFrames = 64;
+    // border columns of exactly periodic plans on the frame-lane kernel from this many frames per call on (up to 32 frames its
+    // sub-group form; round4/fl_cols_small_ab.log: level at 4 and 8 frames, 1080p -> 4K 8-bit +0.4 ... 3.6 % at 16, +1.2 at 32,
+    // +3 at 48; 4:2:0 +6.5 % at 16)
+    static constexpr int kFlColsMinFrames = 16;
     // float planes on the trimmed support (a scan of the source and two launches per plane) from this many taps per plane and call on
     static constexpr double kFloatTrimMinTaps = 1.0e9;
     // ... and its two-periods-per-lane form on integer planes from this many workgroups per launch on
@@ -548,7 +550,16 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 jinc::FrameLaneArgs fa = t.fl_cols;
                 fa.io = io;
                 fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
-                timed(f.ev_gather, border_stream, "border column frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+                // (fewer than 64 frames: the sub-group form, as for whole planes)
+                int g = nframes <= Rules::kFlSub16MaxFrames ? 16 : nframes <= Rules::kFlSub8MaxFrames ? 8 : nframes <= Rules::kFlSub4MaxFrames ? 4
+                        : nframes <= Rules::kFlSub2MaxFrames ? 2 : 0;
+                while (g >= 2 && !jinc::framelane_sub_supported(t.plan.fs, g, fa.ty_shift)) g /= 2;
+                fa.subgroups = g >= 2 && fa.variant != 1 ? g : 0;
+                if (fa.subgroups)
+                    timed(f.ev_gather, border_stream, "border column frame-lane kernel launch (sub-groups)",
+                          [&](hipStream_t s) { return jinc::launch_framelane_sub(fa, s); });
+                else
+                    timed(f.ev_gather, border_stream, "border column frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             }
             const bool colstrip = !fl_cols && t.use_colstrip && f.border_strips != 2;
             // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued

@@ -951,11 +951,12 @@ def test_float_planes_take_the_trimmed_support_only_where_every_sample_is_finite
                                                 ("YUV420P8", 128, 96, 256, 192, dict(cplace="mpeg1")), ("Y8", 192, 108, 96, 54, {}),
                                                 ("Y8", 120, 90, 160, 120, {})],
                          ids=["Y8_2x", "Y16_2x_tap4", "Y32_2x", "YUV420P8_2x", "Y8_half", "Y8_4to3"])
-@pytest.mark.parametrize("frames", [64, 131])
+@pytest.mark.parametrize("frames", [16, 21, 64, 131])
 def test_border_columns_of_periodic_plans_in_batches(gpu_pkg, O, fmt, sw, sh, tw, th, kw, frames):
-    """Batches of >= 64 frames run the border columns (and corners) of exactly periodic plans on the frame-lane kernel -- lanes
-    = frames, a border pixel's private coefficient set a scalar load -- instead of the column-strip + corner kernels (which
-    kernel mode 3 keeps).  Every frame of the batch against the oracle; the two forms against each other on all of them."""
+    """Batches of >= 16 frames run the border columns (and corners) of exactly periodic plans on the frame-lane kernel -- lanes
+    = frames, a border pixel's private coefficient set a scalar load (up to 32 frames: its sub-group form, frames x output rows)
+    -- instead of the column-strip + corner kernels (which kernel mode 3 keeps).  Every frame of the batch against the oracle; the
+    two forms against each other on all of them."""
     torch = pytest.importorskip("torch")
     from test_framelane_pair import _run_batch
     ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
@@ -968,7 +969,7 @@ def test_border_columns_of_periodic_plans_in_batches(gpu_pkg, O, fmt, sw, sh, tw
     strips = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 3)
     for k in range(frames):
         assert_planes_equal(auto[k], strips[k], f.out_dims(), what=f"{fmt} frame {k}: frame-lane border columns vs column strips")
-        if k in (0, 63, frames - 1):
+        if k in (0, min(63, frames // 2), frames - 1):
             assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=4), f.out_dims(), what=f"{fmt} frame {k} vs oracle")
     f.close()
 
