@@ -42,6 +42,10 @@ struct Rules {
     // (by batch size, frame-lane against gather border: 1.5x with tap 4 +6 % at 16 frames, +9 % at 32; with tap 8 -8 % at 16, level
     // at 32, +3 % at 48; 3x with tap 4 -2 % / +3 % / +5 %; DVD -> 1080p with tap 4 +1 % / +5.5 % / +10 %)
     static constexpr int kRunsFrameLaneBorderMinFrames = 32;
+    // ... and from 8 frames where the frame-lane kernel's sub-group form takes the border (filter sizes up to 9: tap 4;
+    // round4/runs_border_small_ab.log: 1.5x with tap 4 -15 % at 4 frames, +7.5 % at 8, +10 % at 16, +9 % at 32; 3x -10 / +6.5 / +13 /
+    // +12 %; DVD -> 1080p -6 / -0.7 / +4 / +8 %)
+    static constexpr int kRunsFrameLaneBorderMinFramesSub = 8;
     // calls of exactly periodic plans below this many taps: one gather launch over the border frame instead of the strip kernels
     static constexpr double kStripBorderMinTaps = 5.0e9;
     // multi-plane calls whose first plane has at most this many output samples run their other planes on the side stream
@@ -125,13 +129,13 @@ bool plane_pair(const void* const src[4], const int src_pitch[4], void* const ds
 
 // Frames per call from which the border frame of a runs-form plan goes to the frame-lane kernel; A/B knob
 // JINC_RUNS_FL_BORDER_FRAMES (0: never); read once.
-int runs_fl_border_min_frames() {
-    static const int v = [] {
+int runs_fl_border_min_frames(bool sub_form) {
+    static const int knob = [] {
         const char* e = std::getenv("JINC_RUNS_FL_BORDER_FRAMES");
-        const int n = e ? std::atoi(e) : Rules::kRunsFrameLaneBorderMinFrames;
-        return n <= 0 ? INT32_MAX : n;
+        return e ? std::atoi(e) : -1;
     }();
-    return v;
+    if (knob >= 0) return knob == 0 ? INT32_MAX : knob;
+    return sub_form ? Rules::kRunsFrameLaneBorderMinFramesSub : Rules::kRunsFrameLaneBorderMinFrames;
 }
 
 bool plane_fork_enabled() {  // A/B knob JINC_PLANE_FORK (default: on); read once
@@ -488,10 +492,17 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         }
         return;
     }
+    // Border rectangles on the frame-lane kernel with fewer than 64 frames: sub-groups per wave of its sub-group form (0: the
+    // 64-frame form -- more than 32 frames, or a filter size / tile the form does not take).
+    auto border_subgroups = [&](const jinc::FrameLaneArgs& fa, int n) {
+        int g = n <= Rules::kFlSub16MaxFrames ? 16 : n <= Rules::kFlSub8MaxFrames ? 8 : n <= Rules::kFlSub4MaxFrames ? 4 : n <= Rules::kFlSub2MaxFrames ? 2 : 0;
+        while (g >= 2 && !jinc::framelane_sub_supported(t.plan.fs, g, fa.ty_shift)) g /= 2;
+        return g >= 2 && fa.variant != 1 ? g : 0;
+    };
     // Border frame of a drifting plan (every border pixel owns a coefficient set): the gather kernel, or in batches the frame-lane
     // kernel (lanes = frames make the private sets scalar loads).
     auto drifting_border = [&]() {
-        if (t.use_fl_border && nframes >= runs_fl_border_min_frames() && t.border_rects.n > 0) {
+        if (t.use_fl_border && t.border_rects.n > 0 && nframes >= runs_fl_border_min_frames(border_subgroups(t.fl_border, 32) != 0)) {
             auto aligned_to = [&](uintptr_t bytes) {
                 return reinterpret_cast<uintptr_t>(dst[i]) % bytes == 0 && static_cast<uintptr_t>(dst_pitch[i]) % bytes == 0 &&
                        (io.nframes <= 1 || io.dst_frame_stride % bytes == 0);  // io.nframes: 2 when two planes travel as one call
@@ -499,7 +510,12 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             jinc::FrameLaneArgs fa = t.fl_border;
             fa.io = io;
             fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
-            timed(f.ev_gather, border_stream, "border frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
+            fa.subgroups = border_subgroups(fa, nframes);
+            if (fa.subgroups)
+                timed(f.ev_gather, border_stream, "border frame-lane kernel launch (sub-groups)",
+                      [&](hipStream_t s) { return jinc::launch_framelane_sub(fa, s); });
+            else
+                timed(f.ev_gather, border_stream, "border frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
         } else if (t.border_rects.n > 0) {
             timed(f.ev_gather, border_stream, "border kernel launch",
                   [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.border_rects, s); });
@@ -550,11 +566,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 jinc::FrameLaneArgs fa = t.fl_cols;
                 fa.io = io;
                 fa.vec_store_ok = (aligned_to(static_cast<uintptr_t>(4 * sb)) ? 1 : 0) | (aligned_to(16) ? 2 : 0);
-                // (fewer than 64 frames: the sub-group form, as for whole planes)
-                int g = nframes <= Rules::kFlSub16MaxFrames ? 16 : nframes <= Rules::kFlSub8MaxFrames ? 8 : nframes <= Rules::kFlSub4MaxFrames ? 4
-                        : nframes <= Rules::kFlSub2MaxFrames ? 2 : 0;
-                while (g >= 2 && !jinc::framelane_sub_supported(t.plan.fs, g, fa.ty_shift)) g /= 2;
-                fa.subgroups = g >= 2 && fa.variant != 1 ? g : 0;
+                fa.subgroups = border_subgroups(fa, nframes);  // (fewer than 64 frames: the sub-group form, as for whole planes)
                 if (fa.subgroups)
                     timed(f.ev_gather, border_stream, "border column frame-lane kernel launch (sub-groups)",
                           [&](hipStream_t s) { return jinc::launch_framelane_sub(fa, s); });
