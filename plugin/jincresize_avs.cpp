@@ -75,11 +75,15 @@ void finish_frame(AVS_FilterInfo* fi, Instance* inst, AVS_VideoFrame* src, AVS_V
     avs_release_video_frame(src);    // ref :627
 }
 
+// A failed frame: the message goes to the host through fi->error (no CPU fallback) and NO frame is returned -- AviSynth+'s C
+// interface throws on fi->error before it takes ownership of what get_frame returned (avisynth_c.cpp, C_VideoFilter::GetFrame), so a
+// frame handed back here would leak, and its content would be undefined anyway.
 AVS_VideoFrame* report(AVS_FilterInfo* fi, Instance* inst, AVS_VideoFrame* src, AVS_VideoFrame* dst) {
-    inst->error = jinc_last_error();  // no CPU fallback: the failure goes to the host
+    inst->error = jinc_last_error();
     fi->error = inst->error.c_str();
     if (src) avs_release_video_frame(src);
-    return dst;
+    if (dst) avs_release_video_frame(dst);
+    return nullptr;
 }
 
 // ref :603-630, synchronous form

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Re-measures the cross-over rules of csrc/dispatch.cpp (struct Rules) on the box it runs on: for every rule one bench run with the
+rule's choice and one with the alternative at a batch size next to the threshold, printed as a table with the ratio.  The constants
+were each taken from one box's A/B; boxes of the pool differ by up to 9 % in the clock they hold, and several rules sit within a few
+per cent of level -- this is the tool that says which ones a given box would set differently.
+
+    python profiles/recheck_rules.py [out.log]            (through gpurun, from the repository root)
+
+Every run is a child process (`bench.py --steps 20 --no-cpu-baseline --no-e2e --no-clock-sampler`) with the A/B knob in its environment."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (rule, configuration, frames per call, {env / args of the rule's choice}, {env / args of the alternative}, what the alternative is)
+CHECKS = [
+    ("kFlSubMinFrames = 3: sub-group form from 3 frames", "A137", 3, {}, {"args": ["--kernel-mode", "1"]}, "gather kernel"),
+    ("kFlSubMinFrames = 3: gather kernel below", "A137", 2, {}, {"args": ["--kernel-mode", "16"]}, "sub-group form"),
+    ("kFlSub4MaxFrames = 16 -> 4 sub-groups at 16 frames", "A137", 16, {}, {"env": {"JINC_FL_SUB": "2"}}, "2 sub-groups"),
+    ("kFlSub2MaxFrames = 32 -> 2 sub-groups at 32 frames", "A137", 32, {}, {"env": {"JINC_FL_SUB": "4"}}, "4 sub-groups"),
+    ("kFlSub2MaxFrames = 32: 64-frame form above", "A137", 40, {}, {"env": {"JINC_FL_SUB": "4"}}, "4 sub-groups"),
+    ("sub-group form at all (16 frames)", "D169", 16, {}, {"env": {"JINC_FL_SUB": "0"}}, "64-frame form"),
+    ("frame-pair form for whole groups of 128", "A137", 128, {}, {"args": ["--kernel-mode", "11"]}, "64-frame form"),
+    ("kFlColsMinFrames = 16: border columns on the frame-lane kernel", "C2", 16, {}, {"env": {"JINC_FL_COLS_FRAMES": "0"}}, "column-strip kernel"),
+    ("kFlColsMinFrames = 16: column strips below", "C2", 8, {}, {"env": {"JINC_FL_COLS_FRAMES": "3"}}, "frame-lane kernel"),
+    ("kRunsFrameLaneBorderMinFramesSub = 8", "N15T4", 8, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
+    ("kRunsFrameLaneBorderMinFrames = 32 (tap 8)", "N15T8", 32, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
+    ("kQuad2x8MinWorkgroups: two periods per lane on 8 x 8", "C2T4", 9, {}, {"env": {"JINC_QUAD2X8": "0"}}, "one period per lane"),
+    ("trimmed support, integer planes", "C2", 64, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
+    ("trimmed support behind the finite-sample scan (float, 8 x 8)", "C4", 16, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
+    ("no trimmed support for float planes at 6 x 6", "C2F", 64, {}, {"args": ["--kernel-mode", "13"]}, "trimmed quad form behind the scan"),
+    ("rows kernel: per-row spans and row count", "C3", 32, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
+    ("direct kernel's interior on the trimmed support", "D12", 128, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
+    ("quad form of the periodic kernel (single frames)", "C2", 1, {}, {"args": ["--kernel-mode", "2"]}, "window kernel"),
+]
+
+
+def run(cfg, frames, variant):
+    env = dict(os.environ)
+    env.update(variant.get("env", {}))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--frames", str(frames), "--steps", "20", "--warmup", "3",
+           "--no-cpu-baseline", "--no-e2e", "--no-clock-sampler"] + variant.get("args", [])
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+    line = json.loads(out[-1])
+    return line["value"], line["roofline"]["kernel"]
+
+
+def main():
+    rows = []
+    for rule, cfg, frames, choice, other, other_name in CHECKS:
+        a = [run(cfg, frames, choice) for _ in range(2)]   # alternating: choice, alternative, choice, alternative
+        b = [run(cfg, frames, other) for _ in range(2)]
+        va, vb = max(v for v, _ in a), max(v for v, _ in b)
+        verdict = "holds" if va >= vb else ("level" if va >= 0.98 * vb else "FLIPS on this box")
+        rows.append(f"{rule:66s} {cfg:6s} {frames:4d} frames  rule {va / 1000:8.1f} Gpix/s ({a[0][1]})  {other_name}: {vb / 1000:8.1f} ({b[0][1]})  "
+                    f"ratio {va / vb:5.3f}  {verdict}")
+        print(rows[-1], flush=True)
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as fh:
+            fh.write("\n".join(rows) + "\n")
+
+
+if __name__ == "__main__":
+    main()

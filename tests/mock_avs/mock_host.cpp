@@ -267,11 +267,18 @@ AVS_VideoFrame* avs_get_frame(AVS_Clip* clip, int n) {
         if (!clip->fi->get_frame) return avs_get_frame(clip->fi->child, n);
         // MT_SERIALIZED (3): the host's worker threads take turns at the one instance.  (MT_MULTI_INSTANCE (2): a real host
         // creates an instance per thread -- here the test invokes the function once per thread.)
+        // As AviSynth+'s C_VideoFilter::GetFrame: when the filter set fi->error the host throws BEFORE it takes ownership of the
+        // returned frame -- a frame returned beside an error is never released (and shows up in mock_live_frames).
+        auto call = [&]() -> AVS_VideoFrame* {
+            clip->fi->error = nullptr;
+            AVS_VideoFrame* f = clip->fi->get_frame(clip->fi.get(), n);
+            return clip->fi->error ? nullptr : f;
+        };
         if (clip->fi->set_cache_hints && clip->fi->set_cache_hints(clip->fi.get(), AVS_CACHE_GET_MTMODE, 0) == 3) {
             std::lock_guard<std::mutex> lock(clip->serialized);
-            return clip->fi->get_frame(clip->fi.get(), n);
+            return call();
         }
-        return clip->fi->get_frame(clip->fi.get(), n);
+        return call();
     }
     ++clip->get_frame_calls;
     if (n < 0 || n >= static_cast<int>(clip->frames.size())) return nullptr;

@@ -236,9 +236,10 @@ def test_filter_object_without_a_gpu_or_with_one(host, O, pkg):
     frame = host.mock_clip_get_frame(clip, 0)
     if pkg.device_count() == 0:
         assert b"HIP device" in host.mock_clip_error(clip)
+        assert not frame          # the error AND no frame: AviSynth+ throws on fi->error and would never release one
     else:
         assert host.mock_clip_error(clip) is None
-    host.mock_frame_release(frame)
+        host.mock_frame_release(frame)
     assert host.mock_clip_get_frame(clip, 5) is None          # child has no such frame -> null (ref :610-611)
     host.mock_clip_release(clip)
     host.mock_source_release(src)
