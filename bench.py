@@ -553,12 +553,15 @@ def make_workload(pkg, torch, config, frames, device, seed):
         if sb == 2:
             t = t.view(torch.uint16)
         src_t.append(t)
+    # A/B knob (measurements only): JINC_BENCH_DST_SHIFT = bytes the destination planes start beyond a 256-byte boundary (one spare
+    # row per frame holds the overhang) -- which store alignment do the kernels meet?
+    dst_shift = int(os.environ.get("JINC_BENCH_DST_SHIFT", "0"))
     for (w, h) in ddims:
-        dst_t.append(torch.zeros((frames, h, pitch_elems(w)), device="cuda", dtype=tdtype))
+        dst_t.append(torch.zeros((frames, h + (1 if dst_shift else 0), pitch_elems(w)), device="cuda", dtype=tdtype))
     sp = [t.data_ptr() for t in src_t]
     spitch = [t.stride(1) * sb for t in src_t]
     sstride = [t.stride(0) * sb for t in src_t]
-    dp = [t.data_ptr() for t in dst_t]
+    dp = [t.data_ptr() + dst_shift for t in dst_t]
     dpitch = [t.stride(1) * sb for t in dst_t]
     dstride = [t.stride(0) * sb for t in dst_t]
     stream = torch.cuda.current_stream()
