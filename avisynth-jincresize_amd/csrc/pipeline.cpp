@@ -503,9 +503,11 @@ void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host
     f.failed.clear();  // the explicit reset: failures of the previous configuration are not carried over
     depth = std::max(1, std::min(depth, kMaxPipelineDepth));
     // Frames per launch unless the caller says otherwise: half the frames in flight, so that one group computes while the
-    // client still collects the previous one -- from 16 frames in flight on; below that single frames on a stream each
-    // (the round-2 shape) overlap better than groups of 2..7 (C2 at depth 4: 5 550 frames/s against 4 400 in pairs).
-    if (group <= 0) group = depth >= 16 ? depth / 2 : 1;
+    // client still collects the previous one -- from 8 frames in flight on; below that single frames on a stream each
+    // (the round-2 shape) overlap better than pairs (host to host, one thread, round4/e2e_small_depths.log: depth 4 in pairs
+    // -4 ... -13 %; depth 8 in fours +2 % on 1080p -> 4K, +10 % on 1.37x; depth 12 in sixes +5 % / +24 %: plans without phase
+    // structure run a group of 3 or more frames on the frame-lane kernel's sub-group form instead of a gather launch per frame).
+    if (group <= 0) group = depth >= 8 ? depth / 2 : 1;
     group = std::min(group, depth);
     const size_t per_frame = std::max<size_t>(1, staging_bytes_per_frame(f));
     auto ring_of = [&](int g) { return (depth + g - 1) / g + 1; };

@@ -173,7 +173,7 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  * coalesces: `group` consecutively submitted frames share one strided device buffer and ONE set of kernel
  * launches (the batch kernels -- lanes = frames, wide tiles -- that single-frame calls cannot use), followed by one
  * D2H copy per frame.  A group leaves when it is full, when a wait asks for one of its frames, or on
- * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 16; else 1): one group computes while the client collects
+ * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 8; else 1): one group computes while the client collects
  * the previous one.  src and dst must stay valid and untouched until the frame's wait returns.  Frames are
  * independent, so neither grouping nor completion order changes results.
  * register_host_buffers != 0: every plane buffer seen is pinned with hipHostRegister (cached by address range,

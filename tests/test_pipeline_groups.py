@@ -42,7 +42,7 @@ def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg,
     ref = _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
     f.set_pipeline(depth, True, group)
-    assert f.pipeline_group == (group or (depth // 2 if depth >= 16 else 1))
+    assert f.pipeline_group == (group or (depth // 2 if depth >= 8 else 1))
     dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
     tickets = [f.submit(srcs[k], dsts[k]) for k in range(n)]
     for k in range(n):
