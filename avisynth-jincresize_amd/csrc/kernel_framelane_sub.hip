@@ -7,9 +7,11 @@
 // (col_start depends on x only), so the G rows of a wave advance their windows through the same source columns in the same
 // steps: the walk by window origin, the ring phase and every loop bound stay wave-uniform, exactly as in
 // ewa_framelane_win_kernel.  What differs between the sub-groups is per-lane data: the source row the window starts at (an LDS
-// offset) and the coefficient set of the pixel, which therefore arrives through VECTOR loads into VGPRs (G distinct addresses per
-// load instruction, 16 bytes each) instead of scalar loads into SGPRs.  Each lane still owns one output sample's whole chain in
-// (ly, lx) order with un-fused multiply and add.
+// offset) and the coefficient set of the pixel, which cannot be a scalar operand any more.  The lanes of a sub-group need the SAME
+// coefficients, though: every row of 16 lanes keeps ONE copy of the set, four floats per lane (one 16-byte vector load per lane
+// and pixel), and the multiply of a tap reads its coefficient from the lane that holds it through a DPP operand (row_newbcast; by
+// quads for sub-groups of 8 or 4 frames) -- see SubSet.  Each lane still owns one output sample's whole chain in (ly, lx) order
+// with un-fused multiply and add.  DESIGN.md section 4.6 has the measurements of the forms tried on the way.
 #include <algorithm>
 
 #include "device_common.hpp"
