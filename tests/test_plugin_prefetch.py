@@ -61,21 +61,22 @@ def pull_with_threads(L, h, clips, nframes, nplanes, dtype, nthreads, pick):
 
 
 CASES = [
-    ("C2YUV", "YUV420P8", 1920, 1080, 3840, 2160, {}, ("ewa_periodic",)),
-    ("A137", "Y8", 1280, 720, 1754, 986, {}, ("ewa_framelane",)),
+    ("C2YUV", "YUV420P8", 1920, 1080, 3840, 2160, {}, ("ewa_periodic",), 32, 256),
+    ("A137", "Y8", 1280, 720, 1754, 986, {}, ("ewa_framelane",), 32, 256),
+    ("A137_lookahead8", "Y8", 1280, 720, 1754, 986, {}, ("ewa_framelane_sub",), 8, 96),   # groups of 4: 4 frames x 16 output rows per wave
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, monkeypatch):
-    """256 frames, 4 threads, JINCRESIZE_LOOKAHEAD=32: bit-exact frame by frame against single synchronous calls (and the
-    oracle on a few), every child frame fetched exactly once, every launch a full 16-frame batch on a batch kernel."""
-    _, fmt_name, sw, sh, tw, th, named, kernels = case
-    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "32")
+    """256 frames, 4 threads, JINCRESIZE_LOOKAHEAD=32 (96 frames at look-ahead 8): bit-exact frame by frame against single
+    synchronous calls (and the oracle on a few), every child frame fetched exactly once, every launch a full batch of half the
+    look-ahead depth on a batch kernel."""
+    _, fmt_name, sw, sh, tw, th, named, kernels, lookahead, nframes = case
+    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", str(lookahead))
     monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
     monkeypatch.delenv("JINCRESIZE_GROUP", raising=False)
     fmt = O.FORMATS[fmt_name]
-    nframes = 256
     dtype = np.uint8
     single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0, **named)
     of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(named))
@@ -91,7 +92,7 @@ def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, 
         got = single.get_frame(planes)
         dims = fmt.plane_dims(tw, th)
         cut = [g[:hh, :ww] for g, (ww, hh) in zip(got, dims)]
-        if n in (0, 77, 255):
+        if n in (0, 77, nframes - 1):
             assert_planes_equal(cut, of.get_frame(planes, threads=8), dims, what=f"single call, frame {n} vs oracle")
         want[n] = crc_of(cut)
     single.close()
@@ -121,7 +122,7 @@ def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, 
     calls = [host.mock_source_calls_of_frame(src, n) for n in range(nframes)]
     assert calls[0] == 2 and all(c == 1 for c in calls[1:]), [(n, c) for n, c in enumerate(calls) if c != 1][:10]   # frame 0: + the property probe
     served = {(name, k) for name, k in seen if name} - {stale}
-    assert served and all(name.startswith(kernels) and k == 16 for name, k in served), served
+    assert served and all(name.startswith(kernels) and k == lookahead // 2 for name, k in served), served
     by_shader, by_dma, _ = pkg.transport_counts()
     assert (by_shader, by_dma) == (nframes, 0)   # pinned in place: every group left by the shader
     host.mock_clip_release(clip)
