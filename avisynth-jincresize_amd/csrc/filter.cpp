@@ -378,11 +378,21 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
     return "ewa_gather_kernel";
 }
 
+namespace {
+// Does the periodic family run `t` on its trimmed support under the filter's kernel mode?  (csrc/dispatch.cpp Choice::trimmed
+// without what depends on the call: float planes at 6 x 6 keep the full window in the automatic mode -- they are not bound by the
+// VALU -- and take the trimmed support, behind the finite-sample scan, where a kernel mode forces it or the support is larger.)
+bool runs_trimmed(const jinc_filter* f, const DeviceTable& t) {
+    if (t.trim_fs <= 0 || f->full_window || f->kernel_mode == 5 || f->kernel_mode == 6) return false;
+    return !(t.trim_needs_finite && f->kernel_mode == 0 && t.trim_fs <= 6);
+}
+}  // namespace
+
 int jinc_filter_periodic_support(const jinc_filter* f, int table) {
     if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return 0;
     const DeviceTable& t = f->tables[table];
     if (!t.use_periodic) return 0;
-    return t.trim_fs > 0 && !f->full_window ? t.trim_fs : t.plan.fs;
+    return runs_trimmed(f, t) ? t.trim_fs : t.plan.fs;
 }
 
 double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kernel) {
@@ -394,14 +404,15 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
         return static_cast<double>(n) * n;
     }
     if (!t.use_periodic) return 0;
-    if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && !f->full_window) return 42.0;  // 6 rows x 7 columns
-    if (rows_kernel == 3 && t.trim_fs == 6 && !f->full_window &&  // ewa_periodic_quad2_kernel: chord rows on four taps (half the samples each)
+    const bool trimmed = runs_trimmed(f, t);
+    if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && trimmed) return 42.0;  // 6 rows x 7 columns
+    if (rows_kernel == 3 && t.trim_fs == 6 && trimmed &&  // ewa_periodic_quad2_kernel: chord rows on four taps (half the samples each)
         (t.periodic_trim.quad_inner & jinc::PeriodicArgs::kQuadInnerTap3) == jinc::PeriodicArgs::kQuadInnerTap3)
         return 34.0;
-    if (rows_kernel == 3 && t.trim_fs == 8 && !f->full_window && t.periodic_trim.quad &&  // quad forms on the 8 x 8 support with the tap-4 pattern
+    if (rows_kernel == 3 && t.trim_fs == 8 && trimmed && t.periodic_trim.quad &&  // quad forms on the 8 x 8 support with the tap-4 pattern
         jinc::quad8_pattern_fits(t.periodic_trim.quad_trim8, jinc::kQuad8TrimTap4Value))
         return 56.0;
-    if (t.trim_fs > 0 && t.trim_nx == t.trim_fs && !f->full_window) return rows_kernel == 1 ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
+    if (trimmed && t.trim_nx == t.trim_fs) return rows_kernel == 1 ? t.trim_rows_taps : static_cast<double>(t.trim_fs) * t.trim_fs;
     return static_cast<double>(t.plan.fs) * t.plan.fs;
 }
 
