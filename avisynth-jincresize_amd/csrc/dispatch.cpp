@@ -71,7 +71,9 @@ struct Rules {
     // sub-group form; round4/fl_cols_small_ab.log: level at 4 and 8 frames, 1080p -> 4K 8-bit +0.4 ... 3.6 % at 16, +1.2 at 32,
     // +3 at 48; 4:2:0 +6.5 % at 16)
     static constexpr int kFlColsMinFrames = 16;
-    // float planes on the trimmed support (a scan of the source and two launches per plane) from this many taps per plane and call on
+    // float planes on the trimmed support (a cleared flag set, a scan of the plane's rim and two launches per plane, the second
+    // returning at once) from this many taps per plane and call on: 1080p -> 4K float, one frame (4e8 taps) 69 against 59 ... 62
+    // Gpix/s, eight frames 144 -> 164, 64 frames 174 -> 207 (round4/float_trim_ab.log)
     static constexpr double kFloatTrimMinTaps = 1.0e9;
     // ... and its two-periods-per-lane form on integer planes from this many workgroups per launch on
     static constexpr long long kQuad2x8MinWorkgroups = 4096;
@@ -308,8 +310,8 @@ struct Choice {
     // The periodic family on the trimmed support (integer planes whose phase sets have a zero rim; device_plan.cpp
     // trim_periodic): the automatic choice wherever it exists; kernel modes 5 / 6 (the fs-7 packed A/B variant) and 15
     // (= the automatic choice on the full window, for A/B and tests: jinc_filter::full_window) keep the reference's window.
-    // Float planes take it frame by frame, where kernel_scan.hip found nothing but finite samples (two launches per plane and
-    // a pass over the source: calls of at least kFloatTrimMinTaps taps per plane).
+    // Float planes take it frame by frame: the trimmed launch computes every frame and flags those in which it staged an infinity
+    // or a NaN, a full-window launch behind it computes the flagged frames again (calls of at least kFloatTrimMinTaps taps per plane).
     // launches that fill the chip with the 128 x 24 tiles of the two-periods-per-lane quad form
     bool quad2_fills(const DeviceTable& t) const {
         return static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 23) / 24) * nframes >= Rules::kQuad2MinWorkgroups;
@@ -319,10 +321,20 @@ struct Choice {
         // the 6-row x 7-column support exists for the quad2 form only: where that form is not what runs, the full window
         if (t.trim_nx != t.trim_fs && !(f.kernel_mode == 13 || (f.kernel_mode == 0 && quad2_fills(t)))) return false;
         if (!t.trim_needs_finite) return true;
-        // (float planes at fs 7 are bound by their bytes, not by the VALU: C2's geometry on float RGB 174.2 Gpix/s on the trimmed
-        // quad form against 174.5 on the full window, a scan and a second launch on top -- round4/direct_trim_ab.log)
-        if (f.kernel_mode == 0 && t.trim_fs <= 6) return false;
-        return static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs * nframes >= Rules::kFloatTrimMinTaps || f.kernel_mode != 0;
+        // (Float planes: the trimmed launch is its own finite-sample scan -- launch_plane -- so what is left of the price is a cleared
+        // flag set, a scan of the plane's rim and a second launch that returns at once: from kFloatTrimMinTaps taps per plane and call.
+        // With a scan PASS in front, round 4's first form, the 6 x 6 support gained nothing on float planes: C2's geometry on float
+        // RGB 174.2 against 174.5 Gpix/s; without it 174 -> 207, round4/float_trim_ab.log.)
+        static const double min_taps = [] {  // A/B knob JINC_FLOAT_TRIM_MIN_TAPS (taps per plane and call from which float planes trim)
+            const char* e = std::getenv("JINC_FLOAT_TRIM_MIN_TAPS");
+            return e ? std::atof(e) : static_cast<double>(Rules::kFloatTrimMinTaps);
+        }();
+        static const int min_fs = [] {  // A/B knob JINC_FLOAT_TRIM_MIN_FS: smallest trimmed support float planes take by themselves
+            const char* e = std::getenv("JINC_FLOAT_TRIM_MIN_FS");
+            return e ? std::atoi(e) : 0;
+        }();
+        if (f.kernel_mode == 0 && t.trim_fs < min_fs) return false;
+        return static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs * nframes >= min_taps || f.kernel_mode != 0;
     }
     const jinc::PeriodicArgs& periodic_args(const DeviceTable& t) const { return trimmed(t) ? t.periodic_trim : t.periodic; }
     int periodic_fs(const DeviceTable& t) const { return trimmed(t) ? t.trim_fs : t.plan.fs; }
@@ -677,11 +689,27 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     }
                     uint32_t* flags = f.finite_flags + (static_cast<size_t>(f.finite_flags_turn % kFlagSets) * 4 + static_cast<size_t>(i)) * f.finite_flags_frames;
                     hip_check(hipMemsetAsync(flags, 0, sizeof(uint32_t) * io.nframes, s), "hipMemsetAsync(finite flags)");
-                    int rc = jinc::launch_finite_scan(io, t.plan.src_w, t.plan.src_h, flags, s);
-                    if (rc) return rc;
                     jinc::PeriodicArgs fin = t.periodic_trim, rest = t.periodic;
                     fin.frame_flags = rest.frame_flags = flags;
-                    fin.run_when = 0, rest.run_when = 1;
+                    int rc = 0;
+                    static const bool scan_pass = [] {  // A/B knob: JINC_FLOAT_SCAN=1 = a scan pass over the whole source in front (round 4's first form)
+                        const char* e = std::getenv("JINC_FLOAT_SCAN");
+                        return e && std::atoi(e) != 0;
+                    }();
+                    if (scan_pass) {
+                        rc = jinc::launch_finite_scan(io, t.plan.src_w, t.plan.src_h, flags, s);
+                        fin.run_when = 0, rest.run_when = 1;
+                    } else {
+                        // The trimmed launch is its own scan: it computes every frame and flags those in whose tiles it stages an
+                        // infinity or a NaN (a compare per staged sample instead of a pass over the source: C4 218 us of 1.25 ms).  Its
+                        // tiles stage at least the source rectangle below; what lies outside it -- the rim only the reference's
+                        // zero-coefficient taps and the border pixels reach -- gets the little scan.
+                        const int n = pfs;
+                        rc = jinc::launch_finite_scan_outside(io, t.plan.src_w, t.plan.src_h, fin.min_sx, fin.min_sy, fin.min_sx + fin.ni + n - 1,
+                                                              fin.min_sy + fin.nj + n - 1, flags, s);
+                        fin.run_when = jinc::PeriodicArgs::kRunAllAndFlag, rest.run_when = 1;
+                    }
+                    if (rc) return rc;
                     rc = jinc::launch_periodic(fin, pfs, io, s, variant);
                     if (rc) return rc;
                     return jinc::launch_periodic(rest, t.plan.fs, io, s, 0);

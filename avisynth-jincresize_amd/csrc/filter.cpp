@@ -380,11 +380,9 @@ const char* jinc_filter_interior_kernel(const jinc_filter* f, int table) {
 
 namespace {
 // Does the periodic family run `t` on its trimmed support under the filter's kernel mode?  (csrc/dispatch.cpp Choice::trimmed
-// without what depends on the call: float planes at 6 x 6 keep the full window in the automatic mode -- they are not bound by the
-// VALU -- and take the trimmed support, behind the finite-sample scan, where a kernel mode forces it or the support is larger.)
+// without what depends on the call: float planes take it from Rules::kFloatTrimMinTaps taps per plane and call on.)
 bool runs_trimmed(const jinc_filter* f, const DeviceTable& t) {
-    if (t.trim_fs <= 0 || f->full_window || f->kernel_mode == 5 || f->kernel_mode == 6) return false;
-    return !(t.trim_needs_finite && f->kernel_mode == 0 && t.trim_fs <= 6);
+    return t.trim_fs > 0 && !f->full_window && f->kernel_mode != 5 && f->kernel_mode != 6;
 }
 }  // namespace
 

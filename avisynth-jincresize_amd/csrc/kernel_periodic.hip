@@ -11,6 +11,25 @@
 namespace jinc {
 namespace {
 
+// Float planes on the trimmed support (PeriodicArgs::frame_flags, run_when; csrc/dispatch.cpp): a launch with run_when 0 / 1
+// returns at once for frames whose flag differs; a launch with run_when == kRunAllAndFlag computes every frame and SETS the flag
+// of a frame in whose staged samples it meets an infinity or a NaN -- the kernel reads every source sample of its tiles anyway, so
+// the finite-sample scan costs a compare per staged sample instead of a pass over the source.  (The full-window launch behind it,
+// run_when 1, then computes those frames again.)
+constexpr uint32_t kRunAllAndFlag = PeriodicArgs::kRunAllAndFlag;
+__device__ __forceinline__ bool skips_frame(const PeriodicArgs& a, size_t frame) {
+    return a.frame_flags && a.run_when != kRunAllAndFlag && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when;
+}
+template <typename T>
+__device__ __forceinline__ float staged_value(const PeriodicArgs& a, size_t frame, T v) {
+    if constexpr (std::is_same_v<T, float>) {
+        if (a.run_when == kRunAllAndFlag && (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) == 0x7f800000u)
+            const_cast<uint32_t*>(a.frame_flags)[frame] = 1u;  // (every writer writes 1)
+    }
+    return to_float(v);
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Periodic interior kernel
 // ------------------------------------------------------------------------------------------------
@@ -40,7 +59,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
 
     // The coefficients of the wave's first phase do not depend on the tile: request them (scalar loads) BEFORE the
     // staging loads and the barrier, so that their latency overlaps the staging instead of following it.
@@ -82,7 +101,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
             }
         }
     }
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     {
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -245,7 +264,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
                 if (r < Cfg::kLdsRows && c < Cfg::kSrcCols) {
-                    const float v = to_float(staged[i][k]);
+                    const float v = staged_value(a, frame, staged[i][k]);
                     if (c < Cfg::kPairsPerRow) trow[2 * c] = v;        // first element of pair c
                     if (c >= 64) trow[2 * (c - 64) + 1] = v;           // second element of pair c - 64
                 }
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const Periodi
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const Periodi
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
             }
         }
     }
@@ -627,7 +646,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
             }
         }
     }
@@ -872,7 +891,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const Period
     const int i0 = tile_x * kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -898,7 +917,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const Period
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
             }
         }
     }
@@ -1136,7 +1155,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -1162,7 +1181,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
             }
         }
     }
@@ -1308,7 +1327,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     {   // stage the source tile as fp32, in two halves of the rows (all loads of a half in front of its LDS writes): the whole
         // tile at once would hold more staged registers than the compute phase has
         const int gx0 = a.min_sx + i0;
@@ -1338,7 +1357,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
 #pragma unroll
                 for (int k = 0; k < kColsPerLane; ++k) {
                     const int c = lane + 64 * k;
-                    if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = to_float(staged[i][k]);
+                    if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
                 }
             }
         }
@@ -1519,7 +1538,7 @@ __global__ __launch_bounds__(512, 8) void ewa_periodic_rows_kernel(const Periodi
     const int i0 = tile_x * Cfg::kTileCols;
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
-    if (a.frame_flags && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when) return;  // float planes: the other launch's frame
+    if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
 
     {
         const int gx0 = a.min_sx + i0;
@@ -1548,7 +1567,7 @@ __global__ __launch_bounds__(512, 8) void ewa_periodic_rows_kernel(const Periodi
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
                 if (r < Cfg::kRows && c < Cfg::kCols)
-                    tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = to_float(staged[i][k]);
+                    tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = staged_value(a, frame, staged[i][k]);
             }
         }
     }

@@ -101,6 +101,9 @@ struct PeriodicArgs {
     // run_when.  nullptr: every frame.
     const uint32_t* frame_flags = nullptr;
     uint32_t run_when = 0;
+    // run_when == kRunAllAndFlag: the launch computes EVERY frame and sets frame_flags[frame] = 1 where it stages a non-finite
+    // sample (the trimmed launch of a float plane is its own finite-sample scan; kernel_periodic.hip staged_value)
+    static constexpr uint32_t kRunAllAndFlag = 2;
 };
 
 // Quad forms on the 8 x 8 support: per (kernel row ly, q) the taps left out per side, two bits at 2 * (2 * ly + q).  The pattern
@@ -289,6 +292,9 @@ bool periodic_supported(int fs, int px, int py, int sx, int sy);
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
 // kernel_scan.hip: flags[frame] = 1 where the frame's float source plane (w x h samples) holds an infinity or a NaN
 int launch_finite_scan(const PlaneIO& io, int w, int h, uint32_t* flags, void* stream);
+// ... the same over the samples of the plane OUTSIDE the rectangle [rx0, rx1) x [ry0, ry1) only (what a trimmed launch that flags
+// the samples it stages itself does not see: PeriodicArgs::kRunAllAndFlag)
+int launch_finite_scan_outside(const PlaneIO& io, int w, int h, int rx0, int ry0, int rx1, int ry1, uint32_t* flags, void* stream);
 
 // Compatibility modes: the summation order of the reference's SIMD paths (kernel_simdorder.hip).  order 1 = SSE4.1,
 // 2 = AVX2, 3 = AVX-512; min_val = lower clamp of float source samples of this plane.

@@ -859,13 +859,7 @@ def test_trimmed_support_of_the_periodic_kernels(gpu_pkg, O, fmt, sw, sh, tw, th
     trimming off.  All are the oracle's result."""
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
     assert f.plan_info(0).filter_size == full
-    if fmt in ("Y32", "RGBPS") and trimmed <= 6:   # float planes at 6 x 6 keep the full window by themselves (not bound by the VALU) ...
-        assert f.periodic_support(0) == full
-        f.set_kernel_mode(13)                      # ... and take the trimmed support, behind the scan, where a kernel mode forces it
-        assert f.periodic_support(0) == trimmed
-        f.set_kernel_mode(0)
-    else:
-        assert f.periodic_support(0) == trimmed
+    assert f.periodic_support(0) == trimmed
     if fmt == "YUV420P16":  # chroma sited as MPEG-2 (an eighth of a sample to the left): all 17 columns, but 16 kernel rows
         assert f.periodic_support(1) == 17
         assert f.periodic_taps(1, rows_kernel=True) <= 17 * 16 and f.periodic_taps(0, rows_kernel=True) <= 16 * 16
@@ -950,6 +944,46 @@ def test_float_planes_take_the_trimmed_support_only_where_every_sample_is_finite
             assert np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32)), f"frame {k} plane {i}: bits differ"
         if k % 3 == 1:
             assert np.isnan(want[0]).any()
+    f.close()
+
+
+@pytest.mark.parametrize("tap", [3, 4, 8])
+@pytest.mark.parametrize("mode", [2, 3, 13], ids=["window", "rows", "quad"])
+def test_one_non_finite_sample_anywhere_in_a_float_plane(gpu_pkg, O, tap, mode):
+    """The trimmed launch of a float plane is its own finite-sample scan: it flags a frame in whose tiles it stages an infinity or
+    a NaN, a small scan covers the source samples no tile stages (the rim only zero-coefficient taps and border pixels reach), and
+    flagged frames are computed again on the full window.  One frame per position of a single infinity -- every corner, the
+    first and last rows and columns and their neighbours up to a filter size in, tile seams, the middle -- between finite
+    frames: NaN footprints and bits as the oracle's, frame by frame."""
+    torch = pytest.importorskip("torch")
+    from test_framelane_pair import _run_batch
+    fmt, sw, sh, tw, th = "Y32", 150, 70, 300, 140
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    of = O.OracleFilter(ofmt, sw, sh, tw, th, tap=tap)
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, tap=tap)
+    fs = f.plan_info(0).filter_size
+    edge = list(range(0, fs + 2))
+    xs = sorted(set(edge + [sw - 1 - e for e in edge] + [63, 64, 65, 127, 128, 129, sw // 2]))
+    ys = sorted(set(edge + [sh - 1 - e for e in edge] + [sh // 2]))
+    spots = [(ys[i % len(ys)], x) for i, x in enumerate(xs)] + [(y, xs[(3 * i) % len(xs)]) for i, y in enumerate(ys)] + \
+            [(0, 0), (0, sw - 1), (sh - 1, 0), (sh - 1, sw - 1)]
+    rng = np.random.default_rng(23)
+    srcs, marks = [], []
+    for k, (y, x) in enumerate(spots):
+        src = [(rng.standard_normal((sh, sw)) * 0.7).astype(np.float32)]
+        if k % 4 != 3:     # (every fourth frame stays finite)
+            src[0][y, x] = (np.inf, -np.inf, np.nan)[k % 3]
+            marks.append(k)
+        srcs.append(src)
+    got = _run_batch(torch, gpu_pkg, f, gfmt, srcs, len(srcs), mode)
+    for k in range(len(srcs)):
+        want = of.get_frame(srcs[k], threads=8)
+        w, h = f.out_dims()[0]
+        a, b = got[k][0][:h, :w], want[0][:h, :w]
+        na, nb = np.isnan(a), np.isnan(b)
+        assert np.array_equal(na, nb), f"frame {k}, sample {spots[k]}: NaN footprint differs ({int(na.sum())} vs {int(nb.sum())})"
+        assert np.array_equal(a[~na].view(np.uint32), b[~nb].view(np.uint32)), f"frame {k}, sample {spots[k]}: bits differ"
+    assert any(np.isnan(of.get_frame(srcs[k], threads=8)[0]).any() for k in marks[:3])
     f.close()
 
 
