@@ -20,14 +20,25 @@ constexpr uint32_t kRunAllAndFlag = PeriodicArgs::kRunAllAndFlag;
 __device__ __forceinline__ bool skips_frame(const PeriodicArgs& a, size_t frame) {
     return a.frame_flags && a.run_when != kRunAllAndFlag && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when;
 }
+// Per thread and tile: did an exponent of all ones (an infinity or a NaN) pass through the staging registers?  Declared beside
+// the staging registers; its destructor, at the end of the staging block, sets the frame's flag.  Integer planes: nothing.
 template <typename T>
-__device__ __forceinline__ float staged_value(const PeriodicArgs& a, size_t frame, T v) {
-    if constexpr (std::is_same_v<T, float>) {
-        if (a.run_when == kRunAllAndFlag && (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) == 0x7f800000u)
-            const_cast<uint32_t*>(a.frame_flags)[frame] = 1u;  // (every writer writes 1)
+struct NonFinite {
+    const PeriodicArgs& a;
+    const size_t frame;
+    uint32_t acc = 0;
+    __device__ __forceinline__ NonFinite(const PeriodicArgs& a_, size_t frame_) : a(a_), frame(frame_) {}
+    __device__ __forceinline__ float take(T v) {
+        // (exponent 0xff: the biased field plus one carries into the sign bit)
+        if constexpr (std::is_same_v<T, float>) acc |= (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) + 0x00800000u;
+        return to_float(v);
     }
-    return to_float(v);
-}
+    __device__ __forceinline__ ~NonFinite() {
+        if constexpr (std::is_same_v<T, float>) {
+            if (a.run_when == kRunAllAndFlag && (acc & 0x80000000u)) const_cast<uint32_t*>(a.frame_flags)[frame] = 1u;  // (every writer writes 1)
+        }
+    }
+};
 
 
 // ------------------------------------------------------------------------------------------------
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
         constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
         constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + 4 * i;
@@ -101,7 +113,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
             }
         }
     }
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
         constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
         constexpr int kColsPerLane = (Cfg::kSrcCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + 4 * i;
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256) void ewa_periodic_pk_kernel(const PeriodicArgs
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
                 if (r < Cfg::kLdsRows && c < Cfg::kSrcCols) {
-                    const float v = staged_value(a, frame, staged[i][k]);
+                    const float v = nonfinite.take(staged[i][k]);
                     if (c < Cfg::kPairsPerRow) trow[2 * c] = v;        // first element of pair c
                     if (c >= 64) trow[2 * (c - 64) + 1] = v;           // second element of pair c - 64
                 }
@@ -563,6 +576,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const Periodi
         constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
         constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + 4 * i;
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad_kernel(const Periodi
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
             }
         }
     }
@@ -654,6 +668,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
         constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
         constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + 4 * i;
@@ -672,7 +687,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad9_kernel(const Period
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
             }
         }
     }
@@ -899,6 +914,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const Period
         constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
         constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + 4 * i;
@@ -917,7 +933,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad8_kernel(const Period
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
             }
         }
     }
@@ -1163,6 +1179,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
         constexpr int kRowsPerWave = (Cfg::kLdsRows + 3) / 4;
         constexpr int kColsPerLane = (Cfg::kLdsCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + 4 * i;
@@ -1181,7 +1198,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
 #pragma unroll
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
-                if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
+                if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
             }
         }
     }
@@ -1339,6 +1356,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             T staged[kHalf][kColsPerLane];
+            NonFinite<T> nonfinite(a, frame);
 #pragma unroll
             for (int i = 0; i < kHalf; ++i) {
                 int gy = gy0 + wave + 4 * (h * kHalf + i);
@@ -1357,7 +1375,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
 #pragma unroll
                 for (int k = 0; k < kColsPerLane; ++k) {
                     const int c = lane + 64 * k;
-                    if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = staged_value(a, frame, staged[i][k]);
+                    if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
                 }
             }
         }
@@ -1548,6 +1566,7 @@ __global__ __launch_bounds__(512, 8) void ewa_periodic_rows_kernel(const Periodi
         constexpr int kRowsPerWave = (Cfg::kRows + Cfg::kWaves - 1) / Cfg::kWaves;
         constexpr int kColsPerLane = (Cfg::kCols + 63) / 64;
         T staged[kRowsPerWave][kColsPerLane];
+        NonFinite<T> nonfinite(a, frame);
 #pragma unroll
         for (int i = 0; i < kRowsPerWave; ++i) {
             int gy = gy0 + wave + Cfg::kWaves * i;
@@ -1567,7 +1586,7 @@ __global__ __launch_bounds__(512, 8) void ewa_periodic_rows_kernel(const Periodi
             for (int k = 0; k < kColsPerLane; ++k) {
                 const int c = lane + 64 * k;
                 if (r < Cfg::kRows && c < Cfg::kCols)
-                    tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = staged_value(a, frame, staged[i][k]);
+                    tile[(c % K) * Cfg::kPlaneStride + r * Cfg::kPlane + c / K] = nonfinite.take(staged[i][k]);
             }
         }
     }

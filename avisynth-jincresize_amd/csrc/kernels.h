@@ -102,7 +102,7 @@ struct PeriodicArgs {
     const uint32_t* frame_flags = nullptr;
     uint32_t run_when = 0;
     // run_when == kRunAllAndFlag: the launch computes EVERY frame and sets frame_flags[frame] = 1 where it stages a non-finite
-    // sample (the trimmed launch of a float plane is its own finite-sample scan; kernel_periodic.hip staged_value)
+    // sample (the trimmed launch of a float plane is its own finite-sample scan; kernel_periodic.hip NonFinite)
     static constexpr uint32_t kRunAllAndFlag = 2;
 };
 
