@@ -29,8 +29,10 @@ CHECKS = [
     ("kRunsFrameLaneBorderMinFrames = 32 (tap 8)", "N15T8", 32, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
     ("kQuad2x8MinWorkgroups: two periods per lane on 8 x 8", "C2T4", 9, {}, {"env": {"JINC_QUAD2X8": "0"}}, "one period per lane"),
     ("trimmed support, integer planes", "C2", 64, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
-    ("trimmed support behind the finite-sample scan (float, 8 x 8)", "C4", 16, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
-    ("no trimmed support for float planes at 6 x 6", "C2F", 64, {}, {"args": ["--kernel-mode", "13"]}, "trimmed quad form behind the scan"),
+    ("trimmed support on float planes (8 x 8)", "C4", 16, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
+    ("float planes on the 6 x 6 support (the trimmed launch its own scan)", "C2F", 64, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
+    ("float planes: no scan pass in front of the trimmed launch", "C4", 16, {}, {"env": {"JINC_FLOAT_SCAN": "1"}}, "scan pass over the source"),
+    ("kFloatTrimMinTaps = 1e9: one 1080p -> 4K float frame stays on the full window", "C2F", 1, {}, {"env": {"JINC_FLOAT_TRIM_MIN_TAPS": "0"}}, "trimmed"),
     ("rows kernel: per-row spans and row count", "C3", 32, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
     ("direct kernel's interior on the trimmed support", "D12", 128, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
     ("quad form of the periodic kernel (single frames)", "C2", 1, {}, {"args": ["--kernel-mode", "2"]}, "window kernel"),
