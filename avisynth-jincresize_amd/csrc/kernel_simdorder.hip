@@ -9,7 +9,8 @@
 // One GPU lane owns one output sample and all W partial sums of it, so the result is the reference's bit for bit
 // (checked against a scalar CPU restatement in the test suite that reproduces the 3 / 7 / 7 pixel differences the reference's opt 1 / 2 / 3
 // show against opt = 0 on 640x360 -> 1280x720).  This is the ONLY translation unit that contains fused multiply-adds
-// (explicit __builtin_fmaf; the file is still compiled with -ffp-contract=off).  Not a fast path: no LDS staging.
+// (explicit __builtin_fmaf; the file is still compiled with -ffp-contract=off).  Not a fast path: no LDS staging (the common filter sizes are unrolled, with a kernel
+// row's coefficients as 16-byte loads).
 #include "device_common.hpp"
 
 #pragma clang fp contract(off)
@@ -26,13 +27,15 @@ __device__ __forceinline__ uint32_t packus_epi16(uint32_t w) {  // the 16-bit pa
     return s < 0 ? 0u : (s > 255 ? 255u : static_cast<uint32_t>(s));
 }
 
-template <typename T, int W, bool FUSED>
+// FS: the filter size at compile time (7, 9, 13, 17: taps 3, 4, 6, 8 at >= 1x -- rows unrolled, a kernel row's coefficients as
+// 16-byte loads), or 0: any size at run time.
+template <typename T, int W, bool FUSED, int FS>
 __global__ __launch_bounds__(256) void ewa_simd_order_kernel(const DevicePlan p, const PlaneIO io, const float min_val) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= p.dst_w || y >= p.dst_h) return;
     const size_t frame = blockIdx.z;
-    const int fs = p.fs, fsp = padded_row(p.fs);
+    const int fs = FS ? FS : p.fs, fsp = padded_row(fs);
     const int rc = p.row_class[y], cc = p.col_class[x];
     int set;
     if (rc < 0)
@@ -47,24 +50,44 @@ __global__ __launch_bounds__(256) void ewa_simd_order_kernel(const DevicePlan p,
     float part[W];
 #pragma unroll
     for (int l = 0; l < W; ++l) part[l] = 0.f;
-    for (int ly = 0; ly < fs; ++ly) {
-        const T* s = reinterpret_cast<const T*>(srow);
-        for (int lx0 = 0; lx0 < fs; lx0 += W) {
+    auto tap = [&](float& sum, float v, float cv) {
+        if constexpr (std::is_same_v<T, float>) v = v > min_val ? v : min_val;  // _mm_max_ps(src, min_val)
+        if constexpr (FUSED)
+            sum = __builtin_fmaf(v, cv, sum);
+        else
+            sum = sum + v * cv;
+    };
+    if constexpr (FS != 0) {
+        constexpr int FSP = padded_row(FS);
+        for (int ly = 0; ly < FS; ++ly) {
+            const T* s = reinterpret_cast<const T*>(srow);
+            float cr[FSP];  // the kernel row's coefficients (rows are padded to multiples of 4 floats, 16-byte aligned)
 #pragma unroll
-            for (int l = 0; l < W; ++l) {
-                const int lx = lx0 + l;
-                if (lx < fs) {  // (lanes past the window multiply by the coefficient row's zero padding: no-ops)
-                    float v = to_float(s[lx]);
-                    if constexpr (std::is_same_v<T, float>) v = v > min_val ? v : min_val;  // _mm_max_ps(src, min_val)
-                    if constexpr (FUSED)
-                        part[l] = __builtin_fmaf(v, c[lx], part[l]);
-                    else
-                        part[l] = part[l] + v * c[lx];
+            for (int q = 0; q < FSP / 4; ++q) {
+                const float4 v4 = *reinterpret_cast<const float4*>(c + 4 * q);
+                cr[4 * q] = v4.x, cr[4 * q + 1] = v4.y, cr[4 * q + 2] = v4.z, cr[4 * q + 3] = v4.w;
+            }
+            T sv[FS];
+#pragma unroll
+            for (int lx = 0; lx < FS; ++lx) sv[lx] = s[lx];
+#pragma unroll
+            for (int lx = 0; lx < FS; ++lx) tap(part[lx % W], to_float(sv[lx]), cr[lx]);  // (lanes past the window: zero padding, no-ops)
+            c += FSP;
+            srow += io.src_pitch;
+        }
+    } else {
+        for (int ly = 0; ly < fs; ++ly) {
+            const T* s = reinterpret_cast<const T*>(srow);
+            for (int lx0 = 0; lx0 < fs; lx0 += W) {
+#pragma unroll
+                for (int l = 0; l < W; ++l) {
+                    const int lx = lx0 + l;
+                    if (lx < fs) tap(part[l], to_float(s[lx]), c[lx]);  // (lanes past the window multiply by the row's zero padding: no-ops)
                 }
             }
+            c += fsp;
+            srow += io.src_pitch;
         }
-        c += fsp;
-        srow += io.src_pitch;
     }
     float q[8], h[4];
 #pragma unroll
@@ -94,11 +117,20 @@ __global__ __launch_bounds__(256) void ewa_simd_order_kernel(const DevicePlan p,
 template <typename T>
 int launch_so_t(const DevicePlan& p, const PlaneIO& io, int order, float min_val, hipStream_t s) {
     const dim3 grid((p.dst_w + 63) / 64, (p.dst_h + 3) / 4, io.nframes), block(256);
-    switch (order) {
-        case 1: hipLaunchKernelGGL((ewa_simd_order_kernel<T, 4, false>), grid, block, 0, s, p, io, min_val); break;
-        case 2: hipLaunchKernelGGL((ewa_simd_order_kernel<T, 8, true>), grid, block, 0, s, p, io, min_val); break;
-        default: hipLaunchKernelGGL((ewa_simd_order_kernel<T, 16, true>), grid, block, 0, s, p, io, min_val); break;
+#define JINC_SO_LAUNCH(FS)                                                                                                       \
+    switch (order) {                                                                                                             \
+        case 1: hipLaunchKernelGGL((ewa_simd_order_kernel<T, 4, false, FS>), grid, block, 0, s, p, io, min_val); break;          \
+        case 2: hipLaunchKernelGGL((ewa_simd_order_kernel<T, 8, true, FS>), grid, block, 0, s, p, io, min_val); break;           \
+        default: hipLaunchKernelGGL((ewa_simd_order_kernel<T, 16, true, FS>), grid, block, 0, s, p, io, min_val); break;         \
     }
+    switch (p.fs) {
+        case 7: JINC_SO_LAUNCH(7) break;
+        case 9: JINC_SO_LAUNCH(9) break;
+        case 13: JINC_SO_LAUNCH(13) break;
+        case 17: JINC_SO_LAUNCH(17) break;
+        default: JINC_SO_LAUNCH(0) break;
+    }
+#undef JINC_SO_LAUNCH
     return static_cast<int>(hipGetLastError());
 }
 
