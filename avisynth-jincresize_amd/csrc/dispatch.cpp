@@ -23,14 +23,16 @@ struct Rules {
     // drifting fs-9 / fs-7 plans with a source step of 2 from 48 / 64
     static constexpr int kFrameLaneMinFramesBigFs = 24;
     // Groups of fewer than 64 frames on the frame-lane kernel's sub-group form (profiles/round4/fl_sub_ab.log, fl_small_ab.log):
-    // 16 / 8 / 4 / 2 sub-groups per wave (4 / 8 / 16 / 32 frames per workgroup) up to these frame counts, the 64-frame form
-    // above (1.37x at 48 frames: 267 against 244 Gpix/s; 5/6 down-scale 216 : 217; 1.5x with tap 4 184 : 191).  The form
-    // passes the gather kernel at 3 frames (1.37x: 1 frame 21 against 32 Gpix/s, 2: 41 : 43, 3: 58 : 48, 4: 72 : 51, 8: 128 : 57).
+    // 16 / 8 / 4 sub-groups per wave (4 / 8 / 16 frames per workgroup) up to these frame counts -- two sub-groups (32 frames) are
+    // never ahead of four (1.37x at 32 frames 298 : 295 Gpix/s, at 24 frames 222 : 229; 5/6 at 32 frames 200 : 226) -- and the
+    // 64-frame form above 48 (1.37x at 48 frames: 267 against 300 on three groups of 16; 5/6 216 : 236; 1.5x with tap 4 184 : 203;
+    // at 56 frames four groups of 16 cost what 64 frames cost).  The form passes the gather kernel at 2 frames (1.37x: 1 frame 32.2
+    // against 31.3 Gpix/s, 2: 60 : 42, 3: 82 : 48, 4: 98 : 51, 8: 169 : 57, 12: 206 : 60).
     static constexpr int kFlSub16MaxFrames = 4;
     static constexpr int kFlSub8MaxFrames = 8;
-    static constexpr int kFlSub4MaxFrames = 16;
-    static constexpr int kFlSub2MaxFrames = 32;
-    static constexpr int kFlSubMinFrames = 3;
+    static constexpr int kFlSub4MaxFrames = 48;
+    static constexpr int kFlSub2MaxFrames = 0;   // (two sub-groups: kernel mode 16 and the JINC_FL_SUB knob only)
+    static constexpr int kFlSubMinFrames = 2;
     // (against the runs form of the direct kernel -- drifting plans with fs >= 9 -- the frame-lane kernel is never chosen:
     // round3/runs_vs_auto.txt, 128 frames, border frame on the frame-lane kernel: DVD -> 1080p with tap 4 169 against 159 Gpix/s,
     // 5/2 with tap 6 135.5 against 124.7, 1.5x with tap 8 at 256 frames 88.9 against 79.7, with tap 4 265 against 255)

@@ -182,25 +182,11 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_sub_kernel(const FrameLa
     FlTile t;
     if (!fl_locate<FPG>(a, FS, t)) return;  // whole block, before any barrier
     fl_tables(a, t, cs, rs, sets);
-    __syncthreads();
     const int nstrips = t.by1 - t.by0 + 1, npix = t.bx1 - t.bx0 + 1;
     const int nsg = (nstrips + G - 1) / G;  // strip groups: G output rows per wave and pass
-    // Coefficient sets of a strip group, requested one group ahead, one cache line per lane (see ewa_framelane_kernel: for a
-    // plan without phase structure every set is used once per workgroup and comes from beyond the L2).
-    auto prefetch_group = [&](int sg2) -> uint32_t {
-        uint32_t keep = 0;
-        if (sg2 < nsg) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int set = sets[min(sg2 * G + g, nstrips - 1) * kFrameLaneMaxTile + min(lane & 31, npix - 1)];
-                const char* sp = reinterpret_cast<const char*>(p.coeffs) + static_cast<size_t>(static_cast<uint32_t>(set) * kSetBytes);
-                for (uint32_t off = static_cast<uint32_t>(lane >> 5) * 64u; off < kSetBytes + 60u; off += 128u)
-                    keep |= *reinterpret_cast<const uint32_t*>(sp + (off < kSetBytes - 4u ? off : kSetBytes - 4u));
-            }
-        }
-        return keep;
-    };
-    uint32_t pf_keep = prefetch_group(wave);  // the wave's first group: in flight during the staging below
+    // (No L2 prefetch of the next strip group's sets, as the 64-frame forms have it: the sets already come through the vector-memory
+    // path, which is the busy one here -- 55 % of the kernel's cycles with the prefetch, whose requests doubled the traffic for an L2
+    // hit rate that is 91 % anyway; without it 1.37x at 16 frames 204 -> 247 Gpix/s, 8 frames 128 -> 168; round4/fl_sub_prefetch_ab.log.)
     const int thp = t.th | 1;  // column-major positions, odd column pitch (as ewa_framelane_win_kernel)
     constexpr int UF = FPG >= 16 ? FPG / 8 : 1;  // frames a wave of an 8-wave workgroup owns in a full group
     fl_stage<T, PS, UF, 16 / UF>(a, t, tile, 1, thp, lane, wave, nwaves);
@@ -215,8 +201,6 @@ __global__ __launch_bounds__(512, 4) void ewa_framelane_sub_kernel(const FrameLa
     const char* cbase = reinterpret_cast<const char*>(p.coeffs) + 16 * (lane & (SubSet<FS, ROW>::LPC - 1));  // the lane's part of a set: SubSet
     const bool vec_ok = (a.vec_store_ok & 1) && ((t.bx0 & 3) == 0);
     for (int sg = wave; sg < nsg; sg += nwaves) {
-        asm volatile("" ::"v"(pf_keep));
-        pf_keep = prefetch_group(sg + nwaves);
         const int r = min(sg * G + grp, nstrips - 1);
         const bool lane_on = frame_on && sg * G + grp < nstrips;
         const int sy = rs[r];

@@ -16,11 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # (rule, configuration, frames per call, {env / args of the rule's choice}, {env / args of the alternative}, what the alternative is)
 CHECKS = [
-    ("kFlSubMinFrames = 3: sub-group form from 3 frames", "A137", 3, {}, {"args": ["--kernel-mode", "1"]}, "gather kernel"),
-    ("kFlSubMinFrames = 3: gather kernel below", "A137", 2, {}, {"args": ["--kernel-mode", "16"]}, "sub-group form"),
-    ("kFlSub4MaxFrames = 16 -> 4 sub-groups at 16 frames", "A137", 16, {}, {"env": {"JINC_FL_SUB": "2"}}, "2 sub-groups"),
-    ("kFlSub2MaxFrames = 32 -> 2 sub-groups at 32 frames", "A137", 32, {}, {"env": {"JINC_FL_SUB": "4"}}, "4 sub-groups"),
-    ("kFlSub2MaxFrames = 32: 64-frame form above", "A137", 40, {}, {"env": {"JINC_FL_SUB": "4"}}, "4 sub-groups"),
+    ("kFlSubMinFrames = 2: sub-group form from 2 frames", "A137", 2, {}, {"args": ["--kernel-mode", "1"]}, "gather kernel"),
+    ("kFlSubMinFrames = 2: gather kernel for one frame", "A137", 1, {}, {"args": ["--kernel-mode", "16"]}, "sub-group form"),
+    ("kFlSub4MaxFrames = 48 -> 4 sub-groups at 16 frames", "A137", 16, {}, {"env": {"JINC_FL_SUB": "2"}}, "2 sub-groups"),
+    ("kFlSub4MaxFrames = 48 -> 4 sub-groups at 32 frames", "A137", 32, {}, {"env": {"JINC_FL_SUB": "2"}}, "2 sub-groups"),
+    ("kFlSub4MaxFrames = 48: sub-groups at 48 frames", "A137", 48, {}, {"env": {"JINC_FL_SUB": "0"}}, "64-frame form"),
+    ("kFlSub4MaxFrames = 48: 64-frame form above", "A137", 56, {}, {"env": {"JINC_FL_SUB": "4"}}, "4 sub-groups"),
     ("sub-group form at all (16 frames)", "D169", 16, {}, {"env": {"JINC_FL_SUB": "0"}}, "64-frame form"),
     ("frame-pair form for whole groups of 128", "A137", 128, {}, {"args": ["--kernel-mode", "11"]}, "64-frame form"),
     ("kFlColsMinFrames = 16: border columns on the frame-lane kernel", "C2", 16, {}, {"env": {"JINC_FL_COLS_FRAMES": "0"}}, "column-strip kernel"),

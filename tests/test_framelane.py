@@ -85,7 +85,7 @@ def test_batches_of_frames(gpu_pkg, O, case):
         stream.synchronize()
         # (last_kernel names the kernel of the batch's last part: beyond whole groups of 128 frames a remainder of fewer than 16
         # frames is a call of its own under the normal rules -- for these plans the gather kernel)
-        small_rest = n > 128 and 0 < n % 128 < 3   # (automatic mode: n >= 24; from 3 frames the sub-group form of the frame-lane kernel)
+        small_rest = n > 128 and 0 < n % 128 < 2   # (automatic mode: n >= 24; from 2 frames the sub-group form of the frame-lane kernel)
         assert f.last_kernel(0).startswith("ewa_gather" if small_rest else "ewa_framelane"), (n, f.last_kernel(0))
         for k in range(n):
             got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]

@@ -1,7 +1,7 @@
 """GPU parity tests of the frame-lane kernel's sub-group form (kernel_framelane_sub.hip: groups of fewer than 64 frames -- a
 wave is 4 / 8 / 16 / 32 frames x 16 / 8 / 4 / 2 output rows of the tile; the lanes of a sub-group share ONE copy of the pixel's
 coefficient set, read through DPP operands).  Through the C ABI, bit-exact against the CPU oracle: every frame of device-resident
-batches in every fill state of the sub-groups (kernel mode 16 = forced), the automatic choice for batches of 3 .. 32 frames and
+batches in every fill state of the sub-groups (kernel mode 16 = forced), the automatic choice for batches of 2 .. 48 frames and
 for what a batch leaves beyond whole groups of 64, unaligned destinations."""
 import numpy as np
 import pytest
@@ -46,13 +46,14 @@ def test_groups_of_fewer_than_64_frames(gpu_pkg, O, case):
     f.close()
 
 
-@pytest.mark.parametrize("n,kernel", [(2, "ewa_gather_kernel"), (3, "ewa_framelane_sub_kernel"), (7, "ewa_framelane_sub_kernel"),
-                                      (16, "ewa_framelane_sub_kernel"), (24, "ewa_framelane_sub_kernel"), (32, "ewa_framelane_sub_kernel"),
-                                      (33, "ewa_framelane_win"), (64, "ewa_framelane_win"), (70, "ewa_framelane_win")])
+@pytest.mark.parametrize("n,kernel", [(1, "ewa_gather_kernel"), (2, "ewa_framelane_sub_kernel"), (3, "ewa_framelane_sub_kernel"), (7, "ewa_framelane_sub_kernel"),
+                                      (16, "ewa_framelane_sub_kernel"), (24, "ewa_framelane_sub_kernel"), (33, "ewa_framelane_sub_kernel"),
+                                      (48, "ewa_framelane_sub_kernel"), (49, "ewa_framelane_win"), (64, "ewa_framelane_win"),
+                                      (70, "ewa_framelane_win")])
 def test_automatic_choice_by_batch_size(gpu_pkg, O, n, kernel):
-    """What a host at look-ahead 32 hands over (groups of 16) and everything else from 3 to 32 frames of a plan without phase
-    structure takes the sub-group form by itself; so does what a batch leaves beyond whole groups of 64 (70 = 64 + 6: last_kernel
-    names the bulk)."""
+    """What a host at look-ahead 32 hands over (groups of 16) and everything else from 2 to 48 frames of a plan without phase
+    structure takes the sub-group form by itself (groups of 16 frames x 4 output rows from 9 frames on); so does what a batch
+    leaves beyond whole groups of 64 (70 = 64 + 6: last_kernel names the bulk)."""
     torch = pytest.importorskip("torch")
     fmt, sw, sh, tw, th = "Y8", 160, 90, 219, 123
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)

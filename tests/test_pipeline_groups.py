@@ -116,7 +116,7 @@ def test_submit_rejects_bad_planes_without_disturbing_the_group(gpu_pkg, O):
 @pytest.mark.parametrize("nframes", [129, 140, 256 + 17])
 def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframes):
     """128 k + r frames = whole groups of 128 on the frame-pair form + a call of r frames under the normal rules
-    (r < 3: the single-frame kernel of the plan; up to 32: the frame-lane kernel's sub-group form -- never a 64-lane launch for
+    (r < 2: the single-frame kernel of the plan; up to 48: the frame-lane kernel's sub-group form -- never a 64-lane launch for
     a few frames); results per frame unchanged."""
     torch = pytest.importorskip("torch")
     fmt, sw, sh, tw, th = "Y8", 160, 90, 219, 123
@@ -129,8 +129,8 @@ def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframe
     f.process_device([src.data_ptr()], [256], [sh * 256], [dst.data_ptr()], [256], [th * 256], nframes)
     torch.cuda.synchronize()
     r = nframes % 128
-    # (r = 1: gather kernel; 3 .. 32: the frame-lane kernel's sub-group form -- kernel_framelane_sub.hip)
-    assert f.last_kernel(0) == ("ewa_gather_kernel" if r < 3 else "ewa_framelane_sub_kernel"), (r, f.last_kernel(0))
+    # (r = 1: gather kernel; 2 .. 48: the frame-lane kernel's sub-group form -- kernel_framelane_sub.hip)
+    assert f.last_kernel(0) == ("ewa_gather_kernel" if r < 2 else "ewa_framelane_sub_kernel"), (r, f.last_kernel(0))
     out = dst.cpu().numpy()
     for k in (0, 127, 128, nframes - 1, nframes // 2):
         want = of.get_frame([host[k]])
