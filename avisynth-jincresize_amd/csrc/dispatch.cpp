@@ -27,7 +27,8 @@ struct Rules {
     // never ahead of four (1.37x at 32 frames 298 : 295 Gpix/s, at 24 frames 222 : 229; 5/6 at 32 frames 200 : 226) -- and the
     // 64-frame form above 48 (1.37x at 48 frames: 267 against 300 on three groups of 16; 5/6 216 : 236; 1.5x with tap 4 184 : 203;
     // at 56 frames four groups of 16 cost what 64 frames cost).  The form passes the gather kernel at 2 frames (1.37x: 1 frame 32.2
-    // against 31.3 Gpix/s, 2: 60 : 42, 3: 82 : 48, 4: 98 : 51, 8: 169 : 57, 12: 206 : 60).
+    // against 31.3 Gpix/s -- level, and a one-frame call keeps the plane pairs of launch_plane --, 2: 60 : 42, 3: 82 : 48, 4: 98 : 51,
+    // 8: 169 : 57, 12: 206 : 60).
     static constexpr int kFlSub16MaxFrames = 4;
     static constexpr int kFlSub8MaxFrames = 8;
     static constexpr int kFlSub4MaxFrames = 48;
