@@ -1,5 +1,11 @@
 """Committed golden vectors (tests/golden/vectors.npz, made by tests/golden/make_golden.py).
-CPU: the oracle still reproduces them.  GPU: the HIP path reproduces them through the C ABI."""
+CPU: the oracle still reproduces them.  GPU: the HIP path reproduces them through the C ABI.
+
+What these vectors are and are not: the ORACLE wrote them (make_golden.py runs oracle/, nothing of the reference: it cannot be
+built in this image), so the GPU half of this file is the oracle comparison of tests/test_gpu_parity.py under another name -- a
+regression net that pins today's oracle output against tomorrow's edits of the oracle itself, not a pin of the oracle to the
+reference.  The only reference-derived figures in the repository are the crc32 / sha prefixes and table statistics of
+tests/golden/kat.json (recorded by the survey from a build of the reference; see DESIGN.md section 2, "parity unpinned")."""
 import json
 import os
 
