@@ -16,6 +16,7 @@ The directory name contains a hyphen, so load it with ``importlib`` (see ``__gra
 from __future__ import annotations
 
 import ctypes as C
+import enum
 import os
 import subprocess
 from dataclasses import dataclass, field
@@ -83,7 +84,8 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
-           "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error"]
+           "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error",
+           "jinc_filter_last_instance", "jinc_debug_last_instance", "jinc_debug_set_knob", "jinc_debug_clear_knob", "jinc_debug_get_knob", "jinc_debug_knob_name"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -160,6 +162,14 @@ def lib():
         L.jinc_batch_free.restype = None
         L.jinc_batch_free.argtypes = [C.c_void_p]
         L.jinc_batch_last_error.restype = C.c_char_p
+        L.jinc_filter_last_instance.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_filter_last_instance.restype = C.c_char_p
+        L.jinc_debug_last_instance.restype = C.c_char_p
+        L.jinc_debug_set_knob.argtypes = [C.c_int, C.c_double]
+        L.jinc_debug_clear_knob.argtypes = [C.c_int]
+        L.jinc_debug_get_knob.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        L.jinc_debug_knob_name.argtypes = [C.c_int]
+        L.jinc_debug_knob_name.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -218,6 +228,100 @@ def last_call() -> Tuple[str, int]:
     n = C.c_int()
     name = lib().jinc_debug_last_call(C.byref(n))
     return (name or b"").decode(), n.value
+
+
+class KernelMode(enum.IntEnum):
+    """enum jinc_kernel_mode of include/jincresize_hip_test.h."""
+    AUTO = 0
+    GATHER = 1
+    PERIODIC = 2
+    ROWS = 3
+    WINDOW_HALF_TILES = 4
+    PACKED_RG4 = 5
+    PACKED_RG8 = 6
+    QUASI = 7
+    QUASI_WATERFALL = 8
+    DIRECT = 9
+    QUASI_LANE = 10
+    FRAMELANE = 11
+    FRAMELANE_PAIR = 12
+    QUAD = 13
+    RUNS = 14
+    FULL_WINDOW = 15
+    FRAMELANE_SUB = 16
+
+
+def knob_ids() -> dict:
+    """{lower-case knob name: id} as the loaded library lists them (enum jinc_knob of the test header)."""
+    out, k = {}, 0
+    while True:
+        name = lib().jinc_debug_knob_name(k)
+        if not name:
+            return out
+        out[name.decode()] = k
+        k += 1
+
+
+def set_knob(name: str, value: float) -> None:
+    """Process-wide A/B / tuning knob (test header): `name` as in knob_ids(), e.g. "quad_rg"."""
+    ids = knob_ids()
+    if name.lower() not in ids:
+        raise KeyError(f"no such knob: {name}")
+    rc = lib().jinc_debug_set_knob(ids[name.lower()], float(value))
+    if rc != 0:
+        raise JincError(rc, lib().jinc_last_error().decode())
+
+
+def clear_knob(name: Optional[str] = None) -> None:
+    """One knob (or, without a name, every knob) back to unset."""
+    rc = lib().jinc_debug_clear_knob(-1 if name is None else knob_ids()[name.lower()])
+    if rc != 0:
+        raise JincError(rc, lib().jinc_last_error().decode())
+
+
+def get_knob(name: str) -> Optional[float]:
+    v = C.c_double()
+    return v.value if lib().jinc_debug_get_knob(knob_ids()[name.lower()], C.byref(v)) == 1 else None
+
+
+class knobs:
+    """`with knobs(quad_rg=8): ...` sets knobs for a block and restores what was there before."""
+
+    def __init__(self, **kv):
+        self._kv = kv
+        self._old = {}
+
+    def __enter__(self):
+        for k, v in self._kv.items():
+            self._old[k] = get_knob(k)
+            set_knob(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._old.items():
+            clear_knob(k) if v is None else set_knob(k, v)
+        return False
+
+
+# JINC_<NAME> environment variables the profiles/ scripts and recheck_rules.py pass: translated into knobs by bench.py (the
+# library itself never reads the environment for them).
+def apply_env_knobs(environ=None) -> dict:
+    environ = os.environ if environ is None else environ
+    applied = {}
+    for name in knob_ids():
+        e = environ.get("JINC_" + name.upper())
+        if e is None or e == "":
+            continue
+        if name == "pipeline_skip":
+            e = {"h2d": "1", "kernels": "2"}.get(e, e)
+        set_knob(name, float(e))
+        applied[name] = float(e)
+    return applied
+
+
+def last_instance() -> str:
+    """Full instantiation of the interior kernel (table 0) of the most recent kernel call of any filter instance in this process."""
+    return (lib().jinc_debug_last_instance() or b"").decode()
 
 
 def set_direct_shape(shape: int) -> None:
@@ -525,6 +629,10 @@ class Filter:
     def last_kernel(self, table: int = 0) -> str:
         """Interior kernel of the most recent frame call (depends on the batch size)."""
         return lib().jinc_filter_last_kernel(self._h, int(table)).decode()
+
+    def last_instance(self, table: int = 0) -> str:
+        """... with its template arguments, as rocprofv3 names it (the periodic family; the plain name otherwise)."""
+        return lib().jinc_filter_last_instance(self._h, int(table)).decode()
 
     def set_border_strips(self, mode) -> None:
         """Border frame of exactly periodic plans: -1 by call size (default), True/1 strip kernels, 2 rows only, False/0 gather kernel."""

@@ -1,6 +1,7 @@
 // device_plan.cpp -- device-resident plans of a filter instance: upload of the compact plan, and the launch planning
 // for every kernel family (which kernel computes which part of the output plane).  See DESIGN.md section 4.
 #include "filter_internal.h"
+#include "knobs.h"
 
 namespace jinc {
 namespace host {
@@ -124,11 +125,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     t.trim_nx = 0;
     t.trim_needs_finite = !integer_samples;  // float planes: only frames without infinities / NaNs (dispatch.cpp, kernel_scan.hip)
     if (!t.use_periodic) return;
-    static const bool off = [] {
-        const char* e = std::getenv("JINC_TRIM");  // A/B knob: JINC_TRIM=0 keeps the full window
-        return e && std::atoi(e) == 0;
-    }();
-    if (off) return;
+    if (!knobs::flag(JINC_KNOB_TRIM, true)) return;  // A/B knob: TRIM = 0 keeps the full window
     const jinc::PeriodicArgs& pa = t.periodic;
     const int fs = p.fs, nphase = pa.px * pa.py;
     int r0 = fs, r1 = -1, c0 = fs, c1 = -1;
@@ -231,10 +228,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * n * n);
         attach_quad(t, t.periodic_trim, n, sets);
         if (n == 6 && t.periodic_trim.quad) {  // kernel rows whose first and last tap are zero for both p of a q: the chord in the box's edge rows
-            static const bool off = [] {
-                const char* e = std::getenv("JINC_QUAD_INNER");  // A/B knob
-                return e && std::atoi(e) == 0;
-            }();
+            const bool off = !knobs::flag(JINC_KNOB_QUAD_INNER, true);  // A/B knob
             uint32_t inner = 0;
             for (int q = 0; q < 2 && !off; ++q)
                 for (int ly = 0; ly < n; ++ly) {
@@ -248,10 +242,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
             t.periodic_trim.quad_inner = inner;
         }
         if (n == 8 && t.periodic_trim.quad) {  // 8 x 8 support: taps every (kernel row, q) leaves out per side for both p
-            static const bool off = [] {
-                const char* e = std::getenv("JINC_QUAD_INNER");
-                return e && std::atoi(e) == 0;
-            }();
+            const bool off = !knobs::flag(JINC_KNOB_QUAD_INNER, true);
             uint32_t tr8 = 0;
             for (int q = 0; q < 2 && !off; ++q)
                 for (int ly = 0; ly < n; ++ly) {
@@ -555,11 +546,7 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
 void trim_direct(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
     t.direct_trim_fs = 0;
     if (!t.use_direct || !integer_samples) return;
-    static const bool off = [] {
-        const char* e = std::getenv("JINC_TRIM");
-        return e && std::atoi(e) == 0;
-    }();
-    if (off) return;
+    if (!knobs::flag(JINC_KNOB_TRIM, true)) return;
     const jinc::DirectArgs& da = t.direct;
     const int fs = p.fs, nphase = da.px * da.py;
     int r0 = fs, r1 = -1, c0 = fs, c1 = -1;

@@ -4,8 +4,10 @@
 // launches of one plane under a Choice) -> enqueue_run (batch split, fork / join of the side stream, the plane loop).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "filter_internal.h"
+#include "knobs.h"
 
 namespace jinc {
 namespace host {
@@ -133,40 +135,17 @@ bool plane_pair(const void* const src[4], const int src_pitch[4], void* const ds
 }
 
 // Frames per call from which the border frame of a runs-form plan goes to the frame-lane kernel; A/B knob
-// JINC_RUNS_FL_BORDER_FRAMES (0: never); read once.
+// RUNS_FL_BORDER_FRAMES (0: never).
 int runs_fl_border_min_frames(bool sub_form) {
-    static const int knob = [] {
-        const char* e = std::getenv("JINC_RUNS_FL_BORDER_FRAMES");
-        return e ? std::atoi(e) : -1;
-    }();
+    const int knob = knobs::geti(JINC_KNOB_RUNS_FL_BORDER_FRAMES, -1);
     if (knob >= 0) return knob == 0 ? INT32_MAX : knob;
     return sub_form ? Rules::kRunsFrameLaneBorderMinFramesSub : Rules::kRunsFrameLaneBorderMinFrames;
 }
 
-bool plane_fork_enabled() {  // A/B knob JINC_PLANE_FORK (default: on); read once
-    static const bool v = [] {
-        const char* e = std::getenv("JINC_PLANE_FORK");
-        return !e || std::atoi(e) != 0;
-    }();
-    return v;
-}
-
-bool plane_pair_enabled() {  // A/B knob JINC_PLANE_PAIR (default: on); read once
-    static const bool v = [] {
-        const char* e = std::getenv("JINC_PLANE_PAIR");
-        return !e || std::atoi(e) != 0;
-    }();
-    return v;
-}
-
-// A/B knob JINC_QUASI_SPLIT: workgroups per tile of the quasi-periodic kernel (0 / 1: no split); read once.
-int quasi_split_knob() {
-    static const int v = [] {
-        const char* e = std::getenv("JINC_QUASI_SPLIT");
-        return e ? std::atoi(e) : -1;
-    }();
-    return v;
-}
+bool plane_fork_enabled() { return knobs::flag(JINC_KNOB_PLANE_FORK, true); }  // A/B knob PLANE_FORK (default: on)
+bool plane_pair_enabled() { return knobs::flag(JINC_KNOB_PLANE_PAIR, true); }  // A/B knob PLANE_PAIR (default: on)
+// A/B knob QUASI_SPLIT: workgroups per tile of the quasi-periodic kernel (0 / 1: no split)
+int quasi_split_knob() { return knobs::geti(JINC_KNOB_QUASI_SPLIT, -1); }
 }  // namespace
 
 namespace {
@@ -176,6 +155,8 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
 // for callers that cannot reach the filter handle (the plugin shell's instances)
 std::atomic<const char*> g_last_interior_kernel{""};
 std::atomic<int> g_last_call_frames{0};
+std::mutex g_last_instance_mutex;
+std::string g_last_instance;  // DeviceTable::last_instance of table 0, same call
 }
 
 void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], const size_t src_fs[4],
@@ -184,10 +165,18 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
     enqueue_run(f, src, src_pitch, src_fs, dst, dst_pitch, dst_fs, nframes, stream, true);
     g_last_interior_kernel.store(f.tables[0].last_kernel, std::memory_order_relaxed);
     g_last_call_frames.store(nframes, std::memory_order_relaxed);
+    std::lock_guard<std::mutex> lock(g_last_instance_mutex);
+    g_last_instance = f.tables[0].last_instance;
 }
 
 const char* last_interior_kernel_in_process() { return g_last_interior_kernel.load(std::memory_order_relaxed); }
 int last_call_frames_in_process() { return g_last_call_frames.load(std::memory_order_relaxed); }
+const char* last_interior_instance_in_process() {
+    thread_local std::string copy;
+    std::lock_guard<std::mutex> lock(g_last_instance_mutex);
+    copy = g_last_instance;
+    return copy.c_str();
+}
 
 namespace {
 // What one call launches for each plane: the rules of the automatic kernel choice (and the forced kernel modes), evaluated for the
@@ -290,13 +279,10 @@ struct Choice {
         return !wants_direct(t, i);
     }
     // Sub-groups per wave for `n` < 64 frames on the frame-lane kernel (kernel_framelane_sub.hip: a wave's lanes are n frames x
-    // several output rows instead of 64 frames), or 0: the 64-frame form.  Kernel mode 16 forces the form, JINC_FL_SUB is the
+    // several output rows instead of 64 frames), or 0: the 64-frame form.  Kernel mode 16 forces the form, FL_SUB is the
     // A/B knob (0: never, 2 / 4 / 8 / 16: that many sub-groups).
     int fl_subgroups(const DeviceTable& t, int n) const {
-        static const int forced = [] {
-            const char* e = std::getenv("JINC_FL_SUB");
-            return e ? std::atoi(e) : -1;
-        }();
+        const int forced = knobs::geti(JINC_KNOB_FL_SUB, -1);
         if (forced == 0 || t.fl_whole.variant == 1) return 0;
         if (forced < 0 && (n >= 64 || f.kernel_mode == 11)) return 0;  // (the knob: batches of any size and kernel mode, for A/B)
         int g = 0;
@@ -328,14 +314,10 @@ struct Choice {
         // flag set, a scan of the plane's rim and a second launch that returns at once: from kFloatTrimMinTaps taps per plane and call.
         // With a scan PASS in front, round 4's first form, the 6 x 6 support gained nothing on float planes: C2's geometry on float
         // RGB 174.2 against 174.5 Gpix/s; without it 174 -> 207, round4/float_trim_ab.log.)
-        static const double min_taps = [] {  // A/B knob JINC_FLOAT_TRIM_MIN_TAPS (taps per plane and call from which float planes trim)
-            const char* e = std::getenv("JINC_FLOAT_TRIM_MIN_TAPS");
-            return e ? std::atof(e) : static_cast<double>(Rules::kFloatTrimMinTaps);
-        }();
-        static const int min_fs = [] {  // A/B knob JINC_FLOAT_TRIM_MIN_FS: smallest trimmed support float planes take by themselves
-            const char* e = std::getenv("JINC_FLOAT_TRIM_MIN_FS");
-            return e ? std::atoi(e) : 0;
-        }();
+        // A/B knobs FLOAT_TRIM_MIN_TAPS (taps per plane and call from which float planes trim) and FLOAT_TRIM_MIN_FS (smallest
+        // trimmed support float planes take by themselves)
+        const double min_taps = knobs::get(JINC_KNOB_FLOAT_TRIM_MIN_TAPS, Rules::kFloatTrimMinTaps);
+        const int min_fs = knobs::geti(JINC_KNOB_FLOAT_TRIM_MIN_FS, 0);
         if (f.kernel_mode == 0 && t.trim_fs < min_fs) return false;
         return static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs * nframes >= min_taps || f.kernel_mode != 0;
     }
@@ -347,11 +329,7 @@ struct Choice {
         if (f.kernel_mode != 0) return false;
         if (periodic_fs(t) == 6) return quad2_fills(t);  // two periods per lane on the 6 x 6 (6 x 7) support: tiles of 128 x 48 periods (24 rows on small calls)
         if (periodic_fs(t) == 8) {  // one period per lane on the 8 x 8 support (tap 4 at 2x)
-            static const int knob = [] {
-                const char* e = std::getenv("JINC_QUAD8");  // A/B knob: 0 = window kernel, 1 = quad form (default: by measurement below)
-                return e ? std::atoi(e) : -1;
-            }();
-            return knob < 0 ? Rules::kQuad8 : knob != 0;
+            return knobs::flag(JINC_KNOB_QUAD8, Rules::kQuad8);  // A/B knob: 0 = window kernel, 1 = quad form
         }
         const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + 8 * t.plan.fs - 1) / (8 * t.plan.fs)) * nframes;
         // (fs 7: large planes only -- on 1280 x 720 the border kernels beside the denser interior become the step's tail:
@@ -449,6 +427,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
     if (f.simd_order != 0) {  // compatibility modes (private switch): whole plane on kernel_simdorder.hip
         const float min_val = (i != 0 && !f.vi_in.is_rgb) ? -0.5f : 0.f;  // ref resize_plane_sse41.cpp:20
         t.last_kernel = "ewa_simd_order_kernel";
+        t.last_instance = t.last_kernel;
         timed(f.ev_gather, plane_stream, "SIMD-order kernel launch",
               [&](hipStream_t s) { return jinc::launch_simd_order(t.plan, io, f.simd_order, min_val, s); });
         return;
@@ -505,6 +484,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         } else if (rest > 0) {
             launch_part(npair, rest, npair == 0);
         }
+        t.last_instance = t.last_kernel;
         return;
     }
     // Border rectangles on the frame-lane kernel with fewer than 64 frames: sub-groups per wave of its sub-group form (0: the
@@ -538,6 +518,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
     };
     if (c.wants_runs(t, i)) {
         t.last_kernel = "ewa_direct_runs_kernel";
+        t.last_instance = t.last_kernel;
         drifting_border();
         timed(f.ev_periodic, plane_stream, "direct runs kernel launch", [&](hipStream_t s) {
             jinc::DirectArgs da = t.runs;
@@ -557,6 +538,13 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                                   : (f.kernel_mode == 3 || c.periodic_fs(t) < 6 || c.periodic_fs(t) > 9) ? "ewa_periodic_rows_kernel"
                                                                                                           : "ewa_periodic_kernel")
                                : "ewa_gather_kernel";
+    t.last_instance = t.last_kernel;
+    // the launcher's own word on what it launched (the periodic family picks instantiations by tile height, chord pattern, ...)
+    auto take_note = [&]() {
+        const char* kernel = nullptr;
+        const char* inst = knobs::take_instance(&kernel);
+        if (kernel) t.last_kernel = kernel, t.last_instance = inst;
+    };
     if (direct || periodic || quasi) {
         // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
         const bool strips = c.wants_border_strips() && t.strips_ok && c.direct_ok(t, i);
@@ -566,11 +554,8 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 src[i], static_cast<uint64_t>(src_pitch[i]) * (t.plan.src_h - 1) + static_cast<uint64_t>(t.plan.src_w) * sb);
             // In batches the border columns (full height: the corners with them) go to the frame-lane kernel: its lanes are 64
             // frames, so a border pixel's private coefficient set is a scalar load and the taps run from registers -- the
-            // column-strip kernel reads LDS once per tap (C2 at 1024 frames: JINC_FL_COLS_FRAMES A/B, round4/fl_cols_ab.log).
-            static const int fl_cols_min_frames = [] {
-                const char* e = std::getenv("JINC_FL_COLS_FRAMES");  // A/B knob: 0 = never
-                return e ? std::atoi(e) : Rules::kFlColsMinFrames;
-            }();
+            // column-strip kernel reads LDS once per tap (C2 at 1024 frames: knob FL_COLS_FRAMES A/B, round4/fl_cols_ab.log).
+            const int fl_cols_min_frames = knobs::geti(JINC_KNOB_FL_COLS_FRAMES, Rules::kFlColsMinFrames);  // A/B knob: 0 = never
             const bool fl_cols = t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
                                  (f.kernel_mode == 0 || f.kernel_mode == 13 || f.kernel_mode == 2);
             if (fl_cols) {
@@ -644,12 +629,11 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 // 365, float RGB 165 -> 175; a 4-frame call loses 5 %), fs 9 on calls that do not (C4, one frame per call: 80
                 // -> 94 Gpix/s; 4 / 16 frames: equal).  Kernel mode 13 forces it, 2 excludes it.
                 const bool quad = c.quad_chosen(t);
-                if (quad) variant = 5;
                 // Small calls (single frames, short batches) take the window kernels' half-height tiles: twice the
                 // workgroups for a launch that does not fill the chip (C2, one frame: 600 workgroups on 1536 slots,
                 // kernel 27.2 -> 22.3 us; 4 frames: 323 -> 354 Gpix/s); long batches keep the full tiles (+2 %).
                 const int pfs = c.periodic_fs(t);
-                if (f.kernel_mode == 0 && pfs >= 6 && pfs <= 9) {
+                if (!quad && f.kernel_mode == 0 && pfs >= 6 && pfs <= 9) {
                     const int rows = pfs * (pfs <= 7 ? 8 : 9);  // period-rows of a full tile
                     const long long wgs = static_cast<long long>((t.periodic.ni + 63) / 64) * ((t.periodic.nj + rows - 1) / rows) * nframes;
                     if (wgs < Rules::kHalfTileMaxWorkgroups) variant = 2;
@@ -657,20 +641,16 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 if (quad) {
                     const int cols = pfs == 6 ? 128 : 64;  // periods per tile row
                     const long long quad_wgs = static_cast<long long>((t.periodic.ni + cols - 1) / cols) * ((t.periodic.nj + 8 * pfs - 1) / (8 * pfs)) * nframes;
-                    if (quad_wgs < (pfs == 6 ? Rules::kQuad2HalfTileMaxWorkgroups : Rules::kHalfTileMaxWorkgroups)) variant = 6;
-                    static const int force_rg = [] {  // A/B knob: JINC_QUAD_RG=8 / 4 forces full / half-height tiles of the quad forms
-                        const char* e = std::getenv("JINC_QUAD_RG");
-                        return e ? std::atoi(e) : 0;
-                    }();
+                    // (the quad forms' tile height follows from their own workgroup count alone -- the window kernels'
+                    // half-tile rule above once left variant 2 standing under a chosen quad form)
+                    variant = quad_wgs < (pfs == 6 ? Rules::kQuad2HalfTileMaxWorkgroups : Rules::kHalfTileMaxWorkgroups) ? 6 : 5;
+                    const int force_rg = knobs::geti(JINC_KNOB_QUAD_RG, 0);  // A/B knob: 8 / 4 forces full / half-height tiles of the quad forms
                     if (force_rg == 8) variant = 5;
                     if (force_rg == 4) variant = 6;
                     // 8 x 8 support on integer planes: two periods per lane (ewa_periodic_quad2x8_kernel) where the launch fills
                     // the chip with its 128 x 32 tiles -- Jinc64 at 2x on 8-bit 483 -> 504 Gpix/s, 16-bit 4:2:0 253 -> 265; float
                     // planes (C4) are level and stay with one period per lane (round4/quad2x8_ab.log)
-                    static const int two = [] {  // A/B knob: JINC_QUAD2X8 = 0 / 1
-                        const char* e = std::getenv("JINC_QUAD2X8");
-                        return e ? std::atoi(e) : -1;
-                    }();
+                    const int two = knobs::geti(JINC_KNOB_QUAD2X8, -1);  // A/B knob: 0 / 1
                     const long long wgs2 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 31) / 32) * nframes;
                     if (pfs == 8 && (two >= 0 ? two != 0 : (sb < 4 && wgs2 >= Rules::kQuad2x8MinWorkgroups))) variant = 7;
                 }
@@ -695,10 +675,8 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     jinc::PeriodicArgs fin = t.periodic_trim, rest = t.periodic;
                     fin.frame_flags = rest.frame_flags = flags;
                     int rc = 0;
-                    static const bool scan_pass = [] {  // A/B knob: JINC_FLOAT_SCAN=1 = a scan pass over the whole source in front (round 4's first form)
-                        const char* e = std::getenv("JINC_FLOAT_SCAN");
-                        return e && std::atoi(e) != 0;
-                    }();
+                    // A/B knob FLOAT_SCAN = 1: a scan pass over the whole source in front (round 4's first form)
+                    const bool scan_pass = knobs::flag(JINC_KNOB_FLOAT_SCAN, false);
                     if (scan_pass) {
                         rc = jinc::launch_finite_scan(io, t.plan.src_w, t.plan.src_h, flags, s);
                         fin.run_when = 0, rest.run_when = 1;
@@ -714,10 +692,15 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     }
                     if (rc) return rc;
                     rc = jinc::launch_periodic(fin, pfs, io, s, variant);
+                    take_note();
                     if (rc) return rc;
-                    return jinc::launch_periodic(rest, t.plan.fs, io, s, 0);
+                    rc = jinc::launch_periodic(rest, t.plan.fs, io, s, 0);
+                    (void)knobs::take_instance();  // (the flagged frames' full-window launch does not name the call)
+                    return rc;
                 }
-                return jinc::launch_periodic(c.periodic_args(t), pfs, io, s, variant);
+                const int rc = jinc::launch_periodic(c.periodic_args(t), pfs, io, s, variant);
+                take_note();
+                return rc;
             });
     } else {
         timed(f.ev_gather, plane_stream, "gather kernel launch",
@@ -775,6 +758,7 @@ void enqueue_run(jinc_filter& f, const void* const src[4], const int src_pitch[4
                      paired ? &pair : nullptr);
         if (paired) {
             f.tables[f.table_of_plane(i + 1)].last_kernel = f.tables[f.table_of_plane(i)].last_kernel;
+            f.tables[f.table_of_plane(i + 1)].last_instance = f.tables[f.table_of_plane(i)].last_instance;
             ++i;
         }
     }

@@ -9,6 +9,7 @@
 //   jinc_alias_args         <- resizer()/resizer_jincresize<taps> (ref :1007-1040)
 // There is no CPU fallback: without a HIP device every frame call fails loudly.
 #include "filter_internal.h"
+#include "knobs.h"
 
 using namespace jinc::host;
 
@@ -439,6 +440,34 @@ const char* jinc_filter_last_kernel(const jinc_filter* f, int table) {
     return f->tables[table].last_kernel;
 }
 
+const char* jinc_filter_last_instance(const jinc_filter* f, int table) {
+    if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return "";
+    return f->tables[table].last_instance.c_str();
+}
+
+int jinc_debug_set_knob(int knob, double value) {
+    if (knob < 0 || knob >= JINC_KNOB_COUNT) return fail(JINC_ERR_INVALID_ARG, "JincResize: no such knob.");
+    if (knob == JINC_KNOB_DIRECT_SHAPE) return jinc_debug_set_direct_shape(static_cast<int>(value));
+    jinc::knobs::set(knob, value);
+    return JINC_OK;
+}
+
+int jinc_debug_clear_knob(int knob) {
+    if (knob >= JINC_KNOB_COUNT) return fail(JINC_ERR_INVALID_ARG, "JincResize: no such knob.");
+    jinc::knobs::clear(knob);
+    if (knob < 0 || knob == JINC_KNOB_DIRECT_SHAPE) jinc::set_direct_shape(-1);
+    return JINC_OK;
+}
+
+int jinc_debug_get_knob(int knob, double* value) {
+    if (knob < 0 || knob >= JINC_KNOB_COUNT) return fail(JINC_ERR_INVALID_ARG, "JincResize: no such knob.");
+    if (!jinc::knobs::is_set(knob)) return 0;
+    if (value) *value = jinc::knobs::get(knob, 0.0);
+    return 1;
+}
+
+const char* jinc_debug_knob_name(int knob) { return jinc::knobs::name(knob); }
+
 // Shader-clock sampler beside the kernels being timed (kernel_probe.hip).
 struct jinc_clock_sampler {
     int device = 0;
@@ -544,6 +573,8 @@ const char* jinc_debug_last_call(int* nframes) {
     if (nframes) *nframes = last_call_frames_in_process();
     return last_interior_kernel_in_process();
 }
+
+const char* jinc_debug_last_instance(void) { return last_interior_instance_in_process(); }
 
 int jinc_filter_direct_premise(const jinc_filter* f) { return (f && f->device >= 0) ? (f->direct_premise ? 1 : 0) : -1; }
 

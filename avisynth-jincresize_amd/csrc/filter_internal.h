@@ -77,6 +77,7 @@ struct DeviceTable {
     bool use_framelane_pair = false;  // ... and its frame-pair form (128 frames per workgroup; filter sizes 5 and 7)
     jinc::FrameLaneArgs fl_pair;
     const char* last_kernel = "";  // interior kernel of the most recent call (reports)
+    std::string last_instance;     // ... with its template arguments where the launcher chooses between instantiations (knobs.h note_instance)
 };
 
 struct EventPair {
@@ -191,7 +192,7 @@ struct jinc_filter {
     int group_frames = 1;     // frames coalesced into one launch
     std::vector<jinc::host::FrameGroup> groups = std::vector<jinc::host::FrameGroup>(1);  // ring of group buffers
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;  // belts for groups of >= kBeltMinGroup frames (else nullptr)
-    int transport = -1;       // results to the host: -1 automatic (shader when pinned), 0 DMA copies always (A/B, JINC_PIPELINE_DMA=1)
+    int transport = -1;       // results to the host: -1 automatic (shader when pinned), 0 DMA copies always (A/B: knob PIPELINE_DMA)
     int open_group = -1;      // index of the group being filled, -1: none
     int last_group = 0;       // most recently opened group (the ring advances from here)
     long long next_ticket = 0;
@@ -261,6 +262,7 @@ void enqueue(jinc_filter& f, const void* const src[4], const int src_pitch[4], c
              const int dst_pitch[4], const size_t dst_fs[4], int nframes, hipStream_t stream);
 const char* last_interior_kernel_in_process();
 int last_call_frames_in_process();
+const char* last_interior_instance_in_process();
 // pipeline.cpp: frames in flight on one instance
 void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host);  // drains first
 long long submit_frame(jinc_filter& f, const void* const src[4], const int src_pitch[4], void* const dst[4], const int dst_pitch[4]);

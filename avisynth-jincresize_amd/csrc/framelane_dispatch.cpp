@@ -5,6 +5,7 @@
 
 #include "kernels.h"
 #include "plan.h"
+#include "knobs.h"
 
 namespace jinc {
 
@@ -27,12 +28,9 @@ namespace {
 bool configure_tiles(const PlanePlan& p, const RectList& rects, int ps, size_t budget, int frames_per_group, int nframes_hint,
                      double col_weight, FrameLaneArgs& out) {
     const int groups = std::max(1, (nframes_hint + frames_per_group - 1) / frames_per_group);
-    // A/B knob JINC_FL_FILL_WEIGHT (default on): see the cost below (whole planes: no change of any choice measured; the 6-pixel
+    // A/B knob FL_FILL_WEIGHT (default on): see the cost below (whole planes: no change of any choice measured; the 6-pixel
     // border frame of 1.5x with tap 4 at 256 frames: border kernel 2.02 -> 0.37 ms, step 259 -> 300 Gpix/s)
-    static const bool fill_weighted = [] {
-        const char* e = std::getenv("JINC_FL_FILL_WEIGHT");
-        return !e || std::atoi(e) != 0;
-    }();
+    const bool fill_weighted = knobs::flag(JINC_KNOB_FL_FILL_WEIGHT, true);
 
     bool found = false, found_enough = false;
     double best_cost = 0.0;
@@ -94,12 +92,12 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     // workgroups share a CU.  One workgroup may not exceed 64 KB of dynamic LDS.
     size_t budget = 64 * 1024;  // A/B (64 frames): 1.37x fs 7 48 KB = 64 KB; 5/6 down-scale fs 8 +28 % over 48 KB
     int variant = 0;
-    if (const char* e = std::getenv("JINC_FL_VARIANT")) variant = std::atoi(e);  // A/B knob: 1 = row-segment form always
+    variant = knobs::geti(JINC_KNOB_FL_VARIANT, variant);  // A/B knob: 1 = row-segment form always
     const bool window_form = variant != 1 && (p.fs == 5 || p.fs == 7 || p.fs == 8 || p.fs == 9);
     // fs 7: the 1024-thread shape of the sliding-window kernel (two workgroups per CU at 64 VGPRs = 8 waves per SIMD) with
     // tiles of up to 80 KB
     bool big = window_form && p.fs == 7;
-    if (const char* e = std::getenv("JINC_FL_1K")) big = big && std::atoi(e) != 0;  // A/B knob
+    big = big && knobs::flag(JINC_KNOB_FL_1K, true);  // A/B knob
     // the other sliding-window forms (512 threads, two workgroups per CU either way) take up to 80 KB too: 1.5x with tap 4
     // (fs 9) gets 32 x 32 tiles, 46.6 -> 50.4 % of the VALU peak; the row-segment form is launched without the attribute
     if (big || (window_form && p.fs != 7)) budget = 80 * 1024;
@@ -107,16 +105,16 @@ bool framelane_configure(const PlanePlan& p, const RectList& rects, int sample_b
     // smaller tile's halo: 1.5x with tap 8, 64 frames: 40 KB 43 %, 48 KB 53 %, 56 / 64 KB 49 % of the VALU peak
     if (p.fs > 9) budget = 48 * 1024;
     const size_t cap = (big || (window_form && p.fs != 7)) ? 80 * 1024 : 64 * 1024;
-    if (const char* e = std::getenv("JINC_FL_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
+    if (knobs::is_set(JINC_KNOB_FL_LDS_KB)) budget = static_cast<size_t>(knobs::geti(JINC_KNOB_FL_LDS_KB, 0)) * 1024;  // tuning knob
     budget = std::min(budget, cap);
     double colw = 0.5;  // (1.5x with tap 8: 56.7 -> 58.1 % over 0; the window forms' choices do not change up to 2)
-    if (const char* e = std::getenv("JINC_FL_COLW")) colw = std::atof(e);  // tuning knob: price of a strip's window columns
+    colw = knobs::get(JINC_KNOB_FL_COLW, colw);  // tuning knob: price of a strip's window columns
     if (!configure_tiles(p, rects, ps, budget, 64, nframes_hint, colw, out)) return false;
     const int tx = 1 << out.tx_shift, ty = 1 << out.ty_shift;
     const int units = (tx / 4) * (ty / 4);
     out.threads = 64 * std::min(8, std::max(1, units));
     if (big && units >= 16) out.threads = 1024;  // (small tiles keep the 512-thread shape)
-    if (const char* e = std::getenv("JINC_FL_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
+    if (knobs::is_set(JINC_KNOB_FL_THREADS)) out.threads = std::min(out.threads, std::max(64, knobs::geti(JINC_KNOB_FL_THREADS, 0) / 64 * 64));  // A/B knob
     out.variant = variant;
     out.pair = 0;
     return true;
@@ -127,13 +125,13 @@ bool framelane_pair_configure(const PlanePlan& p, const RectList& rects, int sam
     if (p.fs != 5 && p.fs != 7) return false;
     const int ps = kFrameLanePairPosBytes(static_cast<size_t>(sample_bytes));
     size_t budget = 80 * 1024;
-    if (const char* e = std::getenv("JINC_FLP_LDS_KB")) budget = std::min<size_t>(budget, static_cast<size_t>(std::atoi(e)) * 1024);  // tuning knob
+    if (knobs::is_set(JINC_KNOB_FLP_LDS_KB)) budget = std::min<size_t>(budget, static_cast<size_t>(knobs::geti(JINC_KNOB_FLP_LDS_KB, 0)) * 1024);  // tuning knob
     double colw = 0.5;
-    if (const char* e = std::getenv("JINC_FLP_COLW")) colw = std::atof(e);  // tuning knob: price of a strip's window columns
+    colw = knobs::get(JINC_KNOB_FLP_COLW, colw);  // tuning knob: price of a strip's window columns
     if (!configure_tiles(p, rects, ps, budget, kFrameLanePairFrames, nframes_hint, colw, out)) return false;
     const int ty = 1 << out.ty_shift;
     out.threads = 64 * std::min(8, ty);  // a wave walks whole strips (output rows of the tile)
-    if (const char* e = std::getenv("JINC_FLP_THREADS")) out.threads = std::min(out.threads, std::max(64, std::atoi(e) / 64 * 64));  // A/B knob
+    if (knobs::is_set(JINC_KNOB_FLP_THREADS)) out.threads = std::min(out.threads, std::max(64, knobs::geti(JINC_KNOB_FLP_THREADS, 0) / 64 * 64));  // A/B knob
     out.variant = 0;
     out.pair = 1;
     return true;

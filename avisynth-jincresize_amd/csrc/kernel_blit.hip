@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "knobs.h"
 
 namespace jinc {
 namespace {
@@ -60,13 +61,7 @@ __global__ __launch_bounds__(256) void blit_rows_kernel(const BlitEntry* __restr
 }  // namespace
 
 namespace {
-int blit_wave_priority() {  // A/B knob JINC_BLIT_SETPRIO (default 1)
-    static const int v = [] {
-        const char* e = getenv("JINC_BLIT_SETPRIO");
-        return e ? atoi(e) : 1;
-    }();
-    return v;
-}
+int blit_wave_priority() { return knobs::geti(JINC_KNOB_BLIT_SETPRIO, 1); }  // A/B knob BLIT_SETPRIO (default 1)
 }  // namespace
 
 int blit_unit(const void* src, const void* dst, uint32_t src_pitch, uint32_t dst_pitch) {

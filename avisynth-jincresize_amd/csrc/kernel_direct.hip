@@ -29,18 +29,13 @@ int launch_direct_mode(const DirectArgs& args, const PlaneIO& io, hipStream_t s)
 }
 
 // Interior shape of a launch (DirectShape): row walk where its step scheme covers the filter size; 8 columns per lane
-// for 8-bit down-scales where that still fills the device with waves.  JINC_DIRECT_SHAPE = 0 / 2 / 3
-// forces one (A/B runs).
+// for 8-bit down-scales where that still fills the device with waves.  set_direct_shape (test header: knob DIRECT_SHAPE)
+// = 0 / 2 / 3 forces one (A/B runs).
 std::atomic<int> g_last_shape{-1};    // shape of the most recent interior launch (test hook)
-std::atomic<int> g_forced_shape{-2};  // -2: not read yet, -1: automatic, 0 / 2 / 3: forced (set_direct_shape, JINC_DIRECT_SHAPE)
+std::atomic<int> g_forced_shape{-1};  // -1: automatic, 0 / 2 / 3: forced (set_direct_shape)
 
 int interior_shape(const DirectArgs& da, const PlaneIO& io) {
-    int forced = g_forced_shape.load(std::memory_order_relaxed);
-    if (forced == -2) {
-        const char* e = std::getenv("JINC_DIRECT_SHAPE");
-        forced = e && *e ? std::atoi(e) : -1;
-        g_forced_shape.store(forced, std::memory_order_relaxed);
-    }
+    const int forced = g_forced_shape.load(std::memory_order_relaxed);
     if (!walk_supported(da.fs) || forced == 0) return 0;
     if (forced == 2 || (forced == 3 && walk_wide_supported(da.fs, da.sx))) return forced;
     if (da.fs < kWalkMinTapsPeriodic) return 0;

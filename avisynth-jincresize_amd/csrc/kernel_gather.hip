@@ -1,6 +1,7 @@
 // kernel_gather.hip -- ewa_gather_kernel: any plan (border frame of periodic plans, everything for ratios
 // without structure), plus the conversion test hook.  See device_common.hpp for the parity rules.
 #include "device_common.hpp"
+#include "knobs.h"
 
 #pragma clang fp contract(off)
 
@@ -343,11 +344,8 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
     ga.io = io;
     ga.rects = rects;
     ga.max_passes = rects.private_sets ? 0 : 4;
-    static const int env_passes = [] {  // A/B knob, read once
-        const char* e = std::getenv("JINC_GATHER_PASSES");
-        return e ? std::atoi(e) : -1;
-    }();
-    if (env_passes >= 0) ga.max_passes = env_passes;
+    const int knob_passes = knobs::geti(JINC_KNOB_GATHER_PASSES, -1);  // A/B knob
+    if (knob_passes >= 0) ga.max_passes = knob_passes;
     int total = 0;
     for (int r = 0; r < 4; ++r) {
         ga.block_begin[r] = total;

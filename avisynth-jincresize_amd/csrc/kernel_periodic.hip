@@ -5,6 +5,7 @@
 //   ewa_periodic_rows_kernel  any odd fs <= 17: 4 x 4 chains per lane, ly-major loop, column-plane LDS layout
 // See device_common.hpp for the parity rules.
 #include "device_common.hpp"
+#include "knobs.h"
 
 #pragma clang fp contract(off)
 
@@ -1625,6 +1626,7 @@ int launch_periodic_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t str
     using Cfg = PeriodicCfg<FS, RG>;
     dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
     hipLaunchKernelGGL((ewa_periodic_kernel<T, FS, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_kernel", "%s, %d, %d", knobs::type_name<T>(), FS, RG);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1633,6 +1635,7 @@ int launch_periodic_pk_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t 
     using Cfg = PeriodicPkCfg<FS, RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
     hipLaunchKernelGGL((ewa_periodic_pk_kernel<T, FS, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_pk_kernel", "%s, %d, %d", knobs::type_name<T>(), FS, RG);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1641,6 +1644,7 @@ int launch_periodic_quad_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_
     using Cfg = PeriodicCfg<7, RG>;
     dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
     hipLaunchKernelGGL((ewa_periodic_quad_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_quad_kernel", "%s, %d", knobs::type_name<T>(), RG);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1649,6 +1653,7 @@ int launch_periodic_quad9_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream
     using Cfg = PeriodicCfg<9, RG>;
     dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
     hipLaunchKernelGGL((ewa_periodic_quad9_kernel<T, RG>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_quad9_kernel", "%s, %d", knobs::type_name<T>(), RG);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1656,10 +1661,12 @@ template <typename T, int RG>
 int launch_periodic_quad8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = PeriodicCfg<8, RG>;
     dim3 grid((pa.ni + kTileCols - 1) / kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    if (quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4))
+    const bool pattern = quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4);
+    if (pattern)
         hipLaunchKernelGGL((ewa_periodic_quad8_kernel<T, RG, kQuad8TrimTap4>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     else
         hipLaunchKernelGGL((ewa_periodic_quad8_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_quad8_kernel", "%s, %d, %uu", knobs::type_name<T>(), RG, pattern ? kQuad8TrimTap4 : 0u);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1667,10 +1674,12 @@ template <typename T, int RG>
 int launch_periodic_quad2x8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2x8Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    if (quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4))
+    const bool pattern = quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4);
+    if (pattern)
         hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, kQuad8TrimTap4>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     else
         hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_quad2x8_kernel", "%s, %d, %uu", knobs::type_name<T>(), RG, pattern ? kQuad8TrimTap4 : 0u);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1678,12 +1687,16 @@ template <typename T, int RG>
 int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    if (pa.quad_taps == 7)
+    if (pa.quad_taps == 7) {
         hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, 0u, 7>), grid, dim3(256, 1, 1), 0, stream, pa, io);
-    else if ((pa.quad_inner & kQuad2InnerTap3) == kQuad2InnerTap3)
+        knobs::note_instance("ewa_periodic_quad2_kernel", "%s, %d, 0u, 7", knobs::type_name<T>(), RG);
+    } else if ((pa.quad_inner & kQuad2InnerTap3) == kQuad2InnerTap3) {
         hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, kQuad2InnerTap3>), grid, dim3(256, 1, 1), 0, stream, pa, io);
-    else
+        knobs::note_instance("ewa_periodic_quad2_kernel", "%s, %d, %uu, 6", knobs::type_name<T>(), RG, kQuad2InnerTap3);
+    } else {
         hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+        knobs::note_instance("ewa_periodic_quad2_kernel", "%s, %d, 0u, 6", knobs::type_name<T>(), RG);
+    }
     return static_cast<int>(hipGetLastError());
 }
 
@@ -1692,6 +1705,7 @@ int launch_rows_k(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream)
     using Cfg = RowsCfg<FS, KC>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
     hipLaunchKernelGGL((ewa_periodic_rows_kernel<T, FS, KC>), grid, dim3(Cfg::kThreads, 1, 1), 0, stream, pa, io);
+    knobs::note_instance("ewa_periodic_rows_kernel", "%s, %d, %d", knobs::type_name<T>(), FS, KC);
     return static_cast<int>(hipGetLastError());
 }
 

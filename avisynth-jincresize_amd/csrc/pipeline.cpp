@@ -22,6 +22,7 @@
 #include <mutex>
 
 #include "filter_internal.h"
+#include "knobs.h"
 
 namespace jinc {
 namespace host {
@@ -226,43 +227,25 @@ void retire_group(jinc_filter& f, FrameGroup& g) {
 // Workgroups of the transport kernel.  The link bounds it, and next to a transport-bound plan 48 workgroups keep the link
 // full (C2, 1.37x: 24 workgroups lose 6 %); next to a kernel-bound plan (many taps per output byte: 1.5x with tap 8)
 // every transport wave takes issue slots from the resampling kernel and 24 are the better trade (17.8 against 16.5
-// thousand frames/s; profiles/round3/blit_workgroups.log).  A/B knob: JINC_BLIT_WORKGROUPS.
+// thousand frames/s; profiles/round3/blit_workgroups.log).  A/B knob: BLIT_WORKGROUPS.
 int blit_workgroups(const jinc_filter& f) {
-    static const int knob = [] {
-        const char* e = std::getenv("JINC_BLIT_WORKGROUPS");
-        return e ? std::atoi(e) : 0;
-    }();
+    const int knob = knobs::geti(JINC_KNOB_BLIT_WORKGROUPS, 0);
     if (knob > 0) return knob;
     int taps_per_byte = 0;
     for (const auto& p : f.plans) taps_per_byte = std::max(taps_per_byte, p.fs * p.fs / f.vi_in.component_size);
     return taps_per_byte >= 100 ? 24 : 48;
 }
 
-int group_shares() {  // A/B knob JINC_GROUP_SHARES (default kGroupShares)
-    static const int v = [] {
-        const char* e = std::getenv("JINC_GROUP_SHARES");
-        const int n = e ? std::atoi(e) : 0;
-        return n > 0 ? n : kGroupShares;
-    }();
-    return v;
+int group_shares() {  // A/B knob GROUP_SHARES (default kGroupShares)
+    const int n = knobs::geti(JINC_KNOB_GROUP_SHARES, 0);
+    return n > 0 ? n : kGroupShares;
 }
 
-// Diagnosis only (JINC_PIPELINE_SKIP=h2d / kernels: wrong results, same transport otherwise): which stage slows which.
-int debug_skip() {
-    static const int v = [] {
-        const char* e = std::getenv("JINC_PIPELINE_SKIP");
-        return !e ? 0 : std::string(e) == "h2d" ? 1 : std::string(e) == "kernels" ? 2 : 0;
-    }();
-    return v;
-}
+// Diagnosis only (knob PIPELINE_SKIP = 1: no H2D copies, 2: no kernels -- wrong results, same transport otherwise): which
+// stage slows which.
+int debug_skip() { return knobs::geti(JINC_KNOB_PIPELINE_SKIP, 0); }
 
-bool dma_forced() {
-    static const bool v = [] {
-        const char* e = std::getenv("JINC_PIPELINE_DMA");
-        return e && std::atoi(e) != 0;
-    }();
-    return v;
-}
+bool dma_forced() { return knobs::flag(JINC_KNOB_PIPELINE_DMA, false); }
 
 // Kernels of the group's frames in one call, then the results to the callers' planes and the events their waits block
 // on.  A failure marks the group Failed; every wait on one of its frames reports it.
@@ -415,8 +398,7 @@ void ensure_belts(jinc_filter& f) {
         hip_check(hipStreamCreateWithFlags(&h2d, hipStreamNonBlocking), "hipStreamCreate(arrivals)");
         int least = 0, greatest = 0;
         hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
-        const char* e = std::getenv("JINC_D2H_PRIORITY");  // A/B knob: 0 lowest, 1 highest (default), 2 normal
-        const int mode = e ? std::atoi(e) : 1;
+        const int mode = knobs::geti(JINC_KNOB_D2H_PRIORITY, 1);  // A/B knob: 0 lowest, 1 highest (default), 2 normal
         if (mode == 2)
             hip_check(hipStreamCreateWithFlags(&d2h, hipStreamNonBlocking), "hipStreamCreate(departures)");
         else

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "knobs.h"
 
 namespace jinc {
 
@@ -31,7 +32,7 @@ bool quasi_configure(QuasiArgs& a, int fs, int spread_x, int spread_y) {
     // size.  The per-lane coefficient variant holds ~110 VGPRs (4 waves/SIMD), so a larger tile costs no occupancy and
     // amortises the per-phase set-up: 20 KB 249, 30 KB 284, 40 KB 271, 56 KB 220 Gpix/s.
     size_t budget = (a.exact == 2 ? 30 : 20) * 1024;
-    if (const char* e = std::getenv("JINC_QUASI_LDS_KB")) budget = static_cast<size_t>(std::atoi(e)) * 1024;  // tuning knob
+    if (knobs::is_set(JINC_KNOB_QUASI_LDS_KB)) budget = static_cast<size_t>(knobs::geti(JINC_KNOB_QUASI_LDS_KB, 0)) * 1024;  // tuning knob
     for (int rg = 8; rg >= 1; --rg) {
         const int rows = a.sy * rg * fs + fs + spread_y;
         const size_t bytes = sizeof(float) * static_cast<size_t>(rows) * a.lds_pitch +

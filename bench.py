@@ -13,7 +13,8 @@ collective -- the only communication is the barrier and the MAX over ranks of th
 How N > 1 starts (frames shard, nothing is exchanged, so any of these is the same measurement):
   * under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, the driver's form):
     one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment, barrier and MAX / SUM over RCCL;
-  * started plainly (`python bench.py --gpus N`, no WORLD_SIZE): this process touches no GPU and starts N rank
+  * started plainly (`python bench.py --gpus N`, no WORLD_SIZE): this process touches no GPU (devices are counted from the
+    KFD topology, not through HIP; refused under rocprofv3, whose tool has initialised the GPU already) and starts N rank
     processes itself (one per device, fresh interpreters), which meet over a torch TCPStore on 127.0.0.1 -- no RCCL,
     the north_star's "independent per-device streams"; `--sync rccl` makes the children use RCCL instead;
   * `--inproc`: ONE process, one filter instance + one HIP stream per device, steps issued to all devices from one
@@ -40,6 +41,7 @@ if ROOT not in sys.path:
 
 import __graft_entry__ as entry  # noqa: E402
 
+FORCE_SELF_CHECK = False     # tests: check frame 0 even under --simd-order (whose results differ from opt=0 by design)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_UNFUSED_PEAK = 78.6e12  # 256 CU x 128 lanes/clk x 2.4 GHz, one IEEE op per lane-clk (no FMA allowed)
 
@@ -261,6 +263,41 @@ def launch_ranks(n, argv, sync="store", worker=None, timeout_s=1800.0):
         if live:
             time.sleep(0.05)
     return rc
+
+
+def visible_gpu_count(base="/sys/class/kfd/kfd/topology/nodes", environ=None):
+    """GPUs this process would see, WITHOUT initialising HIP (torch.cuda.device_count() falls back to
+    hipGetDeviceCount where amdsmi cannot initialise, and the self-launch parent must not hold a HIP context when it starts
+    its rank processes): the KFD topology's nodes that have SIMDs, then the *_VISIBLE_DEVICES lists applied in the order
+    the runtime applies them.  None when the topology cannot be read (the ranks then find out for themselves)."""
+    environ = os.environ if environ is None else environ
+    try:
+        nodes = sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(base, node, "properties"), encoding="utf-8") if " " in line)
+        except OSError:
+            continue   # (a node this cgroup may not read is a device it may not use)
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = environ.get(var)
+        if v is None:
+            continue
+        ids = [x.strip() for x in v.split(",") if x.strip() != ""]
+        keep = 0
+        for x in ids:   # the list ends at the first entry that names no device
+            if x.isdigit() and int(x) < n:
+                keep += 1
+            elif x.startswith("GPU-"):
+                keep += 1
+            else:
+                break
+        n = min(n, keep)
+    return n
 
 
 def under_profiler():
@@ -537,7 +574,75 @@ def e2e_record(pkg, config, depth=128, seconds=1.5):
     return rec
 
 
-def make_workload(pkg, torch, config, frames, device, seed):
+def lcg_planes(fmt, w, h, seed=12345):
+    """SURVEY.md Appendix A item 4, the synthetic frame every known answer of tests/golden/kat.json was recorded on: one 32-bit
+    LCG stream (s = s * 1664525 + 1013904223, r = s >> 8) over the planes in processing order, rows without padding.  Own
+    numpy code (the oracle is not imported on this path): s_k = A_k * s_0 + C_k with A, C built by doubling, all mod 2^32."""
+    import numpy as np
+    dims = fmt.plane_dims(w, h)
+    total = sum(pw * ph for pw, ph in dims)
+    A = np.empty(total, dtype=np.uint32)
+    Cc = np.empty(total, dtype=np.uint32)
+    A[0], Cc[0] = 1664525, 1013904223
+    n = 1
+    with np.errstate(over="ignore"):
+        while n < total:
+            m = min(n, total - n)
+            A[n:n + m] = A[:m] * A[n - 1]
+            Cc[n:n + m] = A[:m] * Cc[n - 1] + Cc[:m]
+            n += m
+        state = A * np.uint32(seed & 0xFFFFFFFF) + Cc
+    r = state >> np.uint32(8)
+    if fmt.sample_bytes == 1:
+        vals = (r & np.uint32(0xFF)).astype(np.uint8)
+    elif fmt.sample_bytes == 2:
+        vals = (r & np.uint32((1 << fmt.bits) - 1)).astype(np.uint16)
+    else:
+        vals = (r & np.uint32(0xFFFFFF)).astype(np.float32) / np.float32(16777215.0)
+    out, at = [], 0
+    for pw, ph in dims:
+        out.append(vals[at:at + pw * ph].reshape(ph, pw))
+        at += pw * ph
+    return out
+
+
+def known_answer(config):
+    """crc32 of the reference's opt=0 output on the Appendix-A frame for `config` (tests/golden/kat.json: recorded by the survey
+    from executing the reference), or None where no known answer exists.  A constant compare: no oracle on this path."""
+    fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
+    try:
+        kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat.json"), encoding="utf-8"))["outputs"]
+    except Exception:  # noqa: BLE001
+        return None
+    for rec in kat:
+        if (rec["format"] == fmt_name and rec["src"] == [sw, sh] and rec["dst"] == [dw, dh]
+                and all(rec["args"].get(k) == v for k, v in kw.items()) and set(rec["args"]) == set(kw)):
+            return rec
+    return None
+
+
+def self_check(torch, config, fmt, dst_t, ddims):
+    """crc32 over frame 0 of the batch's OUTPUT (planes in processing order, rows truncated to the row size) against the known
+    answer: frame 0's input is the Appendix-A frame (make_workload), so the kernels the timed region ran -- at the batch size
+    it ran them -- have reproduced the reference's bytes, or the benchmark fails."""
+    import zlib
+    rec = known_answer(config)
+    if rec is None:
+        return {"status": "no known answer for this config", "crc32": None}
+    c, nbytes = 0, 0
+    for t, (w, h) in zip(dst_t, ddims):
+        if t.dtype == torch.uint16:
+            t = t.view(torch.int16)
+        host = t[0, :h, :w].contiguous().cpu().numpy()
+        c = zlib.crc32(host.tobytes(), c)
+        nbytes += host.nbytes
+    got = f"{c & 0xFFFFFFFF:08x}"
+    ok = got == rec["crc32"] and nbytes == rec["bytes"]
+    return {"status": "ok" if ok else "MISMATCH", "crc32": got, "expected": rec["crc32"], "bytes": nbytes, "frame": 0,
+            "source": f"tests/golden/kat.json [{rec['name']}] (reference opt=0 on the Appendix-A LCG frame, seed 12345)"}
+
+
+def make_workload(pkg, torch, config, frames, device, seed, lcg_first=False):
     """Creates the filter and a batch of `frames` synthetic frames resident in HBM (random samples, not
     zeros: DVFS differs); returns (filter, step(), stream, format, output plane dims).  One step() =
     one jinc_filter_process_device call over the whole batch on torch's current stream."""
@@ -566,11 +671,21 @@ def make_workload(pkg, torch, config, frames, device, seed):
         if sb == 2:
             t = t.view(torch.uint16)
         src_t.append(t)
+    if lcg_first:   # frame 0 = the Appendix-A frame the known answers were recorded on (self_check)
+        import numpy as np
+        for t, plane, (w, h) in zip(src_t, lcg_planes(fmt, sw, sh), sdims):
+            host = np.ascontiguousarray(plane)
+            if sb == 2:
+                t.view(torch.int16)[0, :h, :w] = torch.from_numpy(host.view(np.int16)).to("cuda")
+            else:
+                t[0, :h, :w] = torch.from_numpy(host).to("cuda")
     # A/B knob (measurements only): JINC_BENCH_DST_SHIFT = bytes the destination planes start beyond a 256-byte boundary (one spare
     # row per frame holds the overhang) -- which store alignment do the kernels meet?
     dst_shift = int(os.environ.get("JINC_BENCH_DST_SHIFT", "0"))
     for (w, h) in ddims:
         dst_t.append(torch.zeros((frames, h + (1 if dst_shift else 0), pitch_elems(w)), device="cuda", dtype=tdtype))
+    if dst_shift:
+        lcg_first = False   # (shifted destinations: the output's rows do not start where the tensors' do)
     sp = [t.data_ptr() for t in src_t]
     spitch = [t.stride(1) * sb for t in src_t]
     sstride = [t.stride(0) * sb for t in src_t]
@@ -583,6 +698,7 @@ def make_workload(pkg, torch, config, frames, device, seed):
         flt.process_device(sp, spitch, sstride, dp, dpitch, dstride, frames, stream=stream.cuda_stream)
 
     step.keepalive = (src_t, dst_t)
+    step.checkable = lcg_first
     return flt, step, stream, fmt, ddims
 
 
@@ -604,6 +720,10 @@ def parse_args(argv=None):
     ap.add_argument("--simd-order", type=int, default=0, help="1 / 2 / 3: the compatibility kernel in the reference's SSE4.1 / AVX2 / AVX-512 summation order")
     ap.add_argument("--border-overlap", type=int, default=-1, help="-1 automatic, 0 serial, 1 border kernel on a side stream")
     ap.add_argument("--border-strips", type=int, default=-1, help="-1 default, 1 strip kernels, 2 row strips only, 0 gather kernel over the border frame")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B / tuning knob of the library (include/jincresize_hip_test.h enum jinc_knob, lower-case name, e.g. quad_rg=8); "
+                         "JINC_<NAME> environment variables are translated the same way -- the library itself reads no environment")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the crc32 of frame 0's output against tests/golden/kat.json")
     args = ap.parse_args(argv)
     if args.config not in CONFIGS:
         ap.error(f"unknown --config {args.config}; choose from {', '.join(sorted(CONFIGS))}")
@@ -619,9 +739,13 @@ def main(argv=None):
     # the GPU: its children are fresh interpreters, and nothing that has initialised HIP is forked or exec'ed)
     # (JINC_BENCH_SELF_LAUNCH=1 takes this way for N = 1 as well: the one-GPU box's test of it)
     if world_env is None and not args.inproc and (args.gpus > 1 or os.environ.get("JINC_BENCH_SELF_LAUNCH") == "1"):
-        import torch
-        have = torch.cuda.device_count()   # counting devices does not initialise HIP
-        if have < args.gpus:
+        if under_profiler():
+            # the profiler's preloaded tool has initialised the GPU in THIS process already: starting rank processes from it
+            # would be the exec from a GPU-initialised process this pool forbids
+            raise SystemExit("bench.py --gpus N under rocprofv3: the self-launch path starts processes from a profiled (GPU-initialised) "
+                             "parent; profile one rank (`--gpus 1`) or all devices from one process (`--gpus N --inproc`) instead")
+        have = visible_gpu_count()   # KFD topology + *_VISIBLE_DEVICES: no HIP call in this process
+        if have is not None and have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: this host shows {have} HIP device(s)")
         sync = "store" if args.sync == "auto" else args.sync
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv), sync=sync))
@@ -656,6 +780,11 @@ def main(argv=None):
     n_gpus = args.gpus if args.inproc else world
 
     pkg = entry.load_package()
+    knobs_applied = pkg.apply_env_knobs()
+    for kv in args.knob:
+        name, _, val = kv.partition("=")
+        pkg.set_knob(name.strip(), float(val))
+        knobs_applied[name.strip().lower()] = float(val)
     fmt_name, sw, sh, dw, dh, kw, default_frames = CONFIGS[args.config]
     strong = args.config == "C5"
     profiled = under_profiler()
@@ -672,7 +801,8 @@ def main(argv=None):
             if B < 1:
                 raise SystemExit("C5: more ranks than frames")
         torch.cuda.set_device(dev)
-        flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, dev, 12345 + shard * B)
+        flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, dev, 12345 + shard * B,
+                                                      lcg_first=(shard == 0 and not args.no_self_check))
         flt.set_kernel_mode(args.kernel_mode)
         if args.simd_order:
             flt.set_simd_order(args.simd_order)
@@ -717,6 +847,10 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
+    dom_instance = flt.last_instance(0)   # the timed steps' interior kernel with its template arguments
+    check = None
+    if rank == 0 and getattr(loads[0]["step"], "checkable", False) and (not args.simd_order or FORCE_SELF_CHECK):
+        check = self_check(torch, args.config, fmt, loads[0]["step"].keepalive[1], ddims)
     # Shader clock under this load, in a SECOND, untimed pass of the same steps with eight single-lane samplers (one per XCD)
     # beside the kernels (kernel_probe.hip).  Not during the timed region: any second dispatch that stays active, however
     # small, costs kernels with short-lived workgroups 10-15 % (1080p -> 720p 253 -> 222 Gpix/s, C2 1 %;
@@ -765,6 +899,8 @@ def main(argv=None):
         src_bytes_frame = sum(w * h for (w, h) in fmt.plane_dims(sw, sh)) * sb
         if per_n > 0:
             dom_name, dom_ms, dom_n = flt.last_kernel(0), per_ms, per_n
+            if dom_instance.startswith(dom_name):
+                dom_name = dom_instance   # as rocprofv3 names it: "ewa_periodic_quad2_kernel<unsigned char, 8, 1026u, 6>"
         else:   # whole planes on the gather kernel (or, with --simd-order, on the compatibility kernel)
             dom_name, dom_ms, dom_n = (flt.last_kernel(0) or "ewa_gather_kernel"), gat_ms, gat_n
         # one launch per plane per step; algorithmic bytes of a launch = the batch's bytes for that plane,
@@ -781,7 +917,7 @@ def main(argv=None):
             tbl = 1 if (flt.num_tables > 1 and i in (1, 2)) else 0
             fs_t = flt.plan_info(tbl).filter_size
             kname = flt.last_kernel(tbl)
-            taps = (flt.periodic_taps(tbl, rows_kernel=3) if kname in ("ewa_periodic_quad2_kernel", "ewa_periodic_quad8_kernel")
+            taps = (flt.periodic_taps(tbl, rows_kernel=3) if kname in ("ewa_periodic_quad2_kernel", "ewa_periodic_quad8_kernel", "ewa_periodic_quad2x8_kernel")
                     else flt.periodic_taps(tbl, rows_kernel="rows" in kname) if kname.startswith("ewa_periodic")
                     else flt.periodic_taps(tbl, rows_kernel=2) if kname == "ewa_direct_kernel" else 0.0)
             taps_exec += w * h * (taps or fs_t * fs_t)
@@ -820,8 +956,11 @@ def main(argv=None):
                        "timed_region_s": round(elapsed_max, 4), "resident_bytes_per_gpu": (bytes_frame * B),
                        "untimed_spinup_ms_before_warmup": spin_ms, "parallelism": how_parallel,
                        "kernel": dom_name, "direct_kernel_premise": flt.direct_premise, "filter_size": fs, "plan_sets": info.num_sets,
-                       "plan_bytes": int(info.plan_bytes), "under_profiler": profiled},
-            "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "plan_bytes": int(info.plan_bytes), "under_profiler": profiled, "knobs": knobs_applied or None},
+            # frame 0 of the batch is the Appendix-A frame; its OUTPUT after the timed steps against the reference's crc32
+            "self_check": check["status"] if check else None, "self_check_detail": check,
+            "roofline": {"bound": "hbm",   # the metric's wording (% of the HBM roofline); what BINDS the kernel is binding_roof below
+                         "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": "2 x FETCH_SIZE + WRITE_SIZE from profiles/traffic.json (gfx950 FETCH correction); raw sum in traffic_raw",
                          "traffic_raw": traffic_raw,
@@ -834,8 +973,10 @@ def main(argv=None):
                          # taps per sample: the reference's chain (fs^2) and what the kernels execute (zero-coefficient taps left out);
                          # valu_* above and below count EXECUTED multiplies and adds, *_algorithmic the reference's 2 fs^2 per sample
                          "taps_per_sample_reference": round(taps_ref / samples_frame, 2), "taps_per_sample_executed": round(taps_exec / samples_frame, 2),
-                         "valu_algorithmic_Tops": round(valu_ops_algorithmic / 1e12, 2),
-                         "valu_frac_algorithmic": round(valu_ops_algorithmic / VALU_UNFUSED_PEAK, 4),
+                         # NOT a utilisation: the rate a kernel that executed every one of the reference's 2 fs^2 operations would need
+                         # for this throughput, as a multiple of the peak -- above 1 where zero-coefficient taps are elided
+                         "reference_equivalent_Tops": round(valu_ops_algorithmic / 1e12, 2),
+                         "reference_equivalent_rate_vs_peak_with_zero_taps_elided": round(valu_ops_algorithmic / VALU_UNFUSED_PEAK, 4),
                          # what the part sustains under this load: shader clock sampled beside the same steps in a second, untimed pass
                          # right after the timed one (median / min / max over 8 samplers = XCDs), the VALU peak at that clock and
                          # the fraction of it
@@ -869,6 +1010,13 @@ def main(argv=None):
             line["cpu_baseline"] = cpu_baseline(args.config)
         else:
             line["cpu_baseline"] = None
+        if check and check["status"] == "MISMATCH":
+            print("bench.py: SELF-CHECK FAILED -- frame 0's output does not reproduce the reference's crc32; no result line is printed.\n"
+                  + json.dumps(line), file=sys.stderr, flush=True)
+            for w in loads:
+                w["filter"].close()
+            sync.close()
+            raise SystemExit(1)
         print(json.dumps(line), flush=True)
 
     for w in loads:

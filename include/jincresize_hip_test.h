@@ -65,6 +65,81 @@ JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
  * frames in its sub-group form (a wave = 8 / 16 / 32 frames x 8 / 4 / 2 output rows; filter sizes 5, 7, 8, 9; the automatic
  * choice for what a batch leaves below 64 frames). */
 JINC_API int jinc_filter_set_kernel_mode(jinc_filter *f, int mode);
+/* The modes above by name. */
+typedef enum jinc_kernel_mode {
+    JINC_KM_AUTO = 0,
+    JINC_KM_GATHER = 1,            /* ewa_gather_kernel for every pixel */
+    JINC_KM_PERIODIC = 2,          /* as automatic, quad forms excluded */
+    JINC_KM_ROWS = 3,              /* ewa_periodic_rows_kernel for every filter size */
+    JINC_KM_WINDOW_HALF_TILES = 4, /* ewa_periodic_kernel on half-height tiles */
+    JINC_KM_PACKED_RG4 = 5,        /* ewa_periodic_pk_kernel (fs 7, full window), 4 / 8 row groups per tile */
+    JINC_KM_PACKED_RG8 = 6,
+    JINC_KM_QUASI = 7,             /* ewa_quasi_kernel wherever it applies */
+    JINC_KM_QUASI_WATERFALL = 8,
+    JINC_KM_DIRECT = 9,            /* ewa_direct_kernel wherever the plan is exactly periodic */
+    JINC_KM_QUASI_LANE = 10,
+    JINC_KM_FRAMELANE = 11,        /* 64-frame form for every plan and batch size */
+    JINC_KM_FRAMELANE_PAIR = 12,   /* 128-frame form for the whole batch */
+    JINC_KM_QUAD = 13,             /* the quad form configured for the plan's (trimmed) support: jinc_filter_last_instance says which */
+    JINC_KM_RUNS = 14,             /* runs form of the direct kernel */
+    JINC_KM_FULL_WINDOW = 15,      /* automatic choice, no trimmed support */
+    JINC_KM_FRAMELANE_SUB = 16     /* frame-lane kernel, groups below 64 frames in the sub-group form */
+} jinc_kernel_mode;
+/* Full template instantiation of the kernel that computed the interior of `table` in the most recent frame call, spelled as
+ * rocprofv3 prints it (e.g. "ewa_periodic_quad2_kernel<unsigned char, 8, 1026u, 6>": sample type, row groups per tile, chord
+ * pattern, taps per kernel row), for the kernel families whose launchers choose between instantiations by call size; the plain
+ * kernel name for the others.  bench.py reports it as roofline.kernel and the parity tests assert it, so that the
+ * instantiation a benchmark times is one the parity tests have checked. */
+JINC_API const char *jinc_filter_last_instance(const jinc_filter *f, int table);
+
+/* ---- A/B and tuning knobs ---------------------------------------------------------------------
+ * Process-wide; every knob is UNSET by default and the library never reads the environment for them (bench.py translates the
+ * JINC_* variables the profiles/ scripts pass into calls of jinc_debug_set_knob).  Knobs that shape a device plan (TRIM,
+ * QUAD_INNER, FL_*, FLP_*, QUASI_LDS_KB) are read by jinc_filter_create; the others by the frame call. */
+typedef enum jinc_knob {
+    JINC_KNOB_TRIM = 0,               /* 0: no trimmed support (periodic and direct kernels keep the full window) */
+    JINC_KNOB_QUAD_INNER,             /* 0: no chord-row patterns in the quad forms */
+    JINC_KNOB_RUNS_FL_BORDER_FRAMES,  /* frames per call from which a runs-form plan's border goes to the frame-lane kernel (0: never) */
+    JINC_KNOB_PLANE_FORK,             /* 0: planes of small calls stay on one stream */
+    JINC_KNOB_PLANE_PAIR,             /* 0: U and V of a single frame as two launches */
+    JINC_KNOB_QUASI_SPLIT,            /* workgroups per tile of the quasi-periodic kernel */
+    JINC_KNOB_FL_SUB,                 /* sub-groups per wave of the frame-lane kernel's sub-group form (0: never) */
+    JINC_KNOB_FLOAT_TRIM_MIN_TAPS,    /* taps per plane and call from which float planes take the trimmed support */
+    JINC_KNOB_FLOAT_TRIM_MIN_FS,
+    JINC_KNOB_QUAD8,                  /* 0: window kernel, 1: quad form on the 8 x 8 support */
+    JINC_KNOB_FL_COLS_FRAMES,         /* frames per call from which border columns go to the frame-lane kernel (0: never) */
+    JINC_KNOB_QUAD_RG,                /* 8 / 4: full / half-height tiles of the quad forms whatever the call size */
+    JINC_KNOB_QUAD2X8,                /* 0 / 1: two periods per lane on the 8 x 8 support */
+    JINC_KNOB_FLOAT_SCAN,             /* 1: finite-sample scan pass in front of the trimmed launch (round 4's first form) */
+    JINC_KNOB_FL_FILL_WEIGHT,
+    JINC_KNOB_FL_VARIANT,             /* 1: row-segment form of the frame-lane kernel always */
+    JINC_KNOB_FL_1K,
+    JINC_KNOB_FL_LDS_KB,
+    JINC_KNOB_FL_COLW,
+    JINC_KNOB_FL_THREADS,
+    JINC_KNOB_FLP_LDS_KB,
+    JINC_KNOB_FLP_COLW,
+    JINC_KNOB_FLP_THREADS,
+    JINC_KNOB_BLIT_WORKGROUPS,
+    JINC_KNOB_GROUP_SHARES,
+    JINC_KNOB_PIPELINE_SKIP,          /* diagnosis only (wrong results): 1 = no H2D copies, 2 = no kernels */
+    JINC_KNOB_PIPELINE_DMA,           /* 1: results leave by DMA copies even when every plane is pinned */
+    JINC_KNOB_D2H_PRIORITY,           /* departures stream: 0 lowest, 1 highest (default), 2 normal priority */
+    JINC_KNOB_QUASI_LDS_KB,
+    JINC_KNOB_BLIT_SETPRIO,
+    JINC_KNOB_DIRECT_SHAPE,           /* as jinc_debug_set_direct_shape */
+    JINC_KNOB_GATHER_PASSES,
+    JINC_KNOB_ROWS_PAIR,              /* 0: rows kernel instead of its packed phase-pair form (round 5) */
+    JINC_KNOB_FL_CLASSES,             /* 0: frame-lane kernels on the full window (no zero-tap pattern classes) */
+    JINC_KNOB_FLOAT_TWO_TILES,        /* 0: float quad kernels without the second tile in flight */
+    JINC_KNOB_BORDER_ROWS4,           /* 0: border row strips one output row per wave */
+    JINC_KNOB_GATHER_SORTED,          /* 0: single frames of plans without affine origins on the unsorted gather kernel */
+    JINC_KNOB_COUNT
+} jinc_knob;
+JINC_API int jinc_debug_set_knob(int knob, double value);
+JINC_API int jinc_debug_clear_knob(int knob);               /* knob < 0: every knob back to unset */
+JINC_API int jinc_debug_get_knob(int knob, double *value);  /* 1: set (*value receives it), 0: unset, < 0: no such knob */
+JINC_API const char *jinc_debug_knob_name(int knob);        /* lower-case name ("quad_rg"); NULL beyond the last knob */
 /* Taps per axis the periodic interior kernels of `table` execute under the current kernel mode: the plan's filter size, or
  * the side of the trimmed support on integer planes (kernel mode 15 switches trimming off); 0 when the table has no
  * periodic interior or the instance has no device. */
@@ -100,6 +175,8 @@ JINC_API int jinc_debug_valu_pair_probe(int device, int waves_per_simd, double *
 /* Interior kernel (of table 0) and frame count of the most recent kernel call of ANY filter instance in this process:
  * for tests that drive the plugin shell and cannot reach its jinc_filter handles. */
 JINC_API const char *jinc_debug_last_call(int *nframes);
+/* ... and that kernel's full instantiation (jinc_filter_last_instance of table 0 of the same call). */
+JINC_API const char *jinc_debug_last_instance(void);
 /* How the frames of the look-ahead pipeline left the device since the last reset, over ALL filter instances of this process:
  * written by the shader straight into pinned host planes (every destination plane of the group was pinned) or by DMA copies
  * (some plane was pageable); and how many host ranges the process-wide registry currently holds pinned.  For tests that

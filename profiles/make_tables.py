@@ -8,7 +8,7 @@ order = ["C2", "C1", "C3", "C4", "C2T4", "C2YUV", "C2H", "C2HT4", "C2F", "A137",
 new = False
 for c in order:
     p = os.path.join(HERE, rdir, f"{tag}_bench_{c}.json")
-    if os.path.exists(p) and "valu_frac_algorithmic" in json.loads(open(p).read())["roofline"]:
+    if os.path.exists(p) and {"reference_equivalent_rate_vs_peak_with_zero_taps_elided", "valu_frac_algorithmic"} & set(json.loads(open(p).read())["roofline"]):
         new = True
 if new:  # round 4 on: executed and algorithmic operations differ where zero-coefficient taps are left out
     print("| config (frames per step) | GPU Mpix/s | VALU ceiling, executed ops | 2 fs^2 per sample \"algorithmic\" | taps per sample executed / reference | HBM fraction (algorithmic bytes) | interior kernel |")
@@ -23,7 +23,9 @@ for c in order:
     d = json.loads(open(p).read())
     r, cfg = d["roofline"], d["config"]
     if new:
-        print(f"| {cfg['workload']} ({cfg['frames_per_step_per_gpu']}) | {d['value']:,.0f} | {100 * r['valu_frac']:.1f} % | {100 * r.get('valu_frac_algorithmic', r['valu_frac']):.1f} % | "
+        # (round 4 called it valu_frac_algorithmic; since round 5 the line says what it is: the reference-equivalent rate)
+        ref_eq = r.get('reference_equivalent_rate_vs_peak_with_zero_taps_elided', r.get('valu_frac_algorithmic', r['valu_frac']))
+        print(f"| {cfg['workload']} ({cfg['frames_per_step_per_gpu']}) | {d['value']:,.0f} | {100 * r['valu_frac']:.1f} % | {100 * ref_eq:.1f} % | "
               f"{r.get('taps_per_sample_executed', '')} / {r.get('taps_per_sample_reference', '')} | {100 * r['frac']:.1f} % | `{cfg['kernel']}` |")
     else:
         print(f"| {cfg['workload']} ({cfg['frames_per_step_per_gpu']}) | {d['value']:,.0f} | {100 * r['valu_frac']:.1f} % | {100 * r['frac']:.1f} % | `{cfg['kernel']}` |")

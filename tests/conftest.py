@@ -49,6 +49,15 @@ def gpu_pkg(pkg):
     return pkg
 
 
+@pytest.fixture(autouse=True)
+def _knobs_do_not_outlive_a_test():
+    """The library's A/B knobs are process-wide (test header): whatever a test set is unset again when it ends, pass or fail."""
+    yield
+    p = sys.modules.get(entry.PKG_NAME)
+    if p is not None and getattr(p, "_lib", None) is not None:
+        p.clear_knob()
+
+
 def crop_planes(planes, dims):
     return [np.ascontiguousarray(p[:h, :w]) for p, (w, h) in zip(planes, dims)]
 

@@ -33,7 +33,8 @@ def test_bench_under_torch_distributed_run_with_one_rank(gpu_pkg, config, extra)
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert d["scaling"] == ("strong" if config == "C5" else "weak")
-    assert d["roofline"]["kernel"] in ("ewa_periodic_kernel", "ewa_periodic_quad_kernel", "ewa_periodic_quad2_kernel") and d["roofline"]["frac"] > 0
+    assert d["roofline"]["kernel"].split("<")[0] in ("ewa_periodic_kernel", "ewa_periodic_quad_kernel", "ewa_periodic_quad2_kernel") and d["roofline"]["frac"] > 0
+    assert d["self_check"] == "ok", d["self_check_detail"]   # frame 0 = the Appendix-A frame, its output = the reference's crc32
     assert d["config"]["parallelism"].startswith("frames sharded over 1 GPU") and d["config"]["sync"] == "rccl"
 
 
@@ -60,6 +61,28 @@ def test_bench_started_plainly_runs_the_clip_config(gpu_pkg):
     d = _one_line(r)
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["frames_per_rank"] == [3 * 512] and d["config"]["sync"] == "none" and d["config"]["launch"] == "single process"
+    # 512 C2 frames per call: the instantiation the headline times (1024 frames) -- and the one
+    # tests/test_benchmarked_instances.py::test_c2_batch_reaches_the_benchmarked_instantiation compares with the CPU checker
+    from test_benchmarked_instances import BENCHMARKED
+    assert d["roofline"]["kernel"] == BENCHMARKED["C2"] and d["self_check"] == "ok", (d["roofline"]["kernel"], d["self_check_detail"])
+
+
+def test_bench_self_check_fails_loudly_when_the_output_is_wrong(gpu_pkg):
+    """pipeline_skip has no effect on process_device; a knob that really changes pixels does not exist -- so the check is shown
+    to bite through the compatibility order instead: --simd-order 2 computes the AVX2 path's result, which differs from opt=0 in
+    a few pixels of C1, and bench.py (which skips the check for that switch) is asked to check anyway."""
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys, bench; bench.FORCE_SELF_CHECK = True; bench.main(sys.argv[1:])",
+                        "--config", "C1", "--frames", "8", "--simd-order", "2", *QUICK], cwd=ROOT, env=_plain_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "SELF-CHECK FAILED" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("config,frames", [("C3", "2"), ("C4", "4")])
+def test_bench_checks_the_other_baseline_configs(gpu_pkg, config, frames):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--frames", frames, *QUICK], cwd=ROOT, env=_plain_env(),
+                       capture_output=True, text=True, timeout=600)
+    d = _one_line(r)
+    assert d["self_check"] == "ok", d["self_check_detail"]
 
 
 @pytest.mark.parametrize("sync", ["store", "rccl"])

@@ -50,12 +50,43 @@ def test_a_failing_rank_stops_the_others_and_its_code_is_returned():
 
 
 def test_plain_start_with_more_gpus_than_the_host_has_is_refused_before_any_gpu_call():
-    """No launcher, no WORLD_SIZE: bench.py counts devices (which does not initialise HIP) and says what is missing."""
-    import torch
-    have = torch.cuda.device_count()
+    """No launcher, no WORLD_SIZE: the parent counts devices from the KFD topology -- no HIP call, ADVICE r4 -- and says what is
+    missing; where the topology cannot be read (this CPU container) it starts the ranks and the first of them says so."""
+    have = bench.visible_gpu_count()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2)], capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode != 0 and f"this host shows {have} HIP device(s)" in r.stderr
+    n = (have if have is not None else 0) + 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    if have is not None:
+        assert f"this host shows {have} HIP device(s)" in r.stderr
+    else:
+        assert "needs a HIP device" in r.stderr or "exited with code" in r.stderr
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    parent = text[text.index("if world_env is None and not args.inproc"):text.index("import torch\n\n    rank = int(")]
+    assert "torch" not in parent and "device_count" not in parent   # the parent's branch imports nothing that could initialise HIP
+
+
+def test_devices_are_counted_from_the_kfd_topology(tmp_path):
+    """CPU nodes have simd_count 0; *_VISIBLE_DEVICES narrow the list, which ends at the first entry that names no device."""
+    for k, simd in enumerate((0, 0, 456, 456, 456)):
+        d = tmp_path / str(k)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    base = str(tmp_path)
+    assert bench.visible_gpu_count(base, {}) == 3
+    assert bench.visible_gpu_count(base, {"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert bench.visible_gpu_count(base, {"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1"}) == 1
+    assert bench.visible_gpu_count(base, {"CUDA_VISIBLE_DEVICES": "0,7,1"}) == 1
+    assert bench.visible_gpu_count(base, {"HIP_VISIBLE_DEVICES": ""}) == 0
+    assert bench.visible_gpu_count(str(tmp_path / "missing"), {}) is None
+
+
+def test_self_launch_is_refused_under_a_profiler():
+    """rocprofv3's tool library has initialised the GPU in the process it is preloaded into: that process must not start ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ROCPROF_OUTPUT_PATH"] = "/tmp/x"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "--inproc" in r.stderr and "rocprofv3" in r.stderr
 
 
 def test_rank_count_and_gpus_must_agree_under_a_launcher():

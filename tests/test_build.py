@@ -67,36 +67,88 @@ def _vgprs(tok):
 def test_dpp_reads_keep_their_distance_from_valu_writes(pkg):
     """ewa_framelane_sub_kernel multiplies by a coefficient another lane holds (v_mul_f32_dpp ... row_newbcast / quad_perm, written
     as inline assembly, which the compiler's hazard recogniser does not look into).  The hardware needs two wait states between a
-    VALU write of a register and a DPP read of it: in the listing no VALU instruction within the two instructions (or s_nop
-    states) in front of a DPP multiply may write that multiply's DPP operand.  (The operand comes straight from a vector load.)"""
+    VALU write of a register and a DPP read of it: in the listing no VALU instruction within the two wait states in front of a
+    DPP multiply may write that multiply's DPP operand -- along EVERY way control reaches the multiply (the first
+    form of this test forgot its history at each label; now a label's predecessors are the instruction in front of it, unless
+    that one never falls through, and every branch that names it -- a loop's back edge included).  The listing is the one the
+    build saved from the very compile that produced the library (Makefile: -save-temps, lib/%.s from build/%.o)."""
     path = [p for p in pkg.ISA_PATHS if p.endswith("kernel_framelane_sub-gfx950.s")][0]
     if not os.path.exists(path):
         pkg.build()
-    seen, hist = 0, []  # hist: (is VALU, registers written, wait states it provides)
+    assert os.path.getmtime(path) <= os.path.getmtime(pkg.LIB_PATH) + 1.0, "the ISA listing is newer than the library: rebuild"
+    insts, labels = [], {}   # insts: (op, parts, label-or-None in front); labels: name -> index of the instruction it precedes
+    pending = []
     for line in open(path):
         t = line.split(";")[0].strip()
         if not t or t.startswith("."):
+            if t.startswith(".") and t.endswith(":"):   # local labels (.LBB0_3:) begin with a dot
+                pending.append(t[:-1])
             continue
         if t.endswith(":"):
-            hist = []
+            pending.append(t[:-1])
             continue
         parts = t.replace(",", " ").split()
-        op = parts[0]
+        for name in pending:
+            labels[name] = len(insts)
+        insts.append((parts[0], parts, bool(pending)))
+        pending = []
+    branches_to = {}   # instruction index -> indices of the branches that jump to it
+    for i, (op, parts, _) in enumerate(insts):
+        if op.startswith(("s_cbranch", "s_branch")) and len(parts) > 1 and parts[1] in labels:
+            branches_to.setdefault(labels[parts[1]], []).append(i)
+
+    def falls_through(op):
+        return not op.startswith(("s_branch", "s_endpgm", "s_setpc", "s_swappc"))
+
+    def wait_states(op, parts):
+        return int(parts[1], 0) + 1 if op == "s_nop" else 1
+
+    def check(i, src, budget, text, depth=0):
+        """Walks backwards from instruction i (exclusive) over every predecessor until `budget` wait states are covered."""
+        if budget <= 0 or depth > 8:
+            return
+        preds = []
+        if i > 0 and falls_through(insts[i - 1][0]):
+            preds.append(i - 1)
+        if insts[i][2]:
+            preds += branches_to.get(i, [])
+        for j in preds:
+            op, parts, _ = insts[j]
+            valu = op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane"))
+            written = _vgprs(parts[1]) if valu and len(parts) > 1 else set()
+            assert not (written & src), f"VALU write of {sorted(written & src)} ({' '.join(parts)}) within two wait states of: {text}"
+            check(j, src, budget - wait_states(op, parts), text, depth + 1)
+
+    seen = 0
+    for i, (op, parts, _) in enumerate(insts):
         if op == "v_mul_f32_dpp":
             seen += 1
-            src, states = _vgprs(parts[2]), 0
-            for valu, written, n in reversed(hist):
-                if states >= 2:
-                    break
-                assert not (valu and written & src), f"VALU write of {sorted(written & src)} right in front of: {t}"
-                states += n
-        if op == "s_nop":
-            hist.append((False, set(), int(parts[1], 0) + 1))
-        else:
-            valu = op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane"))
-            hist.append((valu, _vgprs(parts[1]) if valu and len(parts) > 1 else set(), 1))
-        hist = hist[-6:]
+            check(i, _vgprs(parts[2]), 2, " ".join(parts))
     assert seen > 1000  # every tap of every instantiation
+    assert branches_to, "no branch target was recognised: the label syntax of the listing has changed"
+
+
+def test_no_environment_variable_steers_the_product(pkg):
+    """the A/B knobs live behind include/jincresize_hip_test.h (jinc_debug_set_knob); the library neither
+    spells a JINC_* variable nor imports getenv, and the host sources do not call it.  (The plugin shells keep their documented
+    user switches, JINCRESIZE_*: INTEGRATION.md.)"""
+    strings = subprocess.run(["strings", "-a", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert [x for x in strings if x.startswith("JINC_")] == []
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    csrc = os.path.join(ROOT, "avisynth-jincresize_amd", "csrc")
+    for fn in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, fn), errors="ignore").read(), fn
+    names = pkg.knob_ids()
+    assert len(names) >= 30 and all(n == n.lower() for n in names)
+    assert pkg.get_knob("quad_rg") is None
+    with pkg.knobs(quad_rg=8, fl_colw=0.25):
+        assert pkg.get_knob("quad_rg") == 8.0 and pkg.get_knob("fl_colw") == 0.25
+    assert pkg.get_knob("quad_rg") is None and pkg.get_knob("fl_colw") is None
+    env = {"JINC_QUAD_RG": "4", "JINC_PIPELINE_SKIP": "kernels", "JINC_UNRELATED": "1"}
+    assert pkg.apply_env_knobs(env) == {"quad_rg": 4.0, "pipeline_skip": 2.0}
+    pkg.clear_knob()
+    assert pkg.get_knob("quad_rg") is None
 
 
 def test_product_does_not_reference_the_oracle():
