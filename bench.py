@@ -387,10 +387,12 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     except AttributeError:
         avail = os.cpu_count() or 1
 
-    def run(threads, budget, avx2=False):
+    def run(threads, budget, avx2=False, avx512=False):
         n, t0 = 0, time.perf_counter()
         while True:
-            if avx2:
+            if avx512:
+                flt.get_frame_simd(3, src, threads=threads, avx512=True)
+            elif avx2:
                 flt.get_frame_simd(2, src, threads=threads, avx2=True)
             else:
                 flt.get_frame(src, threads=threads)
@@ -409,6 +411,9 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     # the fast CPU path: own AVX2 + FMA code in the summation order of the reference's opt=2 path (oracle/simd_avx2.c; the
     # reference itself cannot be built on this box).  Not bit-equal to opt=0 -- the GPU result is; it is the CPU SPEED baseline.
     have_avx2 = bool(O.lib().oracle_avx2_available())
+    # ... and own AVX-512 code in the order of the reference's opt=3 path (oracle/simd_avx512.c; north_star: "the reference
+    # AVX2/AVX-512 path timed on the same box's host cores"), where the host has AVX-512 F/BW/DQ/VL
+    have_avx512 = bool(O.lib().oracle_avx512_available())
     scan = {}
     for t in cands:
         run(t, 0.2, have_avx2)  # settle the thread pool at this size, untimed
@@ -425,9 +430,12 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     v = 0.5 * (vals[1] + vals[2])
     n, el = sum(r[1] for r in reps[1:]), sum(r[2] for r in reps[1:])
     v1, n1, el1 = run(1, 2.0, have_avx2)
+    a512_rows = run(best, 2.0, avx512=True)[0] if have_avx512 else None   # rows of one frame over the same thread count
+    a512_one = run(1, 2.0, avx512=True)[0] if have_avx512 else None
     o_best, _, _ = run(best, 2.0)   # the opt=0 port (strict sequential order) at the same thread count ...
     o1, on1, oel1 = run(1, 2.0)     # ... and on one core
-    path = ("own AVX2+FMA code in the reference's opt=2 summation order (not bit-equal to opt=0)" if have_avx2
+    path = ("own AVX2+FMA and AVX-512 code in the reference's opt=2 / opt=3 summation orders (not bit-equal to opt=0)" if have_avx2 and have_avx512
+            else "own AVX2+FMA code in the reference's opt=2 summation order (not bit-equal to opt=0)" if have_avx2
             else "oracle (opt=0 port)")
     # SURVEY 8(d)'s method next to it: whole frames in parallel, one single-thread instance per worker (how the reference is
     # deployed: Prefetch(P), MT_MULTI_INSTANCE).  `value` = the better of the two methods, named in `method`.
@@ -437,9 +445,19 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
     fp_best = max(fp[fp_key], key=lambda k: fp[fp_key][k])
     row_value, row_cores = v, best
     method = "rows of one frame over OpenMP threads"
+    value_path = "avx2_order" if have_avx2 else "opt0_port"
     if fp[fp_key][fp_best] > v:
         v, best = fp[fp_key][fp_best], int(fp_best)
         method = "whole frames in parallel, one single-thread filter instance per worker (MT_MULTI_INSTANCE)"
+    # `value` = the best of the stated paths: the AVX-512-order code takes it where it is the faster one on this host
+    a512 = fp["avx512_order_Mpix_s"]
+    if a512:
+        p512 = max(a512, key=lambda k: a512[k])
+        if a512[p512] > v:
+            v, best, value_path = a512[p512], int(p512), "avx512_order"
+            method = "whole frames in parallel, one single-thread filter instance per worker (MT_MULTI_INSTANCE)"
+        if a512_rows and a512_rows > v:
+            v, best, value_path, method = a512_rows, row_cores, "avx512_order", "rows of one frame over OpenMP threads"
     # why more workers than `cores` do not help, from this run's own figures: CPU seconds the process was GIVEN per second
     # of wall time at each P (all threads; time.process_time()).  Where that stops growing with P the lease's CPU time --
     # a CFS quota, or neighbours on the same cores -- is the limit, whatever the affinity mask says.
@@ -453,7 +471,11 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
             "sample": f"{path}; best of two methods on a host with {avail} CPUs in the affinity mask ({cpu_model()}): (a) frame-parallel, "
                       f"P single-thread instances for P in {fp_counts}, {fp['seconds_per_point']:.0f}s each; (b) {n} frames of {cfg_name} "
                       f"in {el:.1f}s with rows over {row_cores} OpenMP threads, the fastest of {cands} at {scan_s:.0f}s each",
-            "path": "avx2_order" if have_avx2 else "opt0_port",
+            "path": value_path,
+            "avx2_order_Mpix_s": fp["avx2_order_Mpix_s"] or None, "avx512_order_Mpix_s": fp["avx512_order_Mpix_s"] or None,
+            "avx512_order_row_parallel_value": round(a512_rows, 2) if a512_rows else None,
+            "avx512_order_single_core_value": round(a512_one, 2) if a512_one else None,
+            "avx512_available": have_avx512,
             "frame_parallel": fp, "row_parallel_value": round(row_value, 2), "row_parallel_cores": row_cores,
             "cpu_model": cpu_model(), "affinity_cpus": avail,
             "single_core_value": round(v1, 2), "single_core_sample": f"{n1} frames in {el1:.1f}s",
@@ -471,6 +493,7 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[cfg_name]
     fmt = O.FORMATS[fmt_name]
     have_avx2 = bool(O.lib().oracle_avx2_available())
+    have_avx512 = bool(O.lib().oracle_avx512_available())
     pmax = max(counts)
     workers = [None] * pmax
 
@@ -486,7 +509,8 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
     [t.join() for t in ts]
     t_build = time.perf_counter() - t_build
 
-    def run(p, avx2):
+    def run(p, path):
+        avx2, avx512 = path == "avx2", path == "avx512"
         done = [0] * p
         go, stop = threading.Event(), threading.Event()
 
@@ -496,7 +520,9 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
             while not stop.is_set():
                 for i, d in enumerate(dst):   # one frame = every plane, one thread (the library call releases the GIL)
                     t = flt.table_for_plane(i)
-                    if avx2:
+                    if avx512:
+                        t.resize_simd(3, src[i], d, -0.5 if (i and not fmt.rgb) else 0.0, 1, False, True)
+                    elif avx2:
                         t.resize_simd(2, src[i], d, -0.5 if (i and not fmt.rgb) else 0.0, 1, True)
                     else:
                         t.resize(src[i], d, flt.peak, 1)
@@ -512,14 +538,15 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
         el, cpu = time.perf_counter() - t0, time.process_time() - c0
         return sum(done) * dw * dh / el / 1e6, cpu / el
 
-    out = {"instances_built_in_s": round(t_build, 2), "seconds_per_point": seconds, "avx2_order_Mpix_s": {}, "opt0_port_Mpix_s": {},
+    out = {"instances_built_in_s": round(t_build, 2), "seconds_per_point": seconds, "avx2_order_Mpix_s": {}, "avx512_order_Mpix_s": {},
+           "opt0_port_Mpix_s": {},
            # CPU seconds (all threads of this process) per second of wall time while P workers ran: the cores it really got
-           "cpu_s_per_wall_s": {"avx2_order_Mpix_s": {}, "opt0_port_Mpix_s": {}}}
+           "cpu_s_per_wall_s": {"avx2_order_Mpix_s": {}, "avx512_order_Mpix_s": {}, "opt0_port_Mpix_s": {}}}
     for p in counts:
-        for key, avx2 in (("avx2_order_Mpix_s", True), ("opt0_port_Mpix_s", False)):
-            if avx2 and not have_avx2:
+        for key, path in (("avx2_order_Mpix_s", "avx2"), ("avx512_order_Mpix_s", "avx512"), ("opt0_port_Mpix_s", "opt0")):
+            if (path == "avx2" and not have_avx2) or (path == "avx512" and not have_avx512):
                 continue
-            rate, cores = run(p, avx2)
+            rate, cores = run(p, path)
             out[key][str(p)] = round(rate, 1)
             out["cpu_s_per_wall_s"][key][str(p)] = round(cores, 1)
     return out

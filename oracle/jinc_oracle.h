@@ -76,7 +76,12 @@ void oracle_resize_plane_simd(int order, const void *src, int src_pitch, void *d
 /* Own AVX2 + FMA implementation in the order of opt = 2 (simd_avx2.c); bit-equal to oracle_resize_plane_simd(2, ...). */
 int oracle_avx2_available(void);
 void oracle_resize_plane_avx2(const void *src, int src_pitch, size_t src_bytes, void *dst, int dst_pitch, const oracle_table *t,
-                              int sample_bytes, float min_val, int threads);  /* src_bytes: size of the plane's allocation */
+                              int sample_bytes, float min_val, int threads);
+/* Own AVX-512 implementation in the order of opt = 3 (simd_avx512.c); bit-equal to oracle_resize_plane_simd(3, ...).
+ * Call only where oracle_avx512_available() returns non-zero (AVX-512 F + BW + DQ + VL). */
+int oracle_avx512_available(void);
+void oracle_resize_plane_avx512(const void *src, int src_pitch, size_t src_bytes, void *dst, int dst_pitch, const oracle_table *t,
+                                int sample_bytes, float min_val_f, int threads);  /* src_bytes: size of the plane's allocation */
 
 /* the synthetic frame generator behind every KAT hash.
  * 32-bit LCG s = s*1664525 + 1013904223, r = s>>8; one stream across planes.

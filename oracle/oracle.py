@@ -89,6 +89,10 @@ def lib():
         L.oracle_resize_plane_avx2.restype = None
         L.oracle_resize_plane_avx2.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(_Table),
                                                C.c_int, C.c_float, C.c_int]
+        L.oracle_avx512_available.restype = C.c_int
+        L.oracle_resize_plane_avx512.restype = None
+        L.oracle_resize_plane_avx512.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.POINTER(_Table),
+                                                 C.c_int, C.c_float, C.c_int]
         L.oracle_lcg_fill.restype = C.c_uint32
         L.oracle_lcg_fill.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.oracle_fnv1a64.restype = C.c_uint64
@@ -173,10 +177,16 @@ class Table:
                                   C.byref(self._t), sb, float(peak), int(threads))
 
 
-    def resize_simd(self, order: int, src: np.ndarray, dst: np.ndarray, min_val: float, threads: int = 1, avx2: bool = False) -> None:
-        """Summation order of the reference's opt = 1 / 2 / 3 paths (simd_order.c); avx2=True: the own AVX2 code (order 2)."""
+    def resize_simd(self, order: int, src: np.ndarray, dst: np.ndarray, min_val: float, threads: int = 1, avx2: bool = False,
+                    avx512: bool = False) -> None:
+        """Summation order of the reference's opt = 1 / 2 / 3 paths (simd_order.c); avx2=True: the own AVX2 code (order 2),
+        avx512=True: the own AVX-512 code (order 3; only where lib().oracle_avx512_available())."""
         sb = src.dtype.itemsize
-        if avx2:
+        if avx512:
+            assert order == 3 and lib().oracle_avx512_available()
+            lib().oracle_resize_plane_avx512(src.ctypes.data, src.strides[0], src.nbytes, dst.ctypes.data, dst.strides[0],
+                                             C.byref(self._t), sb, float(min_val), int(threads))
+        elif avx2:
             assert order == 2
             lib().oracle_resize_plane_avx2(src.ctypes.data, src.strides[0], src.nbytes, dst.ctypes.data, dst.strides[0],
                                            C.byref(self._t), sb, float(min_val), int(threads))
@@ -336,12 +346,13 @@ class OracleFilter:
             out.append(d)
         return out
 
-    def get_frame_simd(self, order: int, src_planes: Sequence[np.ndarray], threads: int = 1, avx2: bool = False) -> List[np.ndarray]:
+    def get_frame_simd(self, order: int, src_planes: Sequence[np.ndarray], threads: int = 1, avx2: bool = False,
+                       avx512: bool = False) -> List[np.ndarray]:
         """The frame in the summation order of the reference's opt = `order` (1 SSE4.1, 2 AVX2, 3 AVX-512) path."""
         out = []
         for i, (pw, ph) in enumerate(self.out_dims()):
             d = alloc_plane(pw, ph, self.fmt.dtype)
             min_val = -0.5 if (i and not self.fmt.rgb) else 0.0   # resize_plane_sse41.cpp:20
-            self.table_for_plane(i).resize_simd(order, src_planes[i], d, min_val, threads, avx2)
+            self.table_for_plane(i).resize_simd(order, src_planes[i], d, min_val, threads, avx2, avx512)
             out.append(d)
         return out

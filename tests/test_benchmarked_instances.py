@@ -36,7 +36,7 @@ def full_height_tiles(gpu_pkg):
 
 def _rg_of(instance):
     """Row groups per tile from 'kernel<type, RG, ...>'."""
-    return int(instance.split("<", 1)[1].split(",")[1])
+    return int(instance.split("<", 1)[1].rstrip(">").split(",")[1])
 
 
 @pytest.mark.parametrize("case", P.QUAD_CASES, ids=P._id)

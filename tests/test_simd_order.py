@@ -57,6 +57,32 @@ def test_own_avx2_code_equals_the_restated_avx2_order(O, case):
     assert_planes_equal(f.get_frame_simd(2, src, threads=4, avx2=True), f.get_frame_simd(2, src, threads=1), f.out_dims(), what="avx2")
 
 
+@pytest.mark.parametrize("case", CASES + [("Y8", 120, 90, 240, 180, dict(tap=16)), ("Y16", 300, 200, 100, 50, dict(tap=4)), ("Y32", 64, 48, 40, 30, {})],
+                         ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
+def test_own_avx512_code_equals_the_restated_avx512_order(O, case):
+    """oracle/simd_avx512.c (16-lane partial sums over all kernel rows, FMA, 512 -> 256 -> 128 fold; the second CPU speed baseline of
+    bench.py) against the scalar restatement of the reference's opt = 3 order, bit for bit -- filter sizes with one, two (fs 17, 33,
+    34) and three 16-lane groups per kernel row, windows that end on the plane's last sample (masked loads, no over-read)."""
+    if not O.lib().oracle_avx512_available():
+        pytest.skip("host CPU without AVX-512 F/BW/DQ/VL")
+    fmt, sw, sh, tw, th, kw = case
+    f = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th, **oracle_kwargs(kw))
+    src = _frame(O, fmt, sw, sh, 37)
+    assert_planes_equal(f.get_frame_simd(3, src, threads=4, avx512=True), f.get_frame_simd(3, src, threads=1), f.out_dims(), what="avx512")
+
+
+def test_own_avx512_code_reproduces_the_reference_pixel_difference_count_on_c1(O):
+    """The one reference-derived fact about opt = 3: on C1 it differs from opt = 0 in 7 of 921 600 pixels, by one code value."""
+    if not O.lib().oracle_avx512_available():
+        pytest.skip("host CPU without AVX-512 F/BW/DQ/VL")
+    fmt = O.FORMATS["Y8"]
+    f = O.OracleFilter(fmt, 640, 360, 1280, 720, tap=3)
+    src = O.lcg_frame(fmt, 640, 360)
+    base = f.get_frame(src, threads=8)[0][:720, :1280].astype(np.int32)
+    out = f.get_frame_simd(3, src, threads=8, avx512=True)[0][:720, :1280].astype(np.int32)
+    assert int((out != base).sum()) == 7 and int(np.abs(out - base).max()) == 1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("order", [1, 2, 3], ids=["sse41_order", "avx2_order", "avx512_order"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
