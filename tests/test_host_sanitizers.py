@@ -24,7 +24,7 @@ def test_host_code_is_clean_under_asan_ubsan(pkg, tmp_path):
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     objs = []
     for name in ("filter", "filter_args", "device_plan", "dispatch", "pipeline", "batch", "plan", "jinc_lut", "quasi_dispatch",
-                 "framelane_dispatch"):
+                 "framelane_dispatch", "knobs"):
         o = str(tmp_path / f"{name}.o")
         subprocess.run([CXX, "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", *san, "-D__HIP_PLATFORM_AMD__",
                         "-I/opt/rocm/include", "-c", os.path.join(PKG, "csrc", f"{name}.cpp"), "-o", o], check=True)
