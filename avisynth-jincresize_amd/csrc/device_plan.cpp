@@ -111,6 +111,39 @@ void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vect
     pa.quad = static_cast<const float*>(dev);
 }
 
+// ewa_periodic_rowpair_kernel's coefficient pairs (kernels.h PeriodicArgs::rowpair): `sets` = the plan's phase sets (phase q * px +
+// p), ny rows of n floats each; `trims` = per phase and kernel row the taps left out on either side (nullptr: none -- the
+// reference's full window, every tap executed).  Only for two phases per period in x that share their window origin.
+void attach_rowpair(DeviceTable& t, jinc::PeriodicArgs& pa, int n, int ny, const std::vector<const float*>& sets, const int32_t* trims) {
+    pa.rowpair = nullptr;
+    pa.rowpair_n = pa.rowpair_ny = pa.rowpair_stride = 0;
+    if (!jinc::rowpair_supported(n) || ny > 17 || ny < 1 || pa.px != 2 || pa.py > 8 || pa.start_x[0] != pa.start_x[1] ||
+        pa.start_x[0] != pa.min_sx)
+        return;
+    const int stride = (2 * n + 3) & ~3;  // floats per kernel row: n pairs, padded to 16 bytes
+    std::vector<float> c(static_cast<size_t>(pa.py) * ny * stride, 0.f);
+    for (int q = 0; q < pa.py; ++q) {
+        uint64_t bits = 0;
+        for (int ly = 0; ly < ny; ++ly) {
+            for (int lx = 0; lx < n; ++lx)
+                for (int px = 0; px < 2; ++px)
+                    c[(static_cast<size_t>(q) * ny + ly) * stride + 2 * lx + px] = sets[static_cast<size_t>(q * 2 + px)][ly * n + lx];
+            int tr = trims ? std::min(trims[(q * 2 + 0) * 32 + ly], trims[(q * 2 + 1) * 32 + ly]) : 0;
+            tr = std::max(0, std::min(tr, std::min(5, (n - 2) / 2)));
+            bits |= static_cast<uint64_t>(tr) << (3 * ly);
+        }
+        pa.rowpair_trim[q] = bits;
+    }
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, c.size() * sizeof(float)), "hipMalloc(row-pair coefficients)");
+    t.lane_blobs.push_back(dev);  // freed with the table
+    hip_check(hipMemcpy(dev, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice), "row-pair coefficient upload");
+    pa.rowpair = static_cast<const float*>(dev);
+    pa.rowpair_n = n;
+    pa.rowpair_ny = ny;
+    pa.rowpair_stride = stride;
+}
+
 // Trimmed support of the periodic interior (integer planes).  The reference's window is filter_size x filter_size taps, but
 // the EWA disc does not fill it: taps beyond the radius carry the coefficient 0.0f (LUT index >= samples, ref :277-281), for
 // the 2x up-scale with tap 3 the whole first kernel row and column of all four phase sets.  A tap whose coefficient is zero
@@ -223,6 +256,11 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     t.periodic_trim = tr;
     t.trim_fs = n;
     t.trim_nx = n;
+    {   // the packed phase-pair form of the rows kernel on this support (12 .. 17 taps per kernel row)
+        std::vector<const float*> sets;
+        for (int ph = 0; ph < nphase; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * ny * n);
+        if (pa.px == 2) attach_rowpair(t, t.periodic_trim, n, ny, sets, n <= 32 ? row_trim.data() : nullptr);
+    }
     if (nphase == 4 && ny == n) {
         std::vector<const float*> sets;
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * n * n);
@@ -308,6 +346,11 @@ void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
     pa.dst_h = p.g.dst_h;
     t.periodic = pa;
     t.use_periodic = true;
+    if (pa.px == 2) {  // the rows kernel's packed phase-pair form on the reference's full window (every tap executed: no trims)
+        std::vector<const float*> sets;
+        for (int ph = 0; ph < pa.px * pa.py; ++ph) sets.push_back(p.set_ptr(pa.set[ph]));
+        attach_rowpair(t, t.periodic, p.fs, p.fs, sets, nullptr);
+    }
 
     t.border_rects = border_frame(p, p.ix0 + p.px * pa.ni, p.iy0 + p.py * pa.nj);
 }

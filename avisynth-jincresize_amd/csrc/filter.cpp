@@ -404,6 +404,13 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
     }
     if (!t.use_periodic) return 0;
     const bool trimmed = runs_trimmed(f, t);
+    if (rows_kernel == 4) {  // ewa_periodic_rowpair_kernel: the spans both phases p of a (q, kernel row) share
+        const jinc::PeriodicArgs& pa = (trimmed && t.trim_nx == t.trim_fs) ? t.periodic_trim : t.periodic;
+        double taps = 0;
+        for (int q = 0; q < pa.py; ++q)
+            for (int ly = 0; ly < pa.rowpair_ny; ++ly) taps += pa.rowpair_n - 2 * static_cast<int>((pa.rowpair_trim[q] >> (3 * ly)) & 7u);
+        return pa.rowpair ? taps / pa.py : 0.0;
+    }
     if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && trimmed) return 42.0;  // 6 rows x 7 columns
     if (rows_kernel == 3 && t.trim_fs == 6 && trimmed &&  // ewa_periodic_quad2_kernel: chord rows on four taps (half the samples each)
         (t.periodic_trim.quad_inner & jinc::PeriodicArgs::kQuadInnerTap3) == jinc::PeriodicArgs::kQuadInnerTap3)

@@ -12,35 +12,7 @@
 namespace jinc {
 namespace {
 
-// Float planes on the trimmed support (PeriodicArgs::frame_flags, run_when; csrc/dispatch.cpp): a launch with run_when 0 / 1
-// returns at once for frames whose flag differs; a launch with run_when == kRunAllAndFlag computes every frame and SETS the flag
-// of a frame in whose staged samples it meets an infinity or a NaN -- the kernel reads every source sample of its tiles anyway, so
-// the finite-sample scan costs a compare per staged sample instead of a pass over the source.  (The full-window launch behind it,
-// run_when 1, then computes those frames again.)
-constexpr uint32_t kRunAllAndFlag = PeriodicArgs::kRunAllAndFlag;
-__device__ __forceinline__ bool skips_frame(const PeriodicArgs& a, size_t frame) {
-    return a.frame_flags && a.run_when != kRunAllAndFlag && ((const JINC_CONSTANT uint32_t*)a.frame_flags)[frame] != a.run_when;
-}
-// Per thread and tile: did an exponent of all ones (an infinity or a NaN) pass through the staging registers?  Declared beside
-// the staging registers; its destructor, at the end of the staging block, sets the frame's flag.  Integer planes: nothing.
-template <typename T>
-struct NonFinite {
-    const PeriodicArgs& a;
-    const size_t frame;
-    uint32_t acc = 0;
-    __device__ __forceinline__ NonFinite(const PeriodicArgs& a_, size_t frame_) : a(a_), frame(frame_) {}
-    __device__ __forceinline__ float take(T v) {
-        // (exponent 0xff: the biased field plus one carries into the sign bit)
-        if constexpr (std::is_same_v<T, float>) acc |= (__builtin_bit_cast(uint32_t, v) & 0x7f800000u) + 0x00800000u;
-        return to_float(v);
-    }
-    __device__ __forceinline__ ~NonFinite() {
-        if constexpr (std::is_same_v<T, float>) {
-            if (a.run_when == kRunAllAndFlag && (acc & 0x80000000u)) const_cast<uint32_t*>(a.frame_flags)[frame] = 1u;  // (every writer writes 1)
-        }
-    }
-};
-
+#include "kernel_periodic_common.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Periodic interior kernel
@@ -179,7 +151,6 @@ __global__ __launch_bounds__(256) void ewa_periodic_kernel(const PeriodicArgs a,
 // both register windows as 2-vectors, so every tap is one v_pk_mul_f32 + one v_pk_add_f32 (two
 // independent IEEE products / sums per instruction; nothing is fused or reassociated: each half is
 // exactly the scalar chain).  The coefficient stays in an SGPR and is broadcast to both halves by op_sel.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Two horizontally adjacent samples of a lane through the buffer resource: one 2-sample store.
 template <typename T>
@@ -1772,6 +1743,10 @@ bool periodic_supported(int fs, int px, int py, int sx, int sy) {
 
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant) {
     if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
+    // 2x up-scales with 12 .. 17 taps per kernel row: the rows kernel's packed phase-pair form (kernel_rowpair.hip) wherever the
+    // plan carries its coefficient pairs; variant 1 (kernel mode 3) and the knob ROWS_PAIR = 0 keep ewa_periodic_rows_kernel
+    if (variant == 0 && args.rowpair && args.rowpair_n == fs && fs >= 10 && knobs::flag(JINC_KNOB_ROWS_PAIR, true))
+        return launch_rowpair(args, io, stream);
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (io.sample_bytes) {
         case 1: return launch_periodic_fs<uint8_t>(args, fs, io, s, variant);

@@ -96,6 +96,12 @@ struct PeriodicArgs {
     // EITHER side (min of its leading and trailing zero coefficients, at most 5), or nullptr
     const int32_t* row_trim = nullptr;
     int rows_ny = 0;  // ewa_periodic_rows_kernel on a support with fewer kernel rows than taps per row: the row count (0: fs rows)
+    // ewa_periodic_rowpair_kernel (2x up-scales with 12 .. 17 taps per kernel row whose two phases p share their window origin):
+    // coefficient pairs rowpair[(q * rowpair_ny + ly) * rowpair_stride + 2 * lx + p] = set(p, q)[ly][lx], and per q the taps each
+    // kernel row leaves out on either side for BOTH p, three bits per kernel row (bits 3 * ly ...); nullptr: no such form
+    const float* rowpair = nullptr;
+    int rowpair_n = 0, rowpair_ny = 0, rowpair_stride = 0;
+    uint64_t rowpair_trim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // float planes on the trimmed support: frame_flags[frame] (kernel_scan.hip: 1 = the frame's plane holds a non-finite
     // sample) decides which of two launches computes a frame -- a launch returns at once for frames whose flag differs from
     // run_when.  nullptr: every frame.
@@ -290,6 +296,9 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 bool periodic_supported(int fs, int px, int py, int sx, int sy);
 // variant: 0 = default choice per filter size, 1 = always the row-streamed kernel (A/B measurements)
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
+// kernel_rowpair.hip: the row-streamed kernel in packed phase-pair form (PeriodicArgs::rowpair; 12 .. 17 taps per kernel row)
+bool rowpair_supported(int taps_per_row);
+int launch_rowpair(const PeriodicArgs& args, const PlaneIO& io, void* stream);
 // kernel_scan.hip: flags[frame] = 1 where the frame's float source plane (w x h samples) holds an infinity or a NaN
 int launch_finite_scan(const PlaneIO& io, int w, int h, uint32_t* flags, void* stream);
 // ... the same over the samples of the plane OUTSIDE the rectangle [rx0, rx1) x [ry0, ry1) only (what a trimmed launch that flags

@@ -945,6 +945,7 @@ def main(argv=None):
             fs_t = flt.plan_info(tbl).filter_size
             kname = flt.last_kernel(tbl)
             taps = (flt.periodic_taps(tbl, rows_kernel=3) if kname in ("ewa_periodic_quad2_kernel", "ewa_periodic_quad8_kernel", "ewa_periodic_quad2x8_kernel")
+                    else flt.periodic_taps(tbl, rows_kernel=4) if kname == "ewa_periodic_rowpair_kernel"
                     else flt.periodic_taps(tbl, rows_kernel="rows" in kname) if kname.startswith("ewa_periodic")
                     else flt.periodic_taps(tbl, rows_kernel=2) if kname == "ewa_direct_kernel" else 0.0)
             taps_exec += w * h * (taps or fs_t * fs_t)

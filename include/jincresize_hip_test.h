@@ -147,7 +147,8 @@ JINC_API int jinc_filter_periodic_support(const jinc_filter *f, int table);
 /* Taps per output sample the periodic interior kernels of `table` execute under the current kernel mode (bench.py: the VALU
  * fraction counts executed operations): side^2 of jinc_filter_periodic_support for the window / quad forms; for
  * ewa_periodic_rows_kernel (rows_kernel == 1) the sum of its per-kernel-row spans, averaged over the phases; rows_kernel == 2:
- * the direct kernel's interior (its trimmed support squared); 3: ewa_periodic_quad2_kernel (34 where its chord rows run on four taps). */
+ * the direct kernel's interior (its trimmed support squared); 3: ewa_periodic_quad2_kernel (34 where its chord rows run on four taps);
+ * 4: ewa_periodic_rowpair_kernel (the spans both phases p of a kernel row share). */
 JINC_API double jinc_filter_periodic_taps(const jinc_filter *f, int table, int rows_kernel);
 /* Name of the kernel that computes the interior of `table` under the current kernel mode (reports, profiles). */
 JINC_API const char *jinc_filter_interior_kernel(const jinc_filter *f, int table);
