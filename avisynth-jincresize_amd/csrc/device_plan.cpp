@@ -112,25 +112,31 @@ void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vect
 }
 
 // ewa_periodic_rowpair_kernel's coefficient pairs (kernels.h PeriodicArgs::rowpair): `sets` = the plan's phase sets (phase q * px +
-// p), ny rows of n floats each; `trims` = per phase and kernel row the taps left out on either side (nullptr: none -- the
+// p), ny rows of n floats each.  `trimmed`: per (q, kernel row) the taps BOTH phases p leave out on either side -- zero coefficients
+// in front of and behind the row's span, exact to skip for finite samples -- are recorded for the kernel; otherwise none (the
 // reference's full window, every tap executed).  Only for two phases per period in x that share their window origin.
-void attach_rowpair(DeviceTable& t, jinc::PeriodicArgs& pa, int n, int ny, const std::vector<const float*>& sets, const int32_t* trims) {
+void attach_rowpair(DeviceTable& t, jinc::PeriodicArgs& pa, int n, int ny, const std::vector<const float*>& sets, bool trimmed) {
     pa.rowpair = nullptr;
     pa.rowpair_n = pa.rowpair_ny = pa.rowpair_stride = 0;
-    if (!jinc::rowpair_supported(n) || ny > 17 || ny < 1 || pa.px != 2 || pa.py > 8 || pa.start_x[0] != pa.start_x[1] ||
+    if (!jinc::rowpair_supported(n) || ny > n || ny < 1 || pa.px != 2 || pa.py > 8 || pa.start_x[0] != pa.start_x[1] ||
         pa.start_x[0] != pa.min_sx)
         return;
     const int stride = (2 * n + 3) & ~3;  // floats per kernel row: n pairs, padded to 16 bytes
+    const int widest = std::min(5, (n - 2) / 2);
     std::vector<float> c(static_cast<size_t>(pa.py) * ny * stride, 0.f);
     for (int q = 0; q < pa.py; ++q) {
         uint64_t bits = 0;
         for (int ly = 0; ly < ny; ++ly) {
-            for (int lx = 0; lx < n; ++lx)
-                for (int px = 0; px < 2; ++px)
-                    c[(static_cast<size_t>(q) * ny + ly) * stride + 2 * lx + px] = sets[static_cast<size_t>(q * 2 + px)][ly * n + lx];
-            int tr = trims ? std::min(trims[(q * 2 + 0) * 32 + ly], trims[(q * 2 + 1) * 32 + ly]) : 0;
-            tr = std::max(0, std::min(tr, std::min(5, (n - 2) / 2)));
-            bits |= static_cast<uint64_t>(tr) << (3 * ly);
+            int tr = widest;
+            for (int px = 0; px < 2; ++px) {
+                const float* r = sets[static_cast<size_t>(q * 2 + px)] + ly * n;
+                for (int lx = 0; lx < n; ++lx) c[(static_cast<size_t>(q) * ny + ly) * stride + 2 * lx + px] = r[lx];
+                int lead = 0, trail = 0;
+                while (lead < n && r[lead] == 0.f) ++lead;
+                while (trail < n - lead && r[n - 1 - trail] == 0.f) ++trail;
+                tr = std::min(tr, std::min(lead, trail));
+            }
+            bits |= static_cast<uint64_t>(trimmed ? tr : 0) << (3 * ly);
         }
         pa.rowpair_trim[q] = bits;
     }
@@ -187,6 +193,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         t.periodic_trim = tr;
         std::vector<const float*> sets;
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * 42);
+        attach_rowpair(t, t.periodic_trim, 7, 6, sets, true);
         attach_quad(t, t.periodic_trim, 6, sets, 7);
         if (t.periodic_trim.quad) {
             t.trim_fs = 6;
@@ -259,7 +266,7 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     {   // the packed phase-pair form of the rows kernel on this support (12 .. 17 taps per kernel row)
         std::vector<const float*> sets;
         for (int ph = 0; ph < nphase; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * ny * n);
-        if (pa.px == 2) attach_rowpair(t, t.periodic_trim, n, ny, sets, n <= 32 ? row_trim.data() : nullptr);
+        if (pa.px == 2) attach_rowpair(t, t.periodic_trim, n, ny, sets, true);
     }
     if (nphase == 4 && ny == n) {
         std::vector<const float*> sets;
@@ -349,7 +356,7 @@ void plan_launches(const jinc::PlanePlan& p, DeviceTable& t) {
     if (pa.px == 2) {  // the rows kernel's packed phase-pair form on the reference's full window (every tap executed: no trims)
         std::vector<const float*> sets;
         for (int ph = 0; ph < pa.px * pa.py; ++ph) sets.push_back(p.set_ptr(pa.set[ph]));
-        attach_rowpair(t, t.periodic, p.fs, p.fs, sets, nullptr);
+        attach_rowpair(t, t.periodic, p.fs, p.fs, sets, false);
     }
 
     t.border_rects = border_frame(p, p.ix0 + p.px * pa.ni, p.iy0 + p.py * pa.nj);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes kernel_rowpair_rows.inc: for N = 12 .. 17 taps per kernel row, one kernel row of ewa_periodic_rowpair_kernel for a lane's four
+"""Writes kernel_rowpair_rows.inc: for N = 6 .. 17 taps per kernel row, one kernel row of ewa_periodic_rowpair_kernel for a lane's four
 chain pairs as two inline-assembly statements.
 
 Why generated text and not templates: the chord of a (q, kernel row) -- TR taps left out on either side, a wave-uniform run-time
@@ -39,17 +39,49 @@ def statement(lines, pairs, coefs, n_pairs_name="w", first_pair=0, first_coef=0)
             f'        : "scc");\n')
 
 
+def max_trim(n):
+    """Taps a kernel row may leave out per side: at most 5, and at least two taps stay."""
+    return min(5, (n - 2) // 2)
+
+
+def entry(tr_op, mt, tag):
+    """Jumps to label a<k> for tr == k (k = 0 .. mt; tr >= mt lands on a<mt>)."""
+    out = []
+    for k in range(mt):
+        out += [f"s_cmp_lt_u32 %{tr_op}, {k + 1}", f"s_cbranch_scc1 .Ljrp_{tag}{k}_%="]
+    if mt:
+        out.append(f"s_branch .Ljrp_{tag}{mt}_%=")
+    return out
+
+
 def row(n):
-    split = min(8, n - 5)          # statement A: taps 0 .. split - 1 (the left flank 0 .. 4 and what follows), B: the rest
+    mt = max_trim(n)
+    nw = 2 * ((n + 3 + 3) // 4)
+    head = (f"template <>\nstruct RowPairRow<{n}> {{\n"
+            f"    static __device__ __forceinline__ void run(f32x2 (&a)[4], const f32x2 (&w)[{nw}], const f32x2 (&c)[{n}], uint32_t tr) {{\n"
+            f"    f32x2 t0, t1, t2, t3;\n")
+    if n <= 9:   # one statement: entry by tr, taps, exit by tr
+        pairs = (n - 1 + 3) // 2 + 1
+        tr_op = 8 + pairs + n
+        lines = entry(tr_op, mt, "a")
+        for lx in range(n):
+            k = n - lx                  # tap lx is executed iff lx >= tr (entry) and tr < n - lx (exit)
+            if k <= mt:
+                lines += [f"s_cmp_lt_u32 %{tr_op}, {k}", f"s_cbranch_scc0 .Ljrp_end_%="]
+            if lx <= mt:
+                lines.append(f".Ljrp_a{lx}_%=:")
+            lines += tap(lx, 0, 8 + pairs + lx)
+        lines.append(".Ljrp_end_%=:")
+        assert tr_op + 1 <= 30
+        return head + statement(lines, pairs, n) + "    }\n};\n"
+    split = min(8, n - mt)          # statement A: taps 0 .. split - 1 (the left flank 0 .. mt - 1 and what follows), B: the rest
+    assert split > mt
     # ---- A: entry by tr ----
     a_pairs = (split - 1 + 3) // 2 + 1
     tr_op_a = 8 + a_pairs + split
-    la = []
-    for k in range(5):             # tr == k: start at tap k
-        la += [f"s_cmp_lt_u32 %{tr_op_a}, {k + 1}", f"s_cbranch_scc1 .Ljrp_a{k}_%="]
-    la.append("s_branch .Ljrp_a5_%=")
+    la = entry(tr_op_a, mt, "a")
     for lx in range(split):
-        if lx <= 5:
+        if lx <= mt:
             la.append(f".Ljrp_a{lx}_%=:")
         la += tap(lx, 0, 8 + a_pairs + lx)
     # ---- B: exit by tr ----
@@ -61,23 +93,16 @@ def row(n):
     lb = []
     for lx in range(split, n):
         k = n - lx                 # tap lx is executed iff tr < n - lx
-        if k <= 5:
+        if k <= mt:
             lb += [f"s_cmp_lt_u32 %{tr_op_b}, {k}", f"s_cbranch_scc0 .Ljrp_end_%="]
         lb += tap(lx, pbase, 8 + b_pairs + (lx - split))
     lb.append(".Ljrp_end_%=:")
-    assert 8 + a_pairs + split + 1 <= 30 and 8 + b_pairs + b_coefs + 1 <= 30
-    nw = 2 * ((n + 3 + 3) // 4)
-    s = (f"template <>\nstruct RowPairRow<{n}> {{\n"
-         f"    static __device__ __forceinline__ void run(f32x2 (&a)[4], const f32x2 (&w)[{nw}], const f32x2 (&c)[{n}], uint32_t tr) {{\n"
-         f"    f32x2 t0, t1, t2, t3;\n")
-    s += statement(la, a_pairs, split)
-    s += statement(lb, b_pairs, b_coefs, first_pair=pbase, first_coef=split)
-    s += "    }\n};\n"
-    return s
+    assert tr_op_a + 1 <= 30 and tr_op_b + 1 <= 30
+    return head + statement(la, a_pairs, split) + statement(lb, b_pairs, b_coefs, first_pair=pbase, first_coef=split) + "    }\n};\n"
 
 
 print("// kernel_rowpair_rows.inc -- GENERATED by gen_rowpair_rows.py (see there); do not edit.\n"
       "// RowPairRow<N>::run(a, w, c, tr): taps lx = tr .. N - 1 - tr of one kernel row onto the lane's four chain pairs.\n"
       "template <int N>\nstruct RowPairRow;\n")
-for n in range(12, 18):
+for n in range(6, 18):
     print(row(n))

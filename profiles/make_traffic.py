@@ -34,10 +34,23 @@ for cfg in ("C2", "C3", "C4", "A137", "N15", "N15T8", "N15T4"):
     # the interior kernel, not a border kernel that runs beside it for as long (1.5x with tap 4: the gather kernel over the border)
     interior = [kv for kv in cands if not kv[0].startswith(("ewa_gather_kernel", "ewa_colstrip_kernel"))]
     name, e = max(interior or cands, key=lambda kv: kv[1]["avg_ns"] * kv[1]["calls"])
-    out[cfg] = {"hbm_bytes_per_launch": int(round(2 * e["FETCH_SIZE_bytes_mean"] + e["WRITE_SIZE_bytes_mean"])),
-                "hbm_bytes_per_launch_raw": int(round(e["hbm_bytes_per_launch_raw"])),
+    # A step of a multi-plane configuration launches the interior kernel once per plane, and the planes' launches may be
+    # DIFFERENT instantiations of it (C3: <unsigned short, 16, ..> for luma, <unsigned short, 17, ..> for the chroma planes): the
+    # step's traffic is the sum over all of them, and "per launch" its mean -- like roofline.algorithmic_bytes_per_launch.
+    # (Rounds 3-4 took the luma instantiation's launches alone, 2/3 of the step's bytes, against a third of the step's
+    # algorithmic bytes: the "2.01 x" of VERDICT r4, an accounting error, not re-reads.)
+    family = name.split("<")[0]
+    members = [(k, v) for k, v in (interior or cands) if k.split("<")[0] == family and "FETCH_SIZE_launches" in v]
+    steps = e.get("FETCH_SIZE_launches") or 1
+    per_step = sum((2 * v["FETCH_SIZE_bytes_mean"] + v["WRITE_SIZE_bytes_mean"]) * v["FETCH_SIZE_launches"] for _, v in members) / steps
+    per_step_raw = sum(v["hbm_bytes_per_launch_raw"] * v["FETCH_SIZE_launches"] for _, v in members) / steps
+    launches_per_step = sum(v["FETCH_SIZE_launches"] for _, v in members) / steps
+    out[cfg] = {"hbm_bytes_per_launch": int(round(per_step / launches_per_step)),
+                "hbm_bytes_per_launch_raw": int(round(per_step_raw / launches_per_step)),
+                "hbm_bytes_per_step": int(round(per_step)), "launches_per_step": round(launches_per_step, 3),
                 "frames_per_launch": d.get("frames_per_launch"),
-                "kernel": name, "fetch_bytes_raw": int(round(e["FETCH_SIZE_bytes_mean"])), "write_bytes": int(round(e["WRITE_SIZE_bytes_mean"])),
+                "kernel": name, "kernels_of_a_step": sorted(k for k, _ in members),
+                "fetch_bytes_raw": int(round(e["FETCH_SIZE_bytes_mean"])), "write_bytes": int(round(e["WRITE_SIZE_bytes_mean"])),
                 "avg_ns_under_rocprof": e["avg_ns"], "calls": e["calls"]}
     if "effective_clock_ghz" in e:   # GRBM_GUI_ACTIVE / 8 / dispatch duration, mean over the launches of that pass
         out[cfg]["effective_clock_ghz"] = round(e["effective_clock_ghz"], 4)

@@ -119,6 +119,49 @@ def test_rowpair_kernel_with_non_finite_float_samples(gpu_pkg, O, tap, lw):
     f.close()
 
 
+SHORT_ROW_CASES = [
+    ("Y8", 301, 99, 602, 198, dict(tap=3), (6,)),                       # C2's geometry in small: 6 x 6 with chord rows
+    ("Y16", 150, 101, 300, 202, dict(tap=3), (6,)),
+    ("Y32", 150, 100, 300, 200, dict(tap=3), (7,)),                      # float below the trim threshold: the full 7 x 7 window
+    ("Y8", 150, 100, 300, 200, dict(tap=4), (8,)),
+    ("Y12", 301, 99, 602, 198, dict(tap=4, blur=0.98), (8,)),
+    ("RGBPS", 160, 100, 320, 200, dict(tap=4, blur=0.98), (9,)),         # C4's arguments in small: full 9 x 9 window
+    ("Y8", 150, 100, 300, 200, dict(tap=5), (10,)),
+    ("Y32", 150, 100, 300, 200, dict(tap=5), (11,)),
+    ("YUV420P8", 302, 200, 604, 400, dict(tap=3), (6, 7)),               # chroma sited as MPEG-2: 6 rows x 7 columns
+    ("YUV420P16", 300, 200, 600, 400, dict(tap=4, cplace="topleft"), (8, None)),
+    ("YUV444P8", 150, 100, 300, 200, dict(tap=3), (6,)),
+]
+
+
+@pytest.mark.parametrize("lw", [0, 64, 16], ids=["auto", "256", "64"])
+@pytest.mark.parametrize("case", SHORT_ROW_CASES, ids=_id)
+def test_rowpair_kernel_on_short_kernel_rows(gpu_pkg, O, case, lw):
+    """Taps 3 .. 5 at 2x (6 .. 11 taps per kernel row; one assembly statement per chain row up to 9 taps) through the knob that puts
+    them on the pair form wherever the plan carries the coefficient pairs; single frames and a 5-frame batch."""
+    torch = pytest.importorskip("torch")
+    from test_framelane_pair import _run_batch
+    fmt, sw, sh, tw, th, kw, taps = case
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    of = O.OracleFilter(ofmt, sw, sh, tw, th, **oracle_kwargs(kw))
+    srcs = [O.lcg_frame(ofmt, sw, sh, seed=640 + k) for k in range(5)]
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, **kw)
+    with gpu_pkg.knobs(rowpair_small=1, **({"rows_pair": lw} if lw else {})):
+        got = f.get_frame(srcs[0])
+        for t in range(f.num_tables):
+            if taps[t] is not None:
+                inst = f.last_instance(t)
+                assert inst.startswith(f"ewa_periodic_rowpair_kernel<") and int(inst.split(",")[1]) == taps[t], inst
+        assert_planes_equal(got, of.get_frame(srcs[0], threads=8), f.out_dims(), what=_id(case))
+        batch = _run_batch(torch, gpu_pkg, f, gfmt, srcs, 5, 0)
+        assert f.last_kernel(0) == "ewa_periodic_rowpair_kernel"
+        for k in range(5):
+            assert_planes_equal(batch[k], of.get_frame(srcs[k], threads=8), f.out_dims(), what=_id(case) + f" frame {k}")
+        f.set_kernel_mode(gpu_pkg.KernelMode.FULL_WINDOW)
+        assert_planes_equal(f.get_frame(srcs[1]), of.get_frame(srcs[1], threads=8), f.out_dims(), what=_id(case) + " full window")
+    f.close()
+
+
 def test_c3_batch_reaches_the_benchmarked_instantiation(gpu_pkg, O):
     """Three C3 frames per call (bench.py: 32): the instantiation `bench.py --config C3` reports as roofline.kernel, every frame
     against the oracle."""
