@@ -44,9 +44,31 @@ struct SharedPin {
     bool owned = false;  // registered here (else: found pinned)
     bool dead = false;   // unregistered early because it turned out stale (see shared_pin_acquire); kept until its references are back
 };
-std::mutex g_pin_mutex;
-std::vector<SharedPin> g_pins;
-unsigned long long g_pin_next_id = 1;
+// The registry outlives every static destructor (a leaked function-local static): a host may free its filters -- and
+// with them release pins -- while the process's own statics are already being destroyed.
+struct PinRegistry {
+    std::mutex mutex;
+    std::vector<SharedPin> pins;
+    unsigned long long next_id = 1;
+};
+PinRegistry& pin_registry() {
+    static PinRegistry& r = *new PinRegistry;
+    return r;
+}
+
+// Every device idle: before a registration that instances still hold references to is unregistered early (a transport kernel
+// or an asynchronous copy of one of them may still be going through the range's device mapping).
+void quiesce_devices() {
+    int n = 0, cur = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    for (int d = 0; d < n; ++d)
+        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
 std::atomic<long long> g_frames_by_shader{0}, g_frames_by_dma{0};  // how results left the device, process-wide (test header)
 
 // A reference to a live registered range that contains [c, c + bytes), registering it if need be; false: not pinnable.
@@ -58,8 +80,8 @@ std::atomic<long long> g_frames_by_shader{0}, g_frames_by_dma{0};  // how result
 // else" only if NONE of our registrations touches it (two stale ranges under its ends with a hole between them would pass
 // the device-address probe and fault in the hole).
 bool shared_pin_acquire(char* c, size_t bytes, unsigned long long* id, char** base, size_t* len) {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (auto& e : g_pins)
+    std::lock_guard<std::mutex> lock(pin_registry().mutex);
+    for (auto& e : pin_registry().pins)
         if (!e.dead && c >= e.base && c + bytes <= e.base + e.bytes) {
             ++e.refs;
             *id = e.id, *base = e.base, *len = e.bytes;
@@ -69,9 +91,10 @@ bool shared_pin_acquire(char* c, size_t bytes, unsigned long long* id, char** ba
     if (hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
         (void)hipGetLastError();
         bool retry = false, touches_ours = false;
-        for (auto& e : g_pins) {
+        for (auto& e : pin_registry().pins) {
             if (e.dead || !e.owned) continue;
             if (c >= e.base && c < e.base + e.bytes) {  // our registration under the new range's start, not containing it: stale
+                if (e.refs > 0) quiesce_devices();  // (holders learn of it only at their next pin_host_range: nothing of theirs may still be in flight)
                 (void)hipHostUnregister(e.base);
                 (void)hipGetLastError();  // (it may already be gone with its memory: the sticky error must not meet the next launch)
                 e.dead = true;
@@ -92,25 +115,25 @@ bool shared_pin_acquire(char* c, size_t bytes, unsigned long long* id, char** ba
             owned = false;
         }
     }
-    g_pins.push_back({g_pin_next_id++, c, bytes, 1, owned, false});
-    *id = g_pins.back().id, *base = c, *len = bytes;
+    pin_registry().pins.push_back({pin_registry().next_id++, c, bytes, 1, owned, false});
+    *id = pin_registry().pins.back().id, *base = c, *len = bytes;
     return true;
 }
 
 bool shared_pin_alive(unsigned long long id) {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (const auto& e : g_pins)
+    std::lock_guard<std::mutex> lock(pin_registry().mutex);
+    for (const auto& e : pin_registry().pins)
         if (e.id == id) return !e.dead;
     return false;
 }
 
 void shared_pin_release(unsigned long long id) {
-    std::lock_guard<std::mutex> lock(g_pin_mutex);
-    for (size_t i = 0; i < g_pins.size(); ++i)
-        if (g_pins[i].id == id) {
-            if (--g_pins[i].refs > 0) return;
-            if (g_pins[i].owned && !g_pins[i].dead && hipHostUnregister(g_pins[i].base) != hipSuccess) (void)hipGetLastError();
-            g_pins.erase(g_pins.begin() + static_cast<std::ptrdiff_t>(i));
+    std::lock_guard<std::mutex> lock(pin_registry().mutex);
+    for (size_t i = 0; i < pin_registry().pins.size(); ++i)
+        if (pin_registry().pins[i].id == id) {
+            if (--pin_registry().pins[i].refs > 0) return;
+            if (pin_registry().pins[i].owned && !pin_registry().pins[i].dead && hipHostUnregister(pin_registry().pins[i].base) != hipSuccess) (void)hipGetLastError();
+            pin_registry().pins.erase(pin_registry().pins.begin() + static_cast<std::ptrdiff_t>(i));
             return;
         }
 }
@@ -448,8 +471,8 @@ void transport_counts(long long* by_shader, long long* by_dma, long long* pinned
     if (by_shader) *by_shader = g_frames_by_shader.load();
     if (by_dma) *by_dma = g_frames_by_dma.load();
     if (pinned_ranges) {
-        std::lock_guard<std::mutex> lock(g_pin_mutex);
-        *pinned_ranges = static_cast<long long>(g_pins.size());
+        std::lock_guard<std::mutex> lock(pin_registry().mutex);
+        *pinned_ranges = static_cast<long long>(pin_registry().pins.size());
     }
     if (reset) g_frames_by_shader = 0, g_frames_by_dma = 0;
 }

@@ -110,8 +110,9 @@ AVS_VideoFrame* get_frame_sync(AVS_FilterInfo* fi, Instance* inst, int n) {
 //   * frame k lives in slot k % depth for as long as it is in the window;
 //   * a served frame frees its slot; `base` moves up over served frames, and the window is refilled up to base + depth;
 //   * a frame is dropped (waited for, its references returned) only when the window moves past it: the client skipped it
-//     (SelectEven: the window trails the newest request by at most depth / 2) or jumped (a request outside the window
-//     moves the window there; frames of the old window that the new one still covers stay in flight);
+//     (SelectEven: the window trails the newest request by at most 3/4 of its depth) or jumped (a request a whole window
+//     or more away moves the window there; frames of the old window that the new one still covers stay in flight);
+//   * a request just below the window (a worker thread that lags) is served by itself and leaves the window alone;
 //   * a frame of the window that was served already and is asked for again (a cache miss upstream) is fetched again.
 // The instance mutex makes the function safe for hosts that ignore the MT mode; under MT_SERIALIZED it is uncontended.
 AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
@@ -130,13 +131,34 @@ AVS_VideoFrame* get_frame_lookahead(AVS_FilterInfo* fi, Instance* inst, int n) {
             if (p.frame >= 0 && (p.frame < base || p.frame >= base + depth)) drop(p);
         inst->base = base;
     };
+    // A request just BELOW the window: under Prefetch(N) a slower worker thread asks for a frame the window has
+    // trailed past (or served already).  Treated as a jump it moved the window back, dropped the newer frames in flight and had
+    // them computed again -- with a look-ahead below twice the host's threads the ring thrashed.  It is served out of band
+    // instead: fetched, submitted and waited for by itself, the ring untouched.  Only a request a whole window or more behind
+    // (a seek) moves the window.
+    if (n < inst->base && n > inst->base - depth) {
+        AVS_VideoFrame* src = avs_get_frame(fi->child, n);
+        if (!src) return nullptr;
+        AVS_VideoFrame* dst = avs_new_video_frame_p(fi->env, &fi->vi, src);
+        const void* sp[4];
+        void* dp[4];
+        int spitch[4], dpitch[4];
+        plane_pointers(&fi->vi, src, dst, sp, spitch, dp, dpitch);
+        long long ticket = -1;
+        if (jinc_filter_submit(inst->filter, sp, spitch, dp, dpitch, &ticket) != JINC_OK || jinc_filter_wait(inst->filter, ticket) != JINC_OK)
+            return report(fi, inst, src, dst);
+        finish_frame(fi, inst, src, dst);
+        return dst;
+    }
     if (n < inst->base || n >= inst->base + depth) {  // a jump
         move_window(n);
         inst->next_submit = n;
     } else if (slot(n).frame != n && n < inst->next_submit) {  // served before, wanted again
         inst->resubmit = n;
     }
-    if (n - inst->base > depth / 2) move_window(n - depth / 2);  // a client that skips frames: trail it, do not stall
+    // a client that skips frames: trail it, do not stall -- but only by what the look-ahead needs in front of n (a quarter of
+    // the window): frames up to 3/4 of the window behind the newest request stay in flight for the threads that lag
+    if (n - inst->base > depth - std::max(1, depth / 4)) move_window(n - (depth - std::max(1, depth / 4)));
     while (inst->base < n && slot(inst->base).frame != inst->base) ++inst->base;  // over frames served (or dropped) already
 
     auto submit = [&](int k) -> int {  // 0 ok, 1 the child has no such frame, 2 failure (reported)

@@ -87,13 +87,37 @@ const VSFrame* get_frame_lookahead(int n, Instance* d, VSFrameContext* frameCtx,
             if (p.frame >= 0 && (p.frame < base || p.frame >= base + depth)) drop(p);
         d->base = base;
     };
+    // a request just below the window (a frame that became ready late): served by itself, the window untouched (see the
+    // AviSynth shell; this context holds frame n, it asked for it in arInitial)
+    if (n < d->base && n > d->base - depth) {
+        const VSFrame* src = vsapi->getFrameFilter(n, d->node, frameCtx);
+        if (!src) {
+            vsapi->setFilterError("JincResize: the source frame is not available.", frameCtx);
+            return nullptr;
+        }
+        VSFrame* dst = vsapi->newVideoFrame(&d->vi.format, d->vi.width, d->vi.height, src, core);
+        const void* sp[4];
+        void* dp[4];
+        int spitch[4], dpitch[4];
+        plane_pointers(vsapi, d, src, dst, sp, spitch, dp, dpitch);
+        long long ticket = -1;
+        if (jinc_filter_submit(d->filter, sp, spitch, dp, dpitch, &ticket) != JINC_OK || jinc_filter_wait(d->filter, ticket) != JINC_OK) {
+            vsapi->setFilterError(jinc_last_error(), frameCtx);
+            vsapi->freeFrame(src);
+            vsapi->freeFrame(dst);
+            return nullptr;
+        }
+        if (d->chroma_location >= 0) vsapi->mapSetInt(vsapi->getFramePropertiesRW(dst), "_ChromaLocation", d->chroma_location, maReplace);
+        vsapi->freeFrame(src);
+        return dst;
+    }
     if (n < d->base || n >= d->base + depth) {
         move_window(n);
         d->next_submit = n;
     } else if (slot(n).frame != n && n < d->next_submit) {
         d->resubmit = n;
     }
-    if (n - d->base > depth / 2) move_window(n - depth / 2);
+    if (n - d->base > depth - std::max(1, depth / 4)) move_window(n - (depth - std::max(1, depth / 4)));
     while (d->base < n && slot(d->base).frame != d->base) ++d->base;
 
     auto submit = [&](int k) -> int {  // 0 ok, 1 this context does not hold frame k, 2 failure (reported)

@@ -131,6 +131,57 @@ def test_four_client_threads_through_one_lookahead_instance(host, O, pkg, case, 
     h.close()
 
 
+def test_a_lagging_requester_does_not_make_the_window_thrash(host, O, pkg, monkeypatch):
+    """requests that arrive out of order by MORE than half the look-ahead depth (a worker thread that lags: frame k
+    is asked for when the newest request is k + 6, look-ahead 8).  The request below the window is served by itself; the window is
+    not moved back, so no frame in flight is dropped and computed again: every child frame is fetched once, the lagging ones at
+    most twice, and every frame is the single-call result."""
+    lookahead, nframes, lag = 8, 64, 6
+    monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", str(lookahead))
+    monkeypatch.delenv("JINCRESIZE_GROUP", raising=False)
+    monkeypatch.delenv("JINCRESIZE_PIN_FRAMES", raising=False)
+    fmt_name, sw, sh, tw, th = "Y8", 320, 180, 640, 360
+    fmt = O.FORMATS[fmt_name]
+    single = pkg.Filter(pkg.FORMATS[fmt_name], sw, sh, tw, th, device=0)
+    h = Host(host)
+    src = host.mock_source_new(h.env, sw, sh, fmt.bits, fmt.sample_bytes, fmt.planes, 1, int(fmt.rgb), fmt.sub_w, fmt.sub_h, nframes, -1, 64)
+    want = {}
+    for n in range(nframes):
+        planes = O.lcg_frame(fmt, sw, sh, seed=61000 + n)
+        fr = host.mock_source_frame(src, n)
+        for i, p in enumerate(planes):
+            h.write_plane(fr, i, p)
+        got = single.get_frame(planes)
+        want[n] = crc_of([g[:hh, :ww] for g, (ww, hh) in zip(got, fmt.plane_dims(tw, th))])
+    single.close()
+    clip, err = h.invoke("JincResize", src, tw, th)
+    assert err is None, err
+    # the order of a fast requester and one that lags `lag` frames behind it: 0 1 2 3 4 5 | 6 0' ... every third frame belongs to
+    # the laggard and is asked for when the leader is `lag` frames ahead
+    leader = [n for n in range(nframes) if n % 3 != 2]
+    laggard = [n for n in range(nframes) if n % 3 == 2]
+    order, li = [], 0
+    for n in leader:
+        order.append(n)
+        while li < len(laggard) and laggard[li] + lag <= n:
+            order.append(laggard[li])
+            li += 1
+    order += laggard[li:]
+    assert sorted(order) == list(range(nframes)) and max(a - b for a, b in zip(order, order[1:])) >= lag
+    for n in order:
+        fr = host.mock_clip_get_frame(clip, n)
+        assert fr and host.mock_clip_error(clip) is None, (n, host.mock_clip_error(clip))
+        assert crc_of([h.read_plane(fr, 0, np.uint8)]) == want[n], f"frame {n} differs from its single-call result"
+        host.mock_frame_release(fr)
+    calls = [host.mock_source_calls_of_frame(src, n) for n in range(nframes)]
+    assert calls[0] <= 3 and max(calls[1:]) <= 2, calls                  # (frame 0: + the property probe)
+    assert sum(calls) <= nframes + len(laggard) + 2, (sum(calls), calls)  # nothing but the laggard's frames is fetched twice
+    host.mock_clip_release(clip)
+    host.mock_source_release(src)
+    assert host.mock_live_clips(h.env) == 0 and host.mock_live_frames(h.env) == 0
+    h.close()
+
+
 def test_depth_one_instances_share_the_frame_pool_and_keep_the_shader_transport(host, O, pkg, monkeypatch):
     """The reference's own shape: MT_MULTI_INSTANCE, four instances on four threads, no look-ahead.  Output frames come from
     ONE 16-buffer pool, so a buffer instance A pinned comes back to instance B: hipHostRegister refuses it there ("already
