@@ -37,6 +37,13 @@ CHECKS = [
     ("rows kernel: per-row spans and row count", "C3", 32, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
     ("direct kernel's interior on the trimmed support", "D12", 128, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
     ("quad form of the periodic kernel (single frames)", "C2", 1, {}, {"args": ["--kernel-mode", "2"]}, "window kernel"),
+    # round 5: the rows kernel in packed phase-pair form (taps 5 .. 8 at 2x), its tile shape, and the quad forms on taps 3 / 4
+    ("row-pair kernel for 12 .. 17 taps per kernel row (tap 8)", "C3", 32, {}, {"env": {"JINC_ROWS_PAIR": "0"}}, "rows kernel"),
+    ("row-pair kernel (tap 6)", "T6", 64, {}, {"env": {"JINC_ROWS_PAIR": "0"}}, "rows kernel"),
+    ("row-pair kernel, one C3 frame per call", "C3", 1, {}, {"env": {"JINC_ROWS_PAIR": "0"}}, "rows kernel"),
+    ("row-pair tile shape: the squarer tile on a tie", "C3", 32, {}, {"env": {"JINC_ROWS_PAIR": "32"}}, "128 x 32 tiles"),
+    ("quad forms, not the row-pair kernel, on 6 taps per kernel row", "C2", 64, {}, {"env": {"JINC_ROWPAIR_SMALL": "1"}}, "row-pair kernel"),
+    ("quad forms, not the row-pair kernel, on 8 taps per kernel row (float)", "C4", 16, {}, {"env": {"JINC_ROWPAIR_SMALL": "1"}}, "row-pair kernel"),
 ]
 
 
