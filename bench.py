@@ -48,7 +48,7 @@ VALU_UNFUSED_PEAK = 78.6e12  # 256 CU x 128 lanes/clk x 2.4 GHz, one IEEE op per
 CONFIGS = {
     # name: (format, src_w, src_h, dst_w, dst_h, script args, default frames per step)
     # C2 default: 1024 frames per step = twice the 512-frame clip of BASELINE.json configs[4], 10.6 GB resident in HBM;
-    # one step is then ~14 ms of kernel time, so that --steps 20 times ~0.28 s instead of 17 ms
+    # one step is then ~10 ms of kernel time, so that the default --steps 100 times ~1 s (r4 weak 13)
     "C2": ("Y8", 1920, 1080, 3840, 2160, dict(tap=3), 1024),
     # BASELINE.json configs[4]: ONE clip of 512 frames sharded over the ranks (strong scaling: the per-rank batch shrinks
     # with N); the default C2 run is the weak-scaling form of the same workload
@@ -732,7 +732,7 @@ def make_workload(pkg, torch, config, frames, device, seed, lcg_first=False):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (default 100: about 1 s of GPU time on C2; VERDICT r4: 20 steps were 0.19 s)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=0, help="frames per step per GPU (default per config)")
     ap.add_argument("--config", default="C2", help="one of CONFIGS (scripts may add entries before calling main())")
