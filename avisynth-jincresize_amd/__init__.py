@@ -27,7 +27,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JINC_LIB") or os.path.join(_HERE, "lib", "libjincresize_hip.so")  # JINC_LIB: A/B runs against another build
 SIMD_ORDER_ISA_PATH = os.path.join(_HERE, "lib", "kernel_simdorder-gfx950.s")  # the one unit with (explicit) fused multiply-adds
-ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_framelane_sub", "kernel_framelane_pair", "kernel_periodic", "kernel_rowpair", "kernel_direct", *[f"kernel_direct_walk_{t}_sx{x}" for t in ("u8", "u16", "f32") for x in (1, 2, 3, 4)], "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
+ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_framelane_sub", "kernel_framelane_pair", "kernel_periodic", "kernel_rowpair", "kernel_strip", "kernel_direct", *[f"kernel_direct_walk_{t}_sx{x}" for t in ("u8", "u16", "f32") for x in (1, 2, 3, 4)], "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
                        "kernel_quasi_exact_fs9", "kernel_quasi_lane_fs7", "kernel_quasi_lane_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
 TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip_test.h")  # introspection, knobs, hooks
@@ -85,7 +85,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error",
-           "jinc_filter_last_instance", "jinc_debug_last_instance", "jinc_debug_set_knob", "jinc_debug_clear_knob", "jinc_debug_get_knob", "jinc_debug_knob_name"]
+           "jinc_filter_last_instance", "jinc_filter_last_border", "jinc_debug_last_instance", "jinc_debug_set_knob", "jinc_debug_clear_knob", "jinc_debug_get_knob", "jinc_debug_knob_name"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -164,6 +164,7 @@ def lib():
         L.jinc_batch_last_error.restype = C.c_char_p
         L.jinc_filter_last_instance.argtypes = [C.c_void_p, C.c_int]
         L.jinc_filter_last_instance.restype = C.c_char_p
+        L.jinc_filter_last_border.argtypes = [C.c_void_p, C.c_int]
         L.jinc_debug_last_instance.restype = C.c_char_p
         L.jinc_debug_set_knob.argtypes = [C.c_int, C.c_double]
         L.jinc_debug_clear_knob.argtypes = [C.c_int]
@@ -629,6 +630,10 @@ class Filter:
     def last_kernel(self, table: int = 0) -> str:
         """Interior kernel of the most recent frame call (depends on the batch size)."""
         return lib().jinc_filter_last_kernel(self._h, int(table)).decode()
+
+    def last_border(self, table: int = 0) -> int:
+        """Border kernels of the most recent frame call as bits (test header: jinc_filter_last_border)."""
+        return int(lib().jinc_filter_last_border(self._h, int(table)))
 
     def last_instance(self, table: int = 0) -> str:
         """... with its template arguments, as rocprofv3 names it (the periodic family; the plain name otherwise)."""

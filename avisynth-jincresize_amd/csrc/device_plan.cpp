@@ -578,6 +578,54 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     }
     t.strips_ok = uniform;
 
+    // kernel_strip.hip (round 5): the strips of filter sizes up to 9 at source step 1 with one register window per lane.  A group
+    // = consecutive border lines that share their window origin across the strip (all of them, for the plans seen: the reference
+    // shifts every border window back to the image's first / last fs lines, ref :395-418); at most four groups per orientation.
+    t.use_strip_rows = t.use_strip_cols = false;
+    if (uniform) {
+        auto build = [&](int axis, jinc::StripArgs& sa) -> bool {
+            const bool rows = axis == 0;
+            const int P = rows ? p.px : p.py, S = rows ? p.sx : p.sy;
+            sa = jinc::StripArgs{};
+            sa.coeffs = t.plan.coeffs;
+            sa.fs = p.fs, sa.axis = axis, sa.P = P, sa.S = S;
+            sa.i0 = rows ? p.ix0 : p.iy0;
+            sa.ni = rows ? da.ni : da.nj;
+            int lo = INT32_MAX, hi = INT32_MIN;
+            for (int k = 0; k < P; ++k) {
+                sa.start[k] = rows ? da.start_x[k] : da.start_y[k];
+                lo = std::min(lo, sa.start[k]), hi = std::max(hi, sa.start[k]);
+            }
+            sa.min_start = lo, sa.spread = hi - lo;
+            if (P > 16 || !jinc::strip_supported(p.fs, P, S, sa.spread)) return false;
+            sa.src_w = p.g.src_w, sa.src_h = p.g.src_h, sa.dst_h = p.g.dst_h;
+            const std::vector<int32_t>& origin_of = rows ? p.row_start : p.col_start;
+            const int ends[2][2] = {{0, rows ? p.iy0 : p.ix0}, {rows ? y_end : x_end, rows ? H : W}};
+            std::vector<int32_t> sets;
+            for (const auto& e : ends)
+                for (int l = e[0]; l < e[1];) {
+                    int m = l;
+                    while (m < e[1] && origin_of[static_cast<size_t>(m)] == origin_of[static_cast<size_t>(l)]) ++m;
+                    if (sa.ngroups == 4) return false;
+                    const int g = sa.ngroups++;
+                    sa.line0[g] = l, sa.nlines[g] = m - l, sa.origin[g] = origin_of[static_cast<size_t>(l)];
+                    sa.set_base[g] = static_cast<int>(sets.size()) / P;
+                    for (int line = l; line < m; ++line)
+                        for (int k = 0; k < P; ++k) sets.push_back(rows ? p.set_of(p.ix0 + k, line) : p.set_of(line, p.iy0 + k));
+                    l = m;
+                }
+            if (sa.ngroups == 0) return false;
+            void* dev = nullptr;
+            hip_check(hipMalloc(&dev, sets.size() * sizeof(int32_t)), "hipMalloc(strip sets)");
+            t.lane_blobs.push_back(dev);  // freed with the table
+            hip_check(hipMemcpy(dev, sets.data(), sets.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip set upload");
+            sa.sets = static_cast<const int32_t*>(dev);
+            return true;
+        };
+        t.use_strip_rows = build(0, t.strip_rows);
+        t.use_strip_cols = build(1, t.strip_cols);
+    }
+
     for (int q = 0; q < p.py; ++q)
         for (int r = 0; r < p.px; ++r)
             da.set[q * p.px + r] = p.interior_set[static_cast<size_t>(p.row_class[p.iy0 + q]) * p.n_col_classes +

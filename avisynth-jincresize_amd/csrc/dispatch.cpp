@@ -369,7 +369,7 @@ struct Choice {
     // kernel over the frame's four rectangles.  The strips are the leaner kernels (C3 at 32 frames: +11 %), but below ~5e9 taps per
     // call their launches cost more than they save (round3/border_strips_ab.txt, one frame per call: C2 122 -> 183 Gpix/s, C1 15.7 ->
     // 25.4, 1080p -> 4K 4:2:0 49 -> 74, 4K -> 1080p 27.7 -> 45, C3 24 -> 31; four frames: C2 346 -> 412, C1 59 -> 93; level from 3e9 ..
-    // 7e9 taps on; tap 16 at 9e9 taps: -30 %).  f.border_strips: -1 this rule, 1 / 2 / 0 forced (tests, A/B).
+    // 7e9 taps on; tap 16 at 9e9 taps: -30 %).  f.border_strips: -1 this rule, 1 / 2 / 3 / 0 forced (tests, A/B; 3 = ewa_strip_kernel where configured).
     bool wants_border_strips() const {
         if (f.border_strips >= 0) return f.border_strips != 0;
         double taps = 0.0;
@@ -556,7 +556,18 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             // frames, so a border pixel's private coefficient set is a scalar load and the taps run from registers -- the
             // column-strip kernel reads LDS once per tap (C2 at 1024 frames: knob FL_COLS_FRAMES A/B, round4/fl_cols_ab.log).
             const int fl_cols_min_frames = knobs::geti(JINC_KNOB_FL_COLS_FRAMES, Rules::kFlColsMinFrames);  // A/B knob: 0 = never
-            const bool fl_cols = t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
+            // Round 5: kernel_strip.hip takes the rows and the columns of filter sizes up to 9 (knob STRIP_LDS = 0: the kernels
+            // below as before; kernel mode 3 and a forced border form keep them too, for the tests that compare the forms).  The
+            // corners then stay with the gather kernel.
+            // Rows: always (C2 at 1024 frames per call: 0.134 against 0.184 ms on ewa_direct_kernel's row strips).  Columns: below the
+            // batch size from which the frame-lane kernel takes them (it stays ahead there: 0.283 ms, corners included, against
+            // 0.300 + corners) -- i.e. instead of ewa_colstrip_kernel.  Knob STRIP_LDS: 1 = this rule, 2 = rows and columns always.
+            const int lds_knob = knobs::geti(JINC_KNOB_STRIP_LDS, 1);
+            const bool lds_strips = f.border_strips == 3 || (lds_knob != 0 && f.border_strips < 0 && f.kernel_mode != 3);
+            const bool strip_rows = lds_strips && t.use_strip_rows;
+            const bool strip_cols = lds_strips && t.use_strip_cols &&
+                                    (f.border_strips == 3 || lds_knob == 2 || !(t.use_fl_cols && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames));
+            const bool fl_cols = !strip_cols && t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
                                  (f.kernel_mode == 0 || f.kernel_mode == 13 || f.kernel_mode == 2);
             if (fl_cols) {
                 auto aligned_to = [&](uintptr_t bytes) {
@@ -573,7 +584,16 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 else
                     timed(f.ev_gather, border_stream, "border column frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             }
-            const bool colstrip = !fl_cols && t.use_colstrip && f.border_strips != 2;
+            t.last_border = (strip_rows ? 16 : 2) | (strip_cols ? 32 : fl_cols ? 8 : (t.use_colstrip && f.border_strips != 2) ? 4 : 1);
+            if (strip_cols || strip_rows) {
+                if (t.corner_rects.n > 0 && strip_cols)
+                    timed(f.ev_gather, border_stream, "corner kernel launch", [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
+                if (strip_rows)
+                    timed(f.ev_gather, border_stream, "border row strip launch", [&](hipStream_t s) { return jinc::launch_strip(t.strip_rows, io, s); });
+                if (strip_cols)
+                    timed(f.ev_gather, border_stream, "border column strip launch", [&](hipStream_t s) { return jinc::launch_strip(t.strip_cols, io, s); });
+            }
+            const bool colstrip = !strip_cols && !fl_cols && t.use_colstrip && f.border_strips != 2;
             // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
             // last it would start when the interior kernel already holds every wave slot.  (Measured again in round 3 with
             // the corners last: no difference on any of eight configurations -- in a long batch the border kernels cost their
@@ -581,16 +601,18 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             if (colstrip && t.corner_rects.n > 0)
                 timed(f.ev_gather, border_stream, "corner kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
-            timed(f.ev_gather, border_stream, "border row kernel launch",
-                  [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
+            if (!strip_rows)
+                timed(f.ev_gather, border_stream, "border row kernel launch",
+                      [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
             if (colstrip) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
-            } else if (!fl_cols && t.column_rects.n > 0) {
+            } else if (!fl_cols && !strip_cols && t.column_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
             }
         } else {
+            t.last_border = 1;
             drifting_border();  // (use_fl_border is set for drifting plans only: the others keep the gather kernel here)
         }
         if (direct)

@@ -581,13 +581,18 @@ const char* jinc_debug_last_call(int* nframes) {
     return last_interior_kernel_in_process();
 }
 
+int jinc_filter_last_border(const jinc_filter* f, int table) {
+    if (!f || f->device < 0 || table < 0 || table >= static_cast<int>(f->tables.size())) return 0;
+    return f->tables[table].last_border;
+}
+
 const char* jinc_debug_last_instance(void) { return last_interior_instance_in_process(); }
 
 int jinc_filter_direct_premise(const jinc_filter* f) { return (f && f->device >= 0) ? (f->direct_premise ? 1 : 0) : -1; }
 
 int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
-    f->border_strips = enable < 0 ? -1 : enable > 2 ? 1 : enable;  // -1: by call size; 2: rows as strips, columns on the gather kernel
+    f->border_strips = enable < 0 ? -1 : enable > 3 ? 1 : enable;  // -1: by call size; 2: rows as strips, columns on the gather kernel; 3: ewa_strip_kernel
     g_last_error.clear();
     return JINC_OK;
 }

@@ -70,12 +70,16 @@ struct DeviceTable {
     jinc::RectList column_rects;  // otherwise: left / right columns, full height, on the gather kernel
     bool use_fl_cols = false;     // ... or, in batches, on the frame-lane kernel (lanes = frames: every pixel's set is a scalar load)
     jinc::FrameLaneArgs fl_cols;
+    // ... or (round 5, filter sizes up to 9, source step 1) on kernel_strip.hip: one register window per lane for the strip's thickness
+    bool use_strip_rows = false, use_strip_cols = false;
+    jinc::StripArgs strip_rows, strip_cols;
     std::vector<void*> lane_blobs;  // lane-major coefficient copies of the private-set rectangles (RectList::lane_coeffs)
     jinc::RectList whole;         // gather work when it does not
     bool use_framelane = false;   // frame-lane kernel configured for the whole plane (batches of frames, any plan)
     jinc::FrameLaneArgs fl_whole;
     bool use_framelane_pair = false;  // ... and its frame-pair form (128 frames per workgroup; filter sizes 5 and 7)
     jinc::FrameLaneArgs fl_pair;
+    int last_border = 0;           // border kernels of the most recent call (test header: jinc_filter_last_border)
     const char* last_kernel = "";  // interior kernel of the most recent call (reports)
     std::string last_instance;     // ... with its template arguments where the launcher chooses between instantiations (knobs.h note_instance)
 };

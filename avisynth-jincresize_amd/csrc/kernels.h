@@ -296,6 +296,24 @@ int launch_gather(const DevicePlan& plan, const PlaneIO& io, const RectList& rec
 bool periodic_supported(int fs, int px, int py, int sx, int sy);
 // variant: 0 = default choice per filter size, 1 = always the row-streamed kernel (A/B measurements)
 int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* stream, int variant = 0);
+// kernel_strip.hip: border rows (axis 0: lanes along x) or border columns (axis 1: lanes along y) of an exactly periodic plan,
+// one register window per lane for the strip's whole thickness.  A group = the lines (output rows | columns) of one strip: they
+// share the source lines [origin, origin + fs) across the strip; along the strip output coordinate i0 + P * i + p reads the
+// window at start[p] + i (source step 1) and line `l` of group g uses coefficient set sets[(set_base[g] + l) * P + p].
+struct StripArgs {
+    const float* coeffs = nullptr;
+    const int32_t* sets = nullptr;  // device
+    int fs = 0, axis = 0;
+    int P = 1, S = 1;
+    int i0 = 0, ni = 0;
+    int start[16] = {0};
+    int min_start = 0, spread = 0;
+    int ngroups = 0;
+    int line0[4] = {0, 0, 0, 0}, nlines[4] = {0, 0, 0, 0}, origin[4] = {0, 0, 0, 0}, set_base[4] = {0, 0, 0, 0};
+    int src_w = 0, src_h = 0, dst_h = 0;
+};
+bool strip_supported(int fs, int period, int step, int spread);
+int launch_strip(const StripArgs& args, const PlaneIO& io, void* stream);
 // kernel_rowpair.hip: the row-streamed kernel in packed phase-pair form (PeriodicArgs::rowpair; 12 .. 17 taps per kernel row)
 bool rowpair_supported(int taps_per_row);
 int launch_rowpair(const PeriodicArgs& args, const PlaneIO& io, void* stream);

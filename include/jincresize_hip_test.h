@@ -135,6 +135,7 @@ typedef enum jinc_knob {
     JINC_KNOB_BORDER_ROWS4,           /* 0: border row strips one output row per wave */
     JINC_KNOB_GATHER_SORTED,          /* 0: single frames of plans without affine origins on the unsorted gather kernel */
     JINC_KNOB_ROWPAIR_SMALL,          /* 1 / 0: ewa_periodic_rowpair_kernel on 6 .. 9 taps per kernel row always / never (unset: by rule) */
+    JINC_KNOB_STRIP_LDS,              /* 0: border rows / columns of periodic plans on the round-4 kernels instead of ewa_strip_kernel */
     JINC_KNOB_COUNT
 } jinc_knob;
 JINC_API int jinc_debug_set_knob(int knob, double value);
@@ -185,9 +186,15 @@ JINC_API const char *jinc_debug_last_instance(void);
  * drive the plugin shell: several instances that share the host's frame pool must all keep the shader path. */
 JINC_API int jinc_debug_transport_counts(long long *by_shader, long long *by_dma, long long *pinned_ranges, int reset);
 /* Border frame of exactly periodic plans: -1 (default) = by call size (strip kernels from ~5e9 taps per call on, one gather
- * launch below); 1 = rows and columns on the strip kernels, corners on the gather kernel; 2 = rows on the strip kernel,
- * columns and corners on the gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */
+ * launch below); 1 = rows and columns on the round-4 strip kernels (ewa_direct_kernel's row strips, ewa_colstrip_kernel or, in batches,
+ * the frame-lane kernel), corners on the gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel;
+ * 3 = rows and columns on ewa_strip_kernel (round 5; filter sizes up to 9 at source step 1: the automatic choice there), corners on
+ * the gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */
 JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
+/* Which kernels computed the border frame of `table` in the most recent frame call, as bits: 1 gather kernel over the frame (or its
+ * columns), 2 ewa_direct_kernel row strips, 4 ewa_colstrip_kernel, 8 frame-lane kernel over the columns, 16 / 32 ewa_strip_kernel
+ * over the rows / the columns; 0: no border launch recorded (plans whose border is not a strip frame). */
+JINC_API int jinc_filter_last_border(const jinc_filter *f, int table);
 /* 1: the border kernels run on a side stream concurrently with the interior kernel (fork/join by events around
  * every call); 0: all on the caller's stream, back to back; -1 (default): the side stream unless the call is so small
  * (below ~1e9 taps) that the fork/join costs more than it hides. */

@@ -500,7 +500,7 @@ STRIP_CASES = [
 ]
 
 
-@pytest.mark.parametrize("strips", [1, 2, 0], ids=["strips", "row_strips_only", "gather_border"])
+@pytest.mark.parametrize("strips", [1, 2, 3, 0], ids=["strips", "row_strips_only", "strip_kernel", "gather_border"])
 @pytest.mark.parametrize("case", STRIP_CASES, ids=_id)
 def test_border_strips_and_gather_border_agree_with_oracle(gpu_pkg, O, case, strips):
     """The border frame of exactly periodic plans runs as row/column strips on ewa_direct_kernel (+ corners on the
@@ -692,8 +692,9 @@ def test_randomised_arguments(gpu_pkg, O, seed, gen):
     # with a tile's phases split over several workgroups (what small calls do in automatic mode).
     # exactly periodic plans: the strip kernels over the border frame, which calls of this size no longer take by themselves
     if any(f.plan_info(t).periodic for t in range(f.num_tables)):
-        f.set_border_strips(1)
-        assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + " border strips")
+        for strips in (1, 3):   # the round-4 strip kernels; ewa_strip_kernel (round 5) where the plan has it
+            f.set_border_strips(strips)
+            assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + f" border strips {strips}")
         f.set_border_strips(-1)
         # the periodic family on the trimmed support (integer planes) in each of its forms -- window, rows, quad -- and on the
         # reference's full window (15)

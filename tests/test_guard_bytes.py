@@ -31,7 +31,9 @@ def test_nothing_outside_the_rows_is_written(gpu_pkg, O, case, pad):
     sdims, ddims = ofmt.plane_dims(sw, sh), f.out_dims()
     frame = O.lcg_frame(ofmt, sw, sh, seed=99)
     sb = frame[0].dtype.itemsize
-    for n in sizes:
+    # every batch size under the automatic border form and, for exactly periodic plans, with ewa_strip_kernel forced (round 5)
+    for n, strips in [(n, st) for n in sizes for st in ((-1, 3) if f.plan_info(0).periodic else (-1,))]:
+        f.set_border_strips(strips)
         # source: frames of a plane back to back, pitch = row bytes rounded up to 4
         sp = [(w * sb + 3) // 4 * 4 for (w, h) in sdims]
         sfs = [p * h for p, (w, h) in zip(sp, sdims)]
