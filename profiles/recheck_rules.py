@@ -44,6 +44,9 @@ CHECKS = [
     ("row-pair tile shape: the squarer tile on a tie", "C3", 32, {}, {"env": {"JINC_ROWS_PAIR": "32"}}, "128 x 32 tiles"),
     ("quad forms, not the row-pair kernel, on 6 taps per kernel row", "C2", 64, {}, {"env": {"JINC_ROWPAIR_SMALL": "1"}}, "row-pair kernel"),
     ("quad forms, not the row-pair kernel, on 8 taps per kernel row (float)", "C4", 16, {}, {"env": {"JINC_ROWPAIR_SMALL": "1"}}, "row-pair kernel"),
+    ("border rows on ewa_strip_kernel", "C2", 1024, {}, {"env": {"JINC_STRIP_LDS": "0"}}, "ewa_direct_kernel row strips"),
+    ("border columns stay on the frame-lane kernel in batches", "C2", 1024, {}, {"env": {"JINC_STRIP_LDS": "2"}}, "ewa_strip_kernel columns"),
+    ("border columns on ewa_strip_kernel below the frame-lane threshold", "C2", 8, {}, {"env": {"JINC_STRIP_LDS": "0"}}, "column-strip kernel"),
 ]
 
 
