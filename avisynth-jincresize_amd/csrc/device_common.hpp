@@ -42,6 +42,16 @@ __device__ __forceinline__ uint32_t round_sample(float r, float peak) {
 // tests/test_gpu_parity.py::test_integer_conversion_ties checks ties, bounds and specials on the device.
 __device__ __forceinline__ uint32_t round_sample_u8(float r) { return __builtin_amdgcn_cvt_pk_u8_f32(r, 0u, 0u); }
 
+// Two 9 ... 16-bit samples as one dword, (a) in the low half: clamp as round_sample, then round-half-even by adding 2^23 -- the
+// sum of a value in [0, 65535] and 8388608.0f has an ulp of 1, so its low mantissa bits ARE the sample rounded to nearest, ties to
+// even (2^23 is even: the tie rule of the sum is the tie rule of the sample) -- and v_perm_b32 picks the two low halves: five
+// instructions per pair against seven (v_med3, v_rndne, v_cvt_u32 each and a v_lshl_or).  The same value as round_sample for every
+// input (NaN: v_med3 returns 0 first); tests/test_gpu_parity.py::test_integer_conversion_ties runs both forms over ties and bounds.
+__device__ __forceinline__ uint32_t round_pair_u16(float a, float b, float peak) {
+    const float ca = __builtin_amdgcn_fmed3f(a, 0.f, peak) + 8388608.0f, cb = __builtin_amdgcn_fmed3f(b, 0.f, peak) + 8388608.0f;
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, cb), __builtin_bit_cast(uint32_t, ca), 0x05040100u);
+}
+
 template <typename T>
 __device__ __forceinline__ T convert_sample(float r, float peak) {
     if constexpr (std::is_same_v<T, float>)

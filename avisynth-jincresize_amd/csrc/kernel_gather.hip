@@ -319,6 +319,14 @@ __global__ void convert_kernel(const float* in, T* out, int n, float peak) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const BufferRsrc rsrc = make_rsrc(out, static_cast<uint32_t>(n) * sizeof(T));
+    if constexpr (std::is_same_v<T, uint16_t>) {  // the packed-pair kernels' path (round_pair_u16): elements 4k + 2 and 4k + 3 as one dword
+        if ((i & 3) == 2 && i + 1 < n) {
+            const uint32_t v = round_pair_u16(in[i], in[i + 1], peak);
+            out[i] = static_cast<uint16_t>(v), out[i + 1] = static_cast<uint16_t>(v >> 16);
+            return;
+        }
+        if ((i & 3) == 3) return;
+    }
     if (i & 1)
         store_sample_buf<T>(rsrc, static_cast<uint32_t>(i) * sizeof(T), 0u, in[i], peak);  // periodic kernels' path
     else

@@ -163,7 +163,7 @@ __device__ __forceinline__ void store_pair_buf(BufferRsrc rsrc, uint32_t voffset
         w = __builtin_amdgcn_cvt_pk_u8_f32(r.y, 1u, w);
         __builtin_amdgcn_raw_buffer_store_b16(static_cast<uint16_t>(w), rsrc, voffset, soffset, 0);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b32(round_sample(r.x, peak) | (round_sample(r.y, peak) << 16), rsrc, voffset, soffset, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(round_pair_u16(r.x, r.y, peak), rsrc, voffset, soffset, 0);
     }
 }
 
@@ -1113,9 +1113,9 @@ __device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset
         else __builtin_amdgcn_raw_buffer_store_b16(static_cast<uint16_t>(w), rsrc, voffset, soffset, 0);
     } else {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        const uint32_t lo = round_sample(a.x, peak) | (round_sample(a.y, peak) << 16);
+        const uint32_t lo = round_pair_u16(a.x, a.y, peak);
         if (b_ok) {
-            const u32x2 v = {lo, round_sample(b.x, peak) | (round_sample(b.y, peak) << 16)};
+            const u32x2 v = {lo, round_pair_u16(b.x, b.y, peak)};
             __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, voffset, soffset, 0);
         } else {
             __builtin_amdgcn_raw_buffer_store_b32(lo, rsrc, voffset, soffset, 0);

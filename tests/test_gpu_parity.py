@@ -280,7 +280,8 @@ def test_many_instances_share_a_device(gpu_pkg, O):
 
 
 def test_integer_conversion_ties(gpu_pkg):
-    """The device conversion (v_cvt_pk_u8_f32 for 8-bit, med3 + rndne + cvt for 9..16-bit) against
+    """The device conversion (v_cvt_pk_u8_f32 for 8-bit; med3 + rndne + cvt for 9..16-bit and, in the packed-pair kernels, med3 +
+    the 2^23 sum + v_perm: the hook runs every fourth element pair through that form) against
     clamp(r, 0, peak) + lrintf (ref :581-582): every tie k + 0.5, both clamp bounds, values just around
     ties, huge values, infinities, NaN (-> 0 on both sides) and negative zero."""
     for dtype, peak in ((np.uint8, 255.0), (np.uint16, 1023.0), (np.uint16, 4095.0), (np.uint16, 65535.0)):
@@ -295,9 +296,11 @@ def test_integer_conversion_ties(gpu_pkg):
             np.random.default_rng(0).uniform(-5, peak + 5, 5000),
         ]).astype(np.float32)
         want = np.rint(np.clip(vals, np.float32(0), np.float32(peak))).astype(dtype)
-        got = gpu_pkg.debug_convert(vals, dtype, peak)
-        assert np.array_equal(got, want), (dtype, peak, vals[got != want][:8], got[got != want][:8], want[got != want][:8])
-        assert gpu_pkg.debug_convert(np.array([np.nan, np.nan], np.float32), dtype, peak).tolist() == [0, 0]
+        for shift in range(4):   # every value through every form of the hook (which form an element takes goes by its index mod 4)
+            v, w = np.roll(vals, shift), np.roll(want, shift)
+            got = gpu_pkg.debug_convert(v, dtype, peak)
+            assert np.array_equal(got, w), (dtype, peak, shift, v[got != w][:8], got[got != w][:8], w[got != w][:8])
+        assert gpu_pkg.debug_convert(np.array([np.nan] * 8, np.float32), dtype, peak).tolist() == [0] * 8
     f = np.array([1.5, -2.25, np.inf, 1e-41, -0.0], np.float32)
     assert np.array_equal(gpu_pkg.debug_convert(f, np.float32, 0.0).view(np.uint32), f.view(np.uint32))
 
