@@ -43,19 +43,73 @@ __global__ __launch_bounds__(kStripLanes) void ewa_strip_kernel(const StripArgs 
     constexpr int along = Cfg::kAlong, pitch = Cfg::kPitch;
     const int a0 = a.min_start + i_first;                            // source position of staged word 0 along the strip
     const int origin = a.origin[g];                                  // first source line across the strip
-    {   // stage: word [k][m] = source(line origin + k across, position a0 + m along), clamped to the plane like every kernel's halo
+    {   // stage: word [k][m] = source(line origin + k across, position a0 + m along), clamped to the plane like every kernel's halo;
+        // all loads in front of the LDS writes
         const char* sbase = static_cast<const char*>(io.src) + frame * io.src_frame_stride;
-        constexpr int n = FS * along;
+        if constexpr (AXIS == 0) {
+            constexpr int n = FS * along, kPer = (n + kStripLanes - 1) / kStripLanes;
+            T staged[kPer];
 #pragma unroll
-        for (int e0 = 0; e0 < n; e0 += kStripLanes) {
-            const int e = e0 + lane;
-            if (e >= n) break;
-            const int k = e / along, m = e - k * along;
-            int across = origin + k, pos = a0 + m;
-            int gx = AXIS == 0 ? pos : across, gy = AXIS == 0 ? across : pos;
-            gx = gx < a.src_w ? gx : a.src_w - 1;
-            gy = gy < a.src_h ? gy : a.src_h - 1;
-            strip_lds[k * pitch + m] = to_float(reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch)[gx]);
+            for (int r = 0; r < kPer; ++r) {
+                const int e = min(r * kStripLanes + lane, n - 1);
+                const int k = e / along, m = e - k * along;
+                int gx = a0 + m, gy = origin + k;
+                gx = gx < a.src_w ? gx : a.src_w - 1;
+                gy = gy < a.src_h ? gy : a.src_h - 1;
+                staged[r] = reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch)[gx];
+            }
+#pragma unroll
+            for (int r = 0; r < kPer; ++r) {
+                const int e = r * kStripLanes + lane;
+                if (e < n) strip_lds[(e / along) * pitch + (e % along)] = to_float(staged[r]);
+            }
+        } else {
+            // column strips: a lane takes whole source ROWS -- the fs samples of a row are one cache line, fetched with vector loads of
+            // four samples (the last one overlapping: every load stays inside [origin, origin + fs)) instead of fs single samples by fs
+            // different lanes: a third of the first form's requests, each row's line asked for once
+            typedef T T4 __attribute__((ext_vector_type(4)));
+            constexpr int kPer = (along + kStripLanes - 1) / kStripLanes;  // rows per lane (2: the second pass holds the halo)
+            constexpr int kVec = (FS + 3) / 4;
+            T4 staged[kPer][kVec];
+            const BufferRsrc srsrc = make_rsrc(const_cast<char*>(sbase), static_cast<uint32_t>(io.src_pitch) * static_cast<uint32_t>(a.src_h - 1) +
+                                                                             static_cast<uint32_t>(a.src_w) * static_cast<uint32_t>(sizeof(T)));
+#pragma unroll
+            for (int r = 0; r < kPer; ++r) {
+                int gy = a0 + min(r * kStripLanes + lane, along - 1);
+                gy = gy < a.src_h ? gy : a.src_h - 1;
+                // raw buffer loads: one request of 4 / 8 / 2 x 8 bytes per four samples at any alignment (through a pointer the
+                // compiler splits a 2-byte-aligned vector into single samples)
+                const uint32_t rowoff = static_cast<uint32_t>(gy) * static_cast<uint32_t>(io.src_pitch) + static_cast<uint32_t>(origin) * static_cast<uint32_t>(sizeof(T));
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    const int k0 = 4 * v + 4 <= FS ? 4 * v : FS - 4;  // (origin + fs <= src_w: host)
+                    const uint32_t off = rowoff + static_cast<uint32_t>(k0 * sizeof(T));
+                    if constexpr (sizeof(T) == 1) {
+                        staged[r][v] = __builtin_bit_cast(T4, __builtin_amdgcn_raw_buffer_load_b32(srsrc, off, 0, 0));
+                    } else if constexpr (sizeof(T) == 2) {
+                        staged[r][v] = __builtin_bit_cast(T4, __builtin_amdgcn_raw_buffer_load_b64(srsrc, off, 0, 0));
+                    } else {
+                        // (single dwords: the compiler merges two 8-byte loads into one of 16 bytes, which at a 4-byte boundary does not
+                        // return its dwords where they belong -- as the 16-byte stores of kernel_periodic.hip)
+                        staged[r][v] = T4{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srsrc, off, 0, 0)),
+                                          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srsrc, off + 4u, 0, 0)),
+                                          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srsrc, off + 8u, 0, 0)),
+                                          __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(srsrc, off + 12u, 0, 0))};
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kPer; ++r) {
+                const int m = r * kStripLanes + lane;
+                if (m < along) {
+#pragma unroll
+                    for (int k = 0; k < FS; ++k) {
+                        const int v = k / 4 < kVec - 1 || FS % 4 == 0 ? k / 4 : kVec - 1;
+                        const int k0 = 4 * v + 4 <= FS ? 4 * v : FS - 4;
+                        strip_lds[k * pitch + m] = to_float(staged[r][v][k - k0]);
+                    }
+                }
+            }
         }
     }
     __syncthreads();
