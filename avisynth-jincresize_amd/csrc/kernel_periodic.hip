@@ -1745,17 +1745,15 @@ int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* s
     if (args.ni <= 0 || args.nj <= 0 || io.nframes <= 0) return 0;
     // 2x up-scales with 12 .. 17 taps per kernel row: the rows kernel's packed phase-pair form (kernel_rowpair.hip) wherever the
     // plan carries its coefficient pairs; variant 1 (kernel mode 3) and the knob ROWS_PAIR = 0 keep ewa_periodic_rows_kernel
-    // Short kernel rows (6 .. 9 taps: taps 3 and 4, where the window and quad forms are the choice): by the knob ROWPAIR_SMALL
-    // (1: wherever the plan carries the pairs and no A/B variant of the other kernels is asked for; 0: never) or, unset, by the
-    // measured rule of dispatch.cpp (variant 8).
+    // Short kernel rows (6 .. 9 taps: taps 3 and 4) stay with the window and quad forms, which measure ahead there (C2 847 : 816
+    // Gpix/s, C4 152 : 139; profiles/round5/rowpair_small_ab.log); the knob ROWPAIR_SMALL = 1 puts them on the pair form wherever
+    // the plan carries the pairs and no A/B variant of the other kernels is asked for.
     if (args.rowpair && knobs::flag(JINC_KNOB_ROWS_PAIR, true)) {
         const int taps = args.quad_taps ? args.quad_taps : fs;  // (6 rows x 7 columns: fs = 6 rows, 7 taps per row)
-        const int small = knobs::geti(JINC_KNOB_ROWPAIR_SMALL, -1);
         const bool auto_variant = variant == 0 || variant == 2 || variant == 5 || variant == 6 || variant == 7;
-        if (args.rowpair_n == taps && ((fs >= 10 && variant == 0) || (fs < 10 && ((small == 1 && auto_variant) || (small != 0 && variant == 8)))))
+        if (args.rowpair_n == taps && ((fs >= 10 && variant == 0) || (fs < 10 && auto_variant && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) == 1)))
             return launch_rowpair(args, io, stream);
     }
-    if (variant == 8) variant = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (io.sample_bytes) {
         case 1: return launch_periodic_fs<uint8_t>(args, fs, io, s, variant);

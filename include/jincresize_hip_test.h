@@ -130,7 +130,7 @@ typedef enum jinc_knob {
     JINC_KNOB_DIRECT_SHAPE,           /* as jinc_debug_set_direct_shape */
     JINC_KNOB_GATHER_PASSES,
     JINC_KNOB_ROWS_PAIR,              /* 0: rows kernel instead of its packed phase-pair form (round 5); 64 / 32 / 16: that tile shape */
-    JINC_KNOB_ROWPAIR_SMALL,          /* 1 / 0: ewa_periodic_rowpair_kernel on 6 .. 9 taps per kernel row always / never (unset: by rule) */
+    JINC_KNOB_ROWPAIR_SMALL,          /* 1: ewa_periodic_rowpair_kernel also on 6 .. 9 taps per kernel row (default: the window / quad forms there) */
     JINC_KNOB_STRIP_LDS,              /* 0: border rows / columns of periodic plans on the round-4 kernels; 1 (default): ewa_strip_kernel by rule; 2: rows and columns on it always */
     JINC_KNOB_COUNT
 } jinc_knob;
