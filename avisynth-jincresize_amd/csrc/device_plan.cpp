@@ -636,6 +636,63 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     if (!t.strips_ok) t.border_rects.private_sets = t.border_rects.unit_stride = true;  // coefficients per lane
 }
 
+// Border columns inside the interior kernel (ewa_periodic_quad2_kernel, integer planes): the columns left and right of the
+// interior, interior rows only (the corners stay with the corner kernel), are computed by the first and the last tile column of the
+// interior launch from the source tile it has staged anyway.  As kernels of their own these 7 + 5 columns of C2 cost 0.28 ms of a
+// 9.8 ms step -- 4.4 M scattered 64-byte lines per launch (profiles/round5/strip_ab.log) -- for 0.05 ms worth of arithmetic.
+// What has to hold (checked here, not assumed): the strips repeat their sets with the interior's period (strips_ok), every column of a
+// side has ONE window origin whose fs columns lie in the edge tile (or one column in front of it), and the sets' kernel rows outside
+// the interior's six trimmed rows are zero (the columns share the interior's row phases, so they are for the plans seen).
+void plan_edge_columns(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
+    t.use_edge_cols = false;
+    t.edge_cols = jinc::PeriodicArgs::EdgeColumns{};
+    if (!integer_samples || !t.use_periodic || !t.use_direct || !t.strips_ok || t.trim_fs != 6 || !t.periodic_trim.quad || p.fs != 7) return;
+    const jinc::PeriodicArgs& pa = t.periodic_trim;
+    if (pa.px != 2 || pa.py != 2 || pa.start_y[0] != pa.start_y[1] || pa.start_x[0] != pa.start_x[1]) return;
+    const int fs = p.fs, r0 = pa.min_sy - t.periodic.min_sy;
+    if (r0 < 0 || r0 + 6 > fs) return;
+    const int x_end = pa.ix0 + 2 * pa.ni, W = p.g.dst_w;
+    constexpr int kTileCols = 128, kLdsCols = 134;  // Quad2Cfg (kernel_periodic.hip)
+    jinc::PeriodicArgs::EdgeColumns e;
+    std::vector<float> blob(static_cast<size_t>(2) * 8 * 2 * 48, 0.f);
+    const int side_x0[2] = {0, x_end}, side_n[2] = {pa.ix0, W - x_end};
+    bool any = false;
+    for (int s = 0; s < 2; ++s) {
+        const int n = side_n[s];
+        if (n <= 0) continue;
+        if (n > 8) return;
+        const int origin = p.col_start[static_cast<size_t>(side_x0[s])];
+        for (int k = 1; k < n; ++k)
+            if (p.col_start[static_cast<size_t>(side_x0[s] + k)] != origin) return;
+        const int tile_x = s == 0 ? 0 : (pa.ni - 1) / kTileCols;
+        const int lds_col = origin - pa.min_sx - kTileCols * tile_x;
+        if (lds_col < -1 || lds_col + fs > kLdsCols || origin < 0 || origin + fs > p.g.src_w) return;
+        for (int k = 0; k < n; ++k)
+            for (int q = 0; q < 2; ++q) {
+                const float* set = p.set_ptr(p.set_of(side_x0[s] + k, pa.iy0 + q));
+                for (int ly = 0; ly < fs; ++ly)
+                    for (int lx = 0; lx < fs; ++lx) {
+                        const float c = set[ly * fs + lx];
+                        if (ly < r0 || ly >= r0 + 6) {
+                            if (c != 0.f) return;  // a tap outside the staged rows
+                        } else {
+                            blob[(static_cast<size_t>((s * 8 + k) * 2 + q)) * 48 + static_cast<size_t>(ly - r0) * 8 + lx] = c;
+                        }
+                    }
+            }
+        e.n[s] = n, e.x0[s] = side_x0[s], e.lds_col[s] = lds_col, e.tile_x[s] = tile_x;
+        any = true;
+    }
+    if (!any) return;
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, blob.size() * sizeof(float)), "hipMalloc(edge column coefficients)");
+    t.lane_blobs.push_back(dev);  // freed with the table
+    hip_check(hipMemcpy(dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice), "edge column coefficient upload");
+    e.coeffs = static_cast<const float*>(dev);
+    t.edge_cols = e;
+    t.use_edge_cols = true;
+}
+
 // The direct kernel's interior on the trimmed support (integer planes; see trim_periodic for why leaving out taps whose
 // coefficient is 0.0f is exact): the bounding box of the phase sets' non-zero coefficients, squared up.  The kernel takes
 // the filter size at run time, so this is a copy of the arguments with a smaller fs, window origins moved by the box's
@@ -813,6 +870,7 @@ void init_device(jinc_filter& f, int device) {
         plan_quasi(f.plans[i], f.tables[i]);
         plan_direct(f.plans[i], f.tables[i]);
         trim_direct(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
+        plan_edge_columns(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
         plan_runs(f.plans[i], f.tables[i]);
         {   // every interior variant of a table must cover the same extent: the border frame is laid out once
             const DeviceTable& t = f.tables[i];

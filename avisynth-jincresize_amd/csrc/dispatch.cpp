@@ -369,7 +369,7 @@ struct Choice {
     // kernel over the frame's four rectangles.  The strips are the leaner kernels (C3 at 32 frames: +11 %), but below ~5e9 taps per
     // call their launches cost more than they save (round3/border_strips_ab.txt, one frame per call: C2 122 -> 183 Gpix/s, C1 15.7 ->
     // 25.4, 1080p -> 4K 4:2:0 49 -> 74, 4K -> 1080p 27.7 -> 45, C3 24 -> 31; four frames: C2 346 -> 412, C1 59 -> 93; level from 3e9 ..
-    // 7e9 taps on; tap 16 at 9e9 taps: -30 %).  f.border_strips: -1 this rule, 1 / 2 / 3 / 0 forced (tests, A/B; 3 = ewa_strip_kernel where configured).
+    // 7e9 taps on; tap 16 at 9e9 taps: -30 %).  f.border_strips: -1 this rule, 1 / 2 / 3 / 4 / 0 forced (tests, A/B; 3 = ewa_strip_kernel where configured, 4 = 3 with the columns in the interior kernel's edge tiles where configured).
     bool wants_border_strips() const {
         if (f.border_strips >= 0) return f.border_strips != 0;
         double taps = 0.0;
@@ -545,9 +545,15 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         const char* inst = knobs::take_instance(&kernel);
         if (kernel) t.last_kernel = kernel, t.last_instance = inst;
     };
+    // Round 5: the border columns inside the interior kernel's edge tiles (ewa_periodic_quad2_kernel on integer planes,
+    // device_plan.cpp plan_edge_columns) wherever that kernel is what runs and the border form is not forced.  Knob EDGE_COLS = 0: the
+    // border kernels as before.
+    bool edge_fused = false;
     if (direct || periodic || quasi) {
         // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
         const bool strips = c.wants_border_strips() && t.strips_ok && c.direct_ok(t, i);
+        edge_fused = strips && periodic && t.use_edge_cols && (f.border_strips < 0 || f.border_strips == 4) && (f.kernel_mode == 0 || f.kernel_mode == 13) && c.trimmed(t) &&
+                     c.quad_chosen(t) && c.periodic_fs(t) == 6 && knobs::flag(JINC_KNOB_EDGE_COLS, true);
         if (strips) {
             jinc::DirectArgs rs = t.row_strips;
             rs.src_bytes = direct_src_bytes(
@@ -563,11 +569,11 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             // batch size from which the frame-lane kernel takes them (it stays ahead there: 0.283 ms, corners included, against
             // 0.300 + corners) -- i.e. instead of ewa_colstrip_kernel.  Knob STRIP_LDS: 1 = this rule, 2 = rows and columns always.
             const int lds_knob = knobs::geti(JINC_KNOB_STRIP_LDS, 1);
-            const bool lds_strips = f.border_strips == 3 || (lds_knob != 0 && f.border_strips < 0 && f.kernel_mode != 3);
+            const bool lds_strips = f.border_strips >= 3 || (lds_knob != 0 && f.border_strips < 0 && f.kernel_mode != 3);
             const bool strip_rows = lds_strips && t.use_strip_rows;
-            const bool strip_cols = lds_strips && t.use_strip_cols &&
-                                    (f.border_strips == 3 || lds_knob == 2 || !(t.use_fl_cols && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames));
-            const bool fl_cols = !strip_cols && t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
+            const bool strip_cols = !edge_fused && lds_strips && t.use_strip_cols &&
+                                    (f.border_strips >= 3 || lds_knob == 2 || !(t.use_fl_cols && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames));
+            const bool fl_cols = !edge_fused && !strip_cols && t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
                                  (f.kernel_mode == 0 || f.kernel_mode == 13 || f.kernel_mode == 2);
             if (fl_cols) {
                 auto aligned_to = [&](uintptr_t bytes) {
@@ -584,16 +590,16 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 else
                     timed(f.ev_gather, border_stream, "border column frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             }
-            t.last_border = (strip_rows ? 16 : 2) | (strip_cols ? 32 : fl_cols ? 8 : (t.use_colstrip && f.border_strips != 2) ? 4 : 1);
-            if (strip_cols || strip_rows) {
-                if (t.corner_rects.n > 0 && strip_cols)
+            t.last_border = (strip_rows ? 16 : 2) | (edge_fused ? 64 : strip_cols ? 32 : fl_cols ? 8 : (t.use_colstrip && f.border_strips != 2) ? 4 : 1);
+            if (strip_cols || strip_rows || edge_fused) {
+                if (t.corner_rects.n > 0 && (strip_cols || edge_fused))
                     timed(f.ev_gather, border_stream, "corner kernel launch", [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
                 if (strip_rows)
                     timed(f.ev_gather, border_stream, "border row strip launch", [&](hipStream_t s) { return jinc::launch_strip(t.strip_rows, io, s); });
                 if (strip_cols)
                     timed(f.ev_gather, border_stream, "border column strip launch", [&](hipStream_t s) { return jinc::launch_strip(t.strip_cols, io, s); });
             }
-            const bool colstrip = !strip_cols && !fl_cols && t.use_colstrip && f.border_strips != 2;
+            const bool colstrip = !edge_fused && !strip_cols && !fl_cols && t.use_colstrip && f.border_strips != 2;
             // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
             // last it would start when the interior kernel already holds every wave slot.  (Measured again in round 3 with
             // the corners last: no difference on any of eight configurations -- in a long batch the border kernels cost their
@@ -607,7 +613,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             if (colstrip) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
-            } else if (!fl_cols && !strip_cols && t.column_rects.n > 0) {
+            } else if (!edge_fused && !fl_cols && !strip_cols && t.column_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
             }
@@ -720,7 +726,9 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     (void)knobs::take_instance();  // (the flagged frames' full-window launch does not name the call)
                     return rc;
                 }
-                const int rc = jinc::launch_periodic(c.periodic_args(t), pfs, io, s, variant);
+                jinc::PeriodicArgs pa = c.periodic_args(t);
+                if (edge_fused) pa.edge = t.edge_cols;  // (the launch is the quad2 form: edge_fused says so)
+                const int rc = jinc::launch_periodic(pa, pfs, io, s, variant);
                 take_note();
                 return rc;
             });

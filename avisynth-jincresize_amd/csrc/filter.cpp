@@ -592,7 +592,7 @@ int jinc_filter_direct_premise(const jinc_filter* f) { return (f && f->device >=
 
 int jinc_filter_set_border_strips(jinc_filter* f, int enable) {
     if (!f) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
-    f->border_strips = enable < 0 ? -1 : enable > 3 ? 1 : enable;  // -1: by call size; 2: rows as strips, columns on the gather kernel; 3: ewa_strip_kernel
+    f->border_strips = enable < 0 ? -1 : enable > 4 ? 1 : enable;  // -1: by call size; 2: rows as strips, columns on the gather kernel; 3: ewa_strip_kernel; 4: 3 + columns inside the interior kernel
     g_last_error.clear();
     return JINC_OK;
 }

@@ -72,6 +72,8 @@ struct DeviceTable {
     jinc::FrameLaneArgs fl_cols;
     // ... or (round 5, filter sizes up to 9, source step 1) on kernel_strip.hip: one register window per lane for the strip's thickness
     bool use_strip_rows = false, use_strip_cols = false;
+    bool use_edge_cols = false;  // border columns inside ewa_periodic_quad2_kernel's edge tiles (plan_edge_columns)
+    jinc::PeriodicArgs::EdgeColumns edge_cols;
     jinc::StripArgs strip_rows, strip_cols;
     std::vector<void*> lane_blobs;  // lane-major coefficient copies of the private-set rectangles (RectList::lane_coeffs)
     jinc::RectList whole;         // gather work when it does not

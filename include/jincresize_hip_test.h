@@ -132,6 +132,7 @@ typedef enum jinc_knob {
     JINC_KNOB_ROWS_PAIR,              /* 0: rows kernel instead of its packed phase-pair form (round 5); 64 / 32 / 16: that tile shape */
     JINC_KNOB_ROWPAIR_SMALL,          /* 1: ewa_periodic_rowpair_kernel also on 6 .. 9 taps per kernel row (default: the window / quad forms there) */
     JINC_KNOB_STRIP_LDS,              /* 0: border rows / columns of periodic plans on the round-4 kernels; 1 (default): ewa_strip_kernel by rule; 2: rows and columns on it always */
+    JINC_KNOB_EDGE_COLS,              /* 0: border columns on the border kernels even where ewa_periodic_quad2_kernel's edge tiles could compute them (round 5) */
     JINC_KNOB_COUNT
 } jinc_knob;
 JINC_API int jinc_debug_set_knob(int knob, double value);
@@ -185,11 +186,13 @@ JINC_API int jinc_debug_transport_counts(long long *by_shader, long long *by_dma
  * launch below); 1 = rows and columns on the round-4 strip kernels (ewa_direct_kernel's row strips, ewa_colstrip_kernel or, in batches,
  * the frame-lane kernel), corners on the gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel;
  * 3 = rows and columns on ewa_strip_kernel (round 5; filter sizes up to 9 at source step 1: the automatic choice there), corners on
- * the gather kernel; 0 = everything on the gather kernel (A/B measurements, tests). */
+ * the gather kernel; 4 = as 3, but the columns inside the interior kernel's edge tiles where that form exists (ewa_periodic_quad2_kernel
+ * on integer planes: the automatic choice there); 0 = everything on the gather kernel (A/B measurements, tests). */
 JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
 /* Which kernels computed the border frame of `table` in the most recent frame call, as bits: 1 gather kernel over the frame (or its
  * columns), 2 ewa_direct_kernel row strips, 4 ewa_colstrip_kernel, 8 frame-lane kernel over the columns, 16 / 32 ewa_strip_kernel
- * over the rows / the columns; 0: no border launch recorded (plans whose border is not a strip frame). */
+ * over the rows / the columns, 64 the columns inside the interior kernel's edge tiles (ewa_periodic_quad2_kernel, integer planes);
+ * 0: no border launch recorded (plans whose border is not a strip frame). */
 JINC_API int jinc_filter_last_border(const jinc_filter *f, int table);
 /* 1: the border kernels run on a side stream concurrently with the interior kernel (fork/join by events around
  * every call); 0: all on the caller's stream, back to back; -1 (default): the side stream unless the call is so small

@@ -79,8 +79,9 @@ def test_strip_kernel_matches_oracle_and_the_other_border_forms(gpu_pkg, O, case
 
 
 def test_strip_kernel_is_the_automatic_choice_in_large_calls(gpu_pkg, O):
-    """24 frames of 1080p -> 4K Y8 per call (>= 5e9 taps: the strip border): rows and columns on ewa_strip_kernel by the rule, the
-    knob strip_lds = 0 puts the round-4 kernels back; every frame of both the same bytes, three against the oracle."""
+    """24 frames of 1080p -> 4K Y8 per call (>= 5e9 taps: the strip border): rows on ewa_strip_kernel and columns inside the interior
+    kernel by the rule; the knobs edge_cols = 0 / strip_lds = 0 put the earlier kernels back; every frame of all forms the same bytes,
+    three against the oracle."""
     torch = pytest.importorskip("torch")
     from test_framelane_pair import _run_batch
     fmt, sw, sh, tw, th, frames = "Y8", 1920, 1080, 3840, 2160, 24
@@ -88,17 +89,22 @@ def test_strip_kernel_is_the_automatic_choice_in_large_calls(gpu_pkg, O):
     of = O.OracleFilter(ofmt, sw, sh, tw, th)
     f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0)
     srcs = [O.lcg_frame(ofmt, sw, sh, seed=4400 + k) for k in range(frames)]
-    auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
-    assert f.last_border(0) == (16 | 8), f.last_border(0)        # rows on ewa_strip_kernel, columns (24 frames) on the frame-lane kernel
-    with gpu_pkg.knobs(strip_lds=2):
+    fused = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+    assert f.last_border(0) == (16 | 64), f.last_border(0)       # rows on ewa_strip_kernel, columns inside ewa_periodic_quad2_kernel's edge tiles
+    assert f.last_instance(0).startswith("ewa_periodic_quad2_kernel<unsigned char"), f.last_instance(0)
+    with gpu_pkg.knobs(edge_cols=0):
+        auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+        assert f.last_border(0) == (16 | 8), f.last_border(0)    # ... columns (24 frames) on the frame-lane kernel
+    with gpu_pkg.knobs(strip_lds=2, edge_cols=0):
         both = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
         assert f.last_border(0) == 48, f.last_border(0)
-    with gpu_pkg.knobs(strip_lds=0):
+    with gpu_pkg.knobs(strip_lds=0, edge_cols=0):
         old = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
         assert f.last_border(0) == (2 | 8), f.last_border(0)     # direct row strips + frame-lane columns
     for k in range(frames):
+        assert_planes_equal(fused[k], old[k], f.out_dims(), what=f"frame {k}: border columns in the interior kernel vs the round-4 border kernels")
         assert_planes_equal(auto[k], old[k], f.out_dims(), what=f"frame {k}: ewa_strip_kernel vs the round-4 border kernels")
         assert_planes_equal(both[k], old[k], f.out_dims(), what=f"frame {k}: ewa_strip_kernel on rows and columns vs the round-4 border kernels")
         if k in (0, 11, frames - 1):
-            assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=16), f.out_dims(), what=f"frame {k} vs oracle")
+            assert_planes_equal(fused[k], of.get_frame(srcs[k], threads=16), f.out_dims(), what=f"frame {k} vs oracle")
     f.close()
