@@ -636,31 +636,35 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     if (!t.strips_ok) t.border_rects.private_sets = t.border_rects.unit_stride = true;  // coefficients per lane
 }
 
-// Border columns inside the interior kernel (ewa_periodic_quad2_kernel, integer planes): the columns left and right of the
+// Border columns inside the interior kernel (ewa_periodic_quad2_kernel / ewa_periodic_quad2x8_kernel, integer planes): the columns left and right of the
 // interior, interior rows only (the corners stay with the corner kernel), are computed by the first and the last tile column of the
 // interior launch from the source tile it has staged anyway.  As kernels of their own these 7 + 5 columns of C2 cost 0.28 ms of a
 // 9.8 ms step -- 4.4 M scattered 64-byte lines per launch (profiles/round5/strip_ab.log) -- for 0.05 ms worth of arithmetic.
 // What has to hold (checked here, not assumed): the strips repeat their sets with the interior's period (strips_ok), every column of a
 // side has ONE window origin whose fs columns lie in the edge tile (or one column in front of it), and the sets' kernel rows outside
-// the interior's six trimmed rows are zero (the columns share the interior's row phases, so they are for the plans seen).
+// the interior's trimmed rows are zero (the columns share the interior's row phases, so they are for the plans seen).
 void plan_edge_columns(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
     t.use_edge_cols = false;
     t.edge_cols = jinc::PeriodicArgs::EdgeColumns{};
-    if (!integer_samples || !t.use_periodic || !t.use_direct || !t.strips_ok || t.trim_fs != 6 || !t.periodic_trim.quad || p.fs != 7) return;
+    // the two-periods-per-lane quad forms: 6 kernel rows of filter size 7 (ewa_periodic_quad2_kernel), 8 of filter size 9 (..quad2x8..)
+    if (!integer_samples || !t.use_periodic || !t.use_direct || !t.strips_ok || !t.periodic_trim.quad) return;
+    if (!((t.trim_fs == 6 && p.fs == 7) || (t.trim_fs == 8 && p.fs == 9))) return;
     const jinc::PeriodicArgs& pa = t.periodic_trim;
     if (pa.px != 2 || pa.py != 2 || pa.start_y[0] != pa.start_y[1] || pa.start_x[0] != pa.start_x[1]) return;
-    const int fs = p.fs, r0 = pa.min_sy - t.periodic.min_sy;
-    if (r0 < 0 || r0 + 6 > fs) return;
+    const int fs = p.fs, nr = t.trim_fs, ncp = (fs + 3) & ~3, r0 = pa.min_sy - t.periodic.min_sy;
+    if (r0 < 0 || r0 + nr > fs) return;
     const int x_end = pa.ix0 + 2 * pa.ni, W = p.g.dst_w;
-    constexpr int kTileCols = 128, kLdsCols = 134;  // Quad2Cfg (kernel_periodic.hip)
+    constexpr int kTileCols = 128, kMax = jinc::PeriodicArgs::EdgeColumns::kMaxPerSide;
+    const int kLdsCols = kTileCols + nr;  // Quad2Cfg / Quad2x8Cfg (kernel_periodic.hip)
+    const size_t block = static_cast<size_t>(nr) * ncp;
     jinc::PeriodicArgs::EdgeColumns e;
-    std::vector<float> blob(static_cast<size_t>(2) * 8 * 2 * 48, 0.f);
+    std::vector<float> blob(static_cast<size_t>(2) * kMax * 2 * block, 0.f);
     const int side_x0[2] = {0, x_end}, side_n[2] = {pa.ix0, W - x_end};
     bool any = false;
     for (int s = 0; s < 2; ++s) {
         const int n = side_n[s];
         if (n <= 0) continue;
-        if (n > 8) return;
+        if (n > kMax) return;
         const int origin = p.col_start[static_cast<size_t>(side_x0[s])];
         for (int k = 1; k < n; ++k)
             if (p.col_start[static_cast<size_t>(side_x0[s] + k)] != origin) return;
@@ -673,10 +677,10 @@ void plan_edge_columns(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sa
                 for (int ly = 0; ly < fs; ++ly)
                     for (int lx = 0; lx < fs; ++lx) {
                         const float c = set[ly * fs + lx];
-                        if (ly < r0 || ly >= r0 + 6) {
+                        if (ly < r0 || ly >= r0 + nr) {
                             if (c != 0.f) return;  // a tap outside the staged rows
                         } else {
-                            blob[(static_cast<size_t>((s * 8 + k) * 2 + q)) * 48 + static_cast<size_t>(ly - r0) * 8 + lx] = c;
+                            blob[(static_cast<size_t>((s * kMax + k) * 2 + q)) * block + static_cast<size_t>(ly - r0) * ncp + lx] = c;
                         }
                     }
             }

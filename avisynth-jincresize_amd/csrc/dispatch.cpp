@@ -338,6 +338,15 @@ struct Choice {
         return t.plan.fs == 7 ? (wgs >= Rules::kHalfTileMaxWorkgroups && periods >= Rules::kQuadMinPeriods) : wgs < Rules::kQuad9MaxWorkgroups;
     }
 
+    // 8 x 8 support on integer planes: two periods per lane (ewa_periodic_quad2x8_kernel) where the launch fills the chip with its
+    // 128 x 32 tiles -- Jinc64 at 2x on 8-bit 483 -> 504 Gpix/s, 16-bit 4:2:0 253 -> 265; float planes (C4) are level and stay with
+    // one period per lane (round4/quad2x8_ab.log).  (Given quad_chosen(t) and periodic_fs(t) == 8.)
+    bool quad2x8_chosen(const DeviceTable& t, int sample_bytes) const {
+        const int two = knobs::geti(JINC_KNOB_QUAD2X8, -1);  // A/B knob: 0 / 1
+        const long long wgs2 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 31) / 32) * nframes;
+        return two >= 0 ? two != 0 : (sample_bytes < 4 && wgs2 >= Rules::kQuad2x8MinWorkgroups);
+    }
+
     // does any plane launch border kernels beside an interior kernel?
     bool any_border_frame() const {
         bool any = false;
@@ -545,7 +554,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         const char* inst = knobs::take_instance(&kernel);
         if (kernel) t.last_kernel = kernel, t.last_instance = inst;
     };
-    // Round 5: the border columns inside the interior kernel's edge tiles (ewa_periodic_quad2_kernel on integer planes,
+    // Round 5: the border columns inside the interior kernel's edge tiles (ewa_periodic_quad2_kernel / ..quad2x8.. on integer planes,
     // device_plan.cpp plan_edge_columns) wherever that kernel is what runs and the border form is not forced.  Knob EDGE_COLS = 0: the
     // border kernels as before.
     bool edge_fused = false;
@@ -553,7 +562,8 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         // border frame: rows on kernel_direct.hip + columns on the gather kernel, or the gather kernel for all of it
         const bool strips = c.wants_border_strips() && t.strips_ok && c.direct_ok(t, i);
         edge_fused = strips && periodic && t.use_edge_cols && (f.border_strips < 0 || f.border_strips == 4) && (f.kernel_mode == 0 || f.kernel_mode == 13) && c.trimmed(t) &&
-                     c.quad_chosen(t) && c.periodic_fs(t) == 6 && knobs::flag(JINC_KNOB_EDGE_COLS, true);
+                     c.quad_chosen(t) && (c.periodic_fs(t) == 6 || (c.periodic_fs(t) == 8 && c.quad2x8_chosen(t, sb))) &&
+                     knobs::flag(JINC_KNOB_EDGE_COLS, true);
         if (strips) {
             jinc::DirectArgs rs = t.row_strips;
             rs.src_bytes = direct_src_bytes(
@@ -675,12 +685,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     const int force_rg = knobs::geti(JINC_KNOB_QUAD_RG, 0);  // A/B knob: 8 / 4 forces full / half-height tiles of the quad forms
                     if (force_rg == 8) variant = 5;
                     if (force_rg == 4) variant = 6;
-                    // 8 x 8 support on integer planes: two periods per lane (ewa_periodic_quad2x8_kernel) where the launch fills
-                    // the chip with its 128 x 32 tiles -- Jinc64 at 2x on 8-bit 483 -> 504 Gpix/s, 16-bit 4:2:0 253 -> 265; float
-                    // planes (C4) are level and stay with one period per lane (round4/quad2x8_ab.log)
-                    const int two = knobs::geti(JINC_KNOB_QUAD2X8, -1);  // A/B knob: 0 / 1
-                    const long long wgs2 = static_cast<long long>((t.periodic.ni + 127) / 128) * ((t.periodic.nj + 31) / 32) * nframes;
-                    if (pfs == 8 && (two >= 0 ? two != 0 : (sb < 4 && wgs2 >= Rules::kQuad2x8MinWorkgroups))) variant = 7;
+                    if (pfs == 8 && c.quad2x8_chosen(t, sb)) variant = 7;  // two periods per lane
                 }
                 if (c.trimmed(t) && t.trim_needs_finite) {
                     // float plane: which frames hold nothing but finite samples?  Those run on the trimmed support; the others
@@ -727,7 +732,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                     return rc;
                 }
                 jinc::PeriodicArgs pa = c.periodic_args(t);
-                if (edge_fused) pa.edge = t.edge_cols;  // (the launch is the quad2 form: edge_fused says so)
+                if (edge_fused) pa.edge = t.edge_cols;  // (the launch is a two-periods-per-lane quad form: edge_fused says so)
                 const int rc = jinc::launch_periodic(pa, pfs, io, s, variant);
                 take_note();
                 return rc;

@@ -1123,68 +1123,94 @@ __device__ __forceinline__ void store_quad_buf(BufferRsrc rsrc, uint32_t voffset
     }
 }
 
-// The plane's border columns beside this tile's rows (PeriodicArgs::EdgeColumns; integer planes, first / last tile column only): lane
-// = period-row of the tile, one 6-row x 7-column register window per lane for every column of the side (they share their window
-// origin) and both row phases (they share theirs); wave w takes row phase w & 1 of the side's columns 4 * (w / 2) .. + 3, whose four
-// samples are adjacent in the lane's output row and leave as one store.  Every sample is the reference's chain: taps in (ly, lx)
-// order, multiply and add un-fused (ref /root/reference/src/JincResize.cpp:570-579); the kernel rows left out carry zero coefficients.
-template <typename T, int RG>
+// The plane's border columns beside this tile's rows (PeriodicArgs::EdgeColumns; integer planes, first / last tile column only) for the
+// two-periods-per-lane quad forms (Cfg: Quad2Cfg / Quad2x8Cfg; NR kernel rows = the interior's trimmed rows, NC = the plan's filter size).
+// Lane = period-row of the tile, one NR-row x NC-column register window per lane for every column of the side (they share their
+// window origin) and both row phases (they share theirs); wave w takes row phase w & 1 of one half of the side's columns, four
+// columns at a time: their samples are adjacent in the lane's output row and leave as one store.  Every sample is the reference's
+// chain: taps in (ly, lx) order, multiply and add un-fused (ref /root/reference/src/JincResize.cpp:570-579); the kernel rows left
+// out carry zero coefficients (checked on the host).
+template <typename T>
+__device__ __forceinline__ bool edge_tile_of(const PeriodicArgs& a, int tile_x) {
+    if constexpr (std::is_same_v<T, float>) return false;  // (float planes: the border kernels, whatever the samples)
+    return a.edge.coeffs != nullptr && ((a.edge.n[0] > 0 && tile_x == a.edge.tile_x[0]) || (a.edge.n[1] > 0 && tile_x == a.edge.tile_x[1]));
+}
+
+// An edge window that starts one source column in front of the tile (the left border's, when the interior's support was trimmed by a
+// column): that column goes into the word in front of each tile row -- the previous row's last spare word, or for row 0 the word in
+// front of the tile (the kernels allocate two).  Call between the staging writes and the barrier, edge tiles only.
+template <typename T, typename Cfg>
+__device__ __forceinline__ void stage_edge_column(const PeriodicArgs& a, const PlaneIO& io, float* tile, int tile_x, const char* sbase, int gx0, int gy0,
+                                                  int wave, int lane) {
+    static_assert(Cfg::kLdsPitch >= Cfg::kLdsCols + 1 && Cfg::kLdsRows <= 64, "a spare word per tile row, one tile row per lane");
+    const bool in_front = (a.edge.n[0] > 0 && tile_x == a.edge.tile_x[0] && a.edge.lds_col[0] < 0) || (a.edge.n[1] > 0 && tile_x == a.edge.tile_x[1] && a.edge.lds_col[1] < 0);
+    if (in_front && wave == 0 && lane < Cfg::kLdsRows && gx0 > 0) {
+        int gy = gy0 + lane;
+        gy = gy < a.src_h ? gy : a.src_h - 1;
+        tile[lane * Cfg::kLdsPitch - 1] = to_float(reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch)[gx0 - 1]);
+    }
+}
+
+template <typename T, typename Cfg, int NR, int NC>
 __device__ __forceinline__ void quad2_edge_columns(const PeriodicArgs& a, const PlaneIO& io, const float* tile, int tile_x, int j0, int wave, int lane,
                                                    BufferRsrc drsrc) {
-    using Cfg = Quad2Cfg<RG>;
+    constexpr int NCP = (NC + 3) & ~3;  // floats per coefficient row
     for (int s = 0; s < 2; ++s) {
         const int n = a.edge.n[s];
         if (n <= 0 || tile_x != a.edge.tile_x[s]) continue;  // workgroup-uniform
-        const int q = wave & 1, k0 = 4 * (wave >> 1);
-        if (k0 >= n) continue;  // wave-uniform
-        const int nk = n - k0 < 4 ? n - k0 : 4;
+        const int q = wave & 1, half = (n + 1) >> 1;
+        const int k_begin = (wave >> 1) * half, k_end = k_begin + half < n ? k_begin + half : n;
+        if (k_begin >= k_end) continue;  // wave-uniform
         const bool live = lane < Cfg::kTileRows && j0 + lane < a.nj;
-        // The window: lane l reads the seven samples of tile row l, rows l + 1 .. l + 5 come over from the lanes above by whole-wave
-        // shifts (read from LDS, the lanes' rows lie 136 words apart: four banks for 64 lanes, 42 reads with a 16-way conflict each.
-        // Measured level with this form all the same -- round5/edge_cols_ab.log -- the chains are what the edge tiles pay for).
+        // The window: lane l reads the NC samples of tile row l, rows l + 1 .. l + NR - 1 come over from the lanes above by whole-wave
+        // shifts (read from LDS, the lanes' rows lie a pitch apart: four banks for 64 lanes, a 16-way conflict per read.  Measured
+        // level with this form all the same -- round5/edge_cols_ab.log -- the chains are what the edge tiles pay for).
         static_assert(Cfg::kLdsRows <= 64, "one tile row per lane");
         const float* wp = tile + (lane < Cfg::kLdsRows ? lane : 0) * Cfg::kLdsPitch + a.edge.lds_col[s];
-        float w[6][7];
+        float w[NR][NC];
 #pragma unroll
-        for (int lx = 0; lx < 7; ++lx) w[0][lx] = wp[lx];
+        for (int lx = 0; lx < NC; ++lx) w[0][lx] = wp[lx];
 #pragma unroll
-        for (int ly = 1; ly < 6; ++ly)
+        for (int ly = 1; ly < NR; ++ly)
 #pragma unroll
-            for (int lx = 0; lx < 7; ++lx)  // wave_shl:1 -- lane l takes lane l + 1's value
+            for (int lx = 0; lx < NC; ++lx)  // wave_shl:1 -- lane l takes lane l + 1's value
                 w[ly][lx] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, w[ly - 1][lx]), 0x130, 0xf, 0xf, false));
-        float r[4];
+        const uint32_t row_off = static_cast<uint32_t>(a.iy0 + 2 * (j0 + lane) + q) * static_cast<uint32_t>(io.dst_pitch);
+        for (int k0 = k_begin; k0 < k_end; k0 += 4) {  // wave-uniform
+            const int nk = k_end - k0 < 4 ? k_end - k0 : 4;
+            float r[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r[k] = 0.f;
-            if (k < nk) {  // wave-uniform
-                const JINC_CONSTANT float* cs = (const JINC_CONSTANT float*)(a.edge.coeffs) + ((s * 8 + k0 + k) * 2 + q) * 48;
-                float acc = 0.f;
+            for (int k = 0; k < 4; ++k) {
+                r[k] = 0.f;
+                if (k < nk) {  // wave-uniform
+                    const JINC_CONSTANT float* cs = (const JINC_CONSTANT float*)(a.edge.coeffs) + ((s * PeriodicArgs::EdgeColumns::kMaxPerSide + k0 + k) * 2 + q) * (NR * NCP);
+                    float acc = 0.f;
 #pragma unroll
-                for (int ly = 0; ly < 6; ++ly)
+                    for (int ly = 0; ly < NR; ++ly)
 #pragma unroll
-                    for (int lx = 0; lx < 7; ++lx) acc = acc + w[ly][lx] * cs[ly * 8 + lx];
-                r[k] = acc;
+                        for (int lx = 0; lx < NC; ++lx) acc = acc + w[ly][lx] * cs[ly * NCP + lx];
+                    r[k] = acc;
+                }
             }
-        }
-        if (!live) continue;
-        const uint32_t voff = static_cast<uint32_t>(a.iy0 + 2 * (j0 + lane) + q) * static_cast<uint32_t>(io.dst_pitch) +
-                              static_cast<uint32_t>(a.edge.x0[s] + k0) * static_cast<uint32_t>(sizeof(T));
-        if (nk == 4) {
-            if constexpr (std::is_same_v<T, uint8_t>) {
-                uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(r[0], 0u, 0u);
-                v = __builtin_amdgcn_cvt_pk_u8_f32(r[1], 1u, v);
-                v = __builtin_amdgcn_cvt_pk_u8_f32(r[2], 2u, v);
-                v = __builtin_amdgcn_cvt_pk_u8_f32(r[3], 3u, v);
-                __builtin_amdgcn_raw_buffer_store_b32(v, drsrc, voff, 0, 0);
+            if (!live) continue;
+            const uint32_t voff = row_off + static_cast<uint32_t>(a.edge.x0[s] + k0) * static_cast<uint32_t>(sizeof(T));
+            if (nk == 4) {
+                if constexpr (std::is_same_v<T, uint8_t>) {
+                    uint32_t v = __builtin_amdgcn_cvt_pk_u8_f32(r[0], 0u, 0u);
+                    v = __builtin_amdgcn_cvt_pk_u8_f32(r[1], 1u, v);
+                    v = __builtin_amdgcn_cvt_pk_u8_f32(r[2], 2u, v);
+                    v = __builtin_amdgcn_cvt_pk_u8_f32(r[3], 3u, v);
+                    __builtin_amdgcn_raw_buffer_store_b32(v, drsrc, voff, 0, 0);
+                } else {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 v = {round_pair_u16(r[0], r[1], io.peak), round_pair_u16(r[2], r[3], io.peak)};
+                    __builtin_amdgcn_raw_buffer_store_b64(v, drsrc, voff, 0, 0);
+                }
             } else {
-                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 v = {round_pair_u16(r[0], r[1], io.peak), round_pair_u16(r[2], r[3], io.peak)};
-                __builtin_amdgcn_raw_buffer_store_b64(v, drsrc, voff, 0, 0);
-            }
-        } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (k < nk) store_sample_buf<T>(drsrc, voff + static_cast<uint32_t>(k * sizeof(T)), 0, r[k], io.peak);
+                for (int k = 0; k < 3; ++k)
+                    if (k < nk) store_sample_buf<T>(drsrc, voff + static_cast<uint32_t>(k * sizeof(T)), 0, r[k], io.peak);
+            }
         }
     }
 }
@@ -1213,9 +1239,7 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
     const size_t frame = blockIdx.z;
     if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
     // integer planes: this tile column also computes the plane's border columns of its rows (PeriodicArgs::EdgeColumns)
-    bool edge_tile = false;
-    if constexpr (!std::is_same_v<T, float>)
-        edge_tile = a.edge.coeffs != nullptr && ((a.edge.n[0] > 0 && tile_x == a.edge.tile_x[0]) || (a.edge.n[1] > 0 && tile_x == a.edge.tile_x[1]));
+    const bool edge_tile = edge_tile_of<T>(a, tile_x);
     {   // stage the source tile as fp32, all loads in front of the LDS writes (see ewa_periodic_kernel)
         const int gx0 = a.min_sx + i0;
         const int gy0 = a.min_sy + j0;
@@ -1247,21 +1271,14 @@ __global__ __launch_bounds__(256, 6) void ewa_periodic_quad2_kernel(const Period
             }
         }
         if constexpr (!std::is_same_v<T, float>) {
-            // an edge window that starts one source column in front of the tile (the left border's, when the interior's support was
-            // trimmed by a column): that column goes into the word in front of each tile row
-            if (edge_tile && wave == 0 && lane < Cfg::kLdsRows && gx0 > 0 &&
-                ((a.edge.n[0] > 0 && tile_x == a.edge.tile_x[0] && a.edge.lds_col[0] < 0) || (a.edge.n[1] > 0 && tile_x == a.edge.tile_x[1] && a.edge.lds_col[1] < 0))) {
-                int gy = gy0 + lane;
-                gy = gy < a.src_h ? gy : a.src_h - 1;
-                tile[lane * Cfg::kLdsPitch - 1] = to_float(reinterpret_cast<const T*>(sbase + static_cast<size_t>(gy) * io.src_pitch)[gx0 - 1]);
-            }
+            if (edge_tile) stage_edge_column<T, Cfg>(a, io, tile, tile_x, sbase, gx0, gy0, wave, lane);
         }
     }
     __syncthreads();
     const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
                                        static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
     if constexpr (!std::is_same_v<T, float>) {
-        if (edge_tile) quad2_edge_columns<T, RG>(a, io, tile, tile_x, j0, wave, lane, drsrc);
+        if (edge_tile) quad2_edge_columns<T, Cfg, 6, 7>(a, io, tile, tile_x, j0, wave, lane, drsrc);
     }
     const int ia = i0 + 2 * lane;  // the lane's first period
     if (ia >= a.ni) return;        // no barrier below
@@ -1393,7 +1410,9 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
     using Cfg = Quad2x8Cfg<RG>;
     constexpr int FS = Cfg::FS;
     static_assert(RG % 4 == 0, "the four waves of a workgroup take RG / 4 row groups each");
-    __shared__ __attribute__((aligned(16))) float tile[Cfg::kLdsRows * Cfg::kLdsPitch];
+    // (two words in front of the tile: row 0's "column -1" of the edge columns, stage_edge_column; the tile stays 8-byte aligned)
+    __shared__ __attribute__((aligned(16))) float tile_words[2 + Cfg::kLdsRows * Cfg::kLdsPitch];
+    float* const tile = tile_words + 2;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1403,6 +1422,7 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
     const int j0 = tile_y * Cfg::kTileRows;
     const size_t frame = blockIdx.z;
     if (skips_frame(a, frame)) return;  // float planes: the other launch's frame
+    const bool edge_tile = edge_tile_of<T>(a, tile_x);  // integer planes: this tile column computes the plane's border columns of its rows
     {   // stage the source tile as fp32, in two halves of the rows (all loads of a half in front of its LDS writes): the whole
         // tile at once would hold more staged registers than the compute phase has
         const int gx0 = a.min_sx + i0;
@@ -1433,20 +1453,27 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
 #pragma unroll
                 for (int k = 0; k < kColsPerLane; ++k) {
                     const int c = lane + 64 * k;
-                    if (r < Cfg::kLdsRows && c < Cfg::kLdsPitch) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
+                    // (the pitch's two spare words stay unwritten here: the second is the next row's column -1)
+                    if (r < Cfg::kLdsRows && c < Cfg::kLdsCols) tile[r * Cfg::kLdsPitch + c] = nonfinite.take(staged[i][k]);
                 }
             }
         }
+        if constexpr (!std::is_same_v<T, float>) {
+            if (edge_tile) stage_edge_column<T, Cfg>(a, io, tile, tile_x, sbase, gx0, gy0, wave, lane);
+        }
     }
     __syncthreads();
+    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
+                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
+    if constexpr (!std::is_same_v<T, float>) {
+        if (edge_tile) quad2_edge_columns<T, Cfg, 8, 9>(a, io, tile, tile_x, j0, wave, lane, drsrc);
+    }
     const int ia = i0 + 2 * lane;
     if (ia >= a.ni) return;  // no barrier below
     const bool b_ok = ia + 1 < a.ni;
 
     const JINC_CONSTANT f32x2* quad = (const JINC_CONSTANT f32x2*)(a.quad);
     const float* base = tile + 2 * lane;
-    const BufferRsrc drsrc = make_rsrc(static_cast<char*>(io.dst) + frame * io.dst_frame_stride,
-                                       static_cast<uint32_t>(io.dst_pitch) * a.dst_h);  // wave-uniform
     const uint32_t xoff = static_cast<uint32_t>(a.ix0 + 2 * ia) * static_cast<uint32_t>(sizeof(T));
 
     constexpr int kGroupsPerWave = RG / 4;

@@ -110,14 +110,16 @@ struct PeriodicArgs {
     // run_when == kRunAllAndFlag: the launch computes EVERY frame and sets frame_flags[frame] = 1 where it stages a non-finite
     // sample (the trimmed launch of a float plane is its own finite-sample scan; kernel_periodic.hip NonFinite)
     static constexpr uint32_t kRunAllAndFlag = 2;
-    // ewa_periodic_quad2_kernel on integer planes: the plane's border COLUMNS beside the interior rows, computed by the first / last
+    // ewa_periodic_quad2_kernel / ewa_periodic_quad2x8_kernel on integer planes: the plane's border COLUMNS beside the interior rows, computed by the first / last
     // tile column out of the tile it has staged anyway (device_plan.cpp plan_edge_columns; as kernels of their own the columns were
     // bound by the scattered 64-byte lines of their source windows and stores, not by arithmetic).  Side s (0 left, 1 right): n[s]
     // output columns from x0[s] on, all with the source window whose first column is LDS column lds_col[s] (-1: the column in front
     // of the tile, staged into the pitch's spare word) of tile column tile_x[s]; coefficient rows
-    // coeffs[((s * 8 + k) * 2 + q) * 48 + ly * 8 + lx] = kernel rows r0 .. r0 + 5 (the interior's trimmed rows) of column k's set
-    // at row phase q.  coeffs == nullptr: the border kernels compute the columns.
+    // coeffs[((s * kMaxPerSide + k) * 2 + q) * (NR * NCP) + ly * NCP + lx] = kernel rows r0 .. r0 + NR - 1 (the interior's trimmed rows: 6,
+    // or 8 for ewa_periodic_quad2x8_kernel) of column k's set at row phase q, NCP = the filter size rounded up to a multiple of 4.
+    // coeffs == nullptr: the border kernels compute the columns.
     struct EdgeColumns {
+        static constexpr int kMaxPerSide = 16;
         const float* coeffs = nullptr;
         int n[2] = {0, 0}, x0[2] = {0, 0}, lds_col[2] = {0, 0}, tile_x[2] = {0, 0};
     } edge;

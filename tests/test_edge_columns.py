@@ -1,5 +1,5 @@
-"""Border columns inside the interior kernel (round 5): on integer planes at 2x with tap 3 the first and the last tile column of
-ewa_periodic_quad2_kernel compute the plane's border columns of their rows from the tile they have staged (PeriodicArgs::EdgeColumns,
+"""Border columns inside the interior kernel (round 5): on integer planes at 2x with tap 3 / tap 4 the first and the last tile column
+of ewa_periodic_quad2_kernel / ewa_periodic_quad2x8_kernel compute the plane's border columns of their rows from the tile they have staged (PeriodicArgs::EdgeColumns,
 device_plan.cpp plan_edge_columns).  Forced through jinc_filter_set_border_strips(4) with kernel mode QUAD on small planes, compared
 with the oracle and with the border kernels' bytes; `last_border` bit 64 says the form ran.  The automatic rule's case (C2 batches)
 is in test_strip_kernel.py / test_benchmarked_instances.py."""
@@ -22,6 +22,12 @@ CASES = [
     ("YUV420P16", 400, 144, 800, 288, dict(tap=3)),
     ("YUV444P8", 256, 144, 512, 288, dict(tap=3)),
     ("YUV420P8", 256, 144, 512, 288, dict(tap=3, cplace="topleft")),
+    ("Y8", 192, 108, 384, 216, dict(tap=4)),                      # filter size 9 on the 8 x 8 support: ewa_periodic_quad2x8_kernel
+    ("Y8", 500, 90, 1000, 180, dict(tap=4)),
+    ("Y8", 263, 301, 526, 602, dict(tap=4, blur=0.98)),
+    ("Y16", 333, 211, 666, 422, dict(tap=4)),
+    ("YUV420P8", 400, 144, 800, 288, dict(tap=4)),
+    ("YUV420P10", 256, 144, 512, 288, dict(tap=4, cplace="topleft")),
     ("Y8", 200, 120, 400, 240, dict(tap=3, src_left=2.5, src_top=-1.25, src_width=190.5, src_height=118.0)),  # cropped: uneven borders (may not configure)
 ]
 
@@ -45,7 +51,8 @@ def test_edge_columns_match_the_oracle_and_the_border_kernels(gpu_pkg, O, case, 
     def run(strips):
         f.set_border_strips(strips)
         f.set_kernel_mode(gpu_pkg.KernelMode.QUAD)
-        return [f.get_frame(srcs[0])] if frames == 1 else _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, gpu_pkg.KernelMode.QUAD)
+        with gpu_pkg.knobs(quad2x8=1):   # (tap 4: two periods per lane whatever the call's size)
+            return [f.get_frame(srcs[0])] if frames == 1 else _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, gpu_pkg.KernelMode.QUAD)
 
     got = run(4)
     fused = [t for t in range(f.num_tables) if f.last_border(t) & 64]
@@ -53,7 +60,7 @@ def test_edge_columns_match_the_oracle_and_the_border_kernels(gpu_pkg, O, case, 
         f.close()
         pytest.skip("no table of this plan puts its border columns into the interior kernel")
     for t in fused:
-        assert f.last_instance(t).startswith("ewa_periodic_quad2_kernel<"), f.last_instance(t)
+        assert f.last_instance(t).startswith(("ewa_periodic_quad2_kernel<", "ewa_periodic_quad2x8_kernel<")), f.last_instance(t)
         assert f.last_border(t) & (32 | 8 | 4 | 1) == 0, f.last_border(t)   # no column kernel beside it
     with gpu_pkg.knobs(edge_cols=0):
         plain = run(4)
