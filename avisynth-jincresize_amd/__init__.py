@@ -27,7 +27,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("JINC_LIB") or os.path.join(_HERE, "lib", "libjincresize_hip.so")  # JINC_LIB: A/B runs against another build
 SIMD_ORDER_ISA_PATH = os.path.join(_HERE, "lib", "kernel_simdorder-gfx950.s")  # the one unit with (explicit) fused multiply-adds
-ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_framelane_sub", "kernel_framelane_pair", "kernel_periodic", "kernel_rowpair", "kernel_strip", "kernel_direct", *[f"kernel_direct_walk_{t}_sx{x}" for t in ("u8", "u16", "f32") for x in (1, 2, 3, 4)], "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
+ISA_PATHS = [os.path.join(_HERE, "lib", f"{k}-gfx950.s") for k in ("kernel_gather", "kernel_framelane", "kernel_framelane_sub", "kernel_framelane_pair", "kernel_periodic", "kernel_rowpair", "kernel_strip", "kernel_colpair", "kernel_direct", *[f"kernel_direct_walk_{t}_sx{x}" for t in ("u8", "u16", "f32") for x in (1, 2, 3, 4)], "kernel_colstrip", "kernel_quasi_fs7", "kernel_quasi_fs9", "kernel_quasi_exact_fs7",
                        "kernel_quasi_exact_fs9", "kernel_quasi_lane_fs7", "kernel_quasi_lane_fs9")]
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip.h")
 TEST_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "jincresize_hip_test.h")  # introspection, knobs, hooks

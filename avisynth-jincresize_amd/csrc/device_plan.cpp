@@ -118,7 +118,7 @@ void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vect
 void attach_rowpair(DeviceTable& t, jinc::PeriodicArgs& pa, int n, int ny, const std::vector<const float*>& sets, bool trimmed) {
     pa.rowpair = nullptr;
     pa.rowpair_n = pa.rowpair_ny = pa.rowpair_stride = 0;
-    if (!jinc::rowpair_supported(n) || ny > n || ny < 1 || pa.px != 2 || pa.py > 8 || pa.start_x[0] != pa.start_x[1] ||
+    if (!jinc::rowpair_supported(n) || ny > n || ny < 1 || pa.px != 2 || pa.py > jinc::PeriodicArgs::kRowPairMaxPhases || pa.start_x[0] != pa.start_x[1] ||
         pa.start_x[0] != pa.min_sx)
         return;
     const int stride = (2 * n + 3) & ~3;  // floats per kernel row: n pairs, padded to 16 bytes
@@ -137,6 +137,18 @@ void attach_rowpair(DeviceTable& t, jinc::PeriodicArgs& pa, int n, int ny, const
                 tr = std::min(tr, std::min(lead, trail));
             }
             bits |= static_cast<uint64_t>(trimmed ? tr : 0) << (3 * ly);
+        }
+        if (trimmed) {  // kernel rows that are zero throughout for both p, in front of and behind the rest (border rows: shifted windows)
+            auto zero_row = [&](int ly) {
+                for (int px = 0; px < 2; ++px)
+                    for (int lx = 0; lx < n; ++lx)
+                        if (sets[static_cast<size_t>(q * 2 + px)][ly * n + lx] != 0.f) return false;
+                return true;
+            };
+            int first = 0, last = ny;  // [first, last)
+            while (first < ny - 1 && zero_row(first)) ++first;
+            while (last > first + 1 && zero_row(last - 1)) --last;
+            bits |= static_cast<uint64_t>(first) << 54 | static_cast<uint64_t>(last) << 59;
         }
         pa.rowpair_trim[q] = bits;
     }
@@ -636,6 +648,98 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
     if (!t.strips_ok) t.border_rects.private_sets = t.border_rects.unit_stride = true;  // coefficients per lane
 }
 
+// Border rows of 2x up-scales with 10 .. 17 taps per kernel row on ewa_periodic_rowpair_kernel (round 5): the rows of one end of the
+// plane, interior columns, are one launch of the interior's packed kernel (its one-period-row form) with the rows as its "row phases" -- every
+// border row has one coefficient set per column phase (strips_ok) and all rows of an end share their window origin (the reference
+// shifts every border window back to the image's first / last fs lines, ref :395-418), which is all that kernel asks of a phase.
+// ewa_direct_kernel's row strips, which these launches replace, ran at about a sixth of the interior's rate per tap (C3: 0.10 ms per
+// plane and launch for 1.5 % of the samples).
+// Integer planes leave out the zero taps of each (row, kernel row) chord as the interior does, and the kernel rows that are zero
+// throughout (the windows are shifted against the disc); float planes execute every tap.
+void plan_rowpair_rows(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples) {
+    t.rowpair_rows.clear();
+    if (!t.use_periodic || !t.use_direct || !t.strips_ok || !jinc::rowpair_strip_supported(p.fs)) return;
+    const jinc::PeriodicArgs& pa = t.periodic;
+    if (pa.px != 2 || pa.start_x[0] != pa.start_x[1] || pa.start_x[0] != pa.min_sx) return;
+    const int H = p.g.dst_h, y_end = pa.iy0 + pa.py * pa.nj;
+    const int ends[2][2] = {{0, pa.iy0}, {y_end, H}};
+    std::vector<jinc::PeriodicArgs> launches;
+    for (const auto& e : ends) {
+        const int m = e[1] - e[0];
+        if (m <= 0) continue;
+        if (m > jinc::PeriodicArgs::kRowPairMaxPhases) return;
+        const int origin = p.row_start[static_cast<size_t>(e[0])];
+        for (int y = e[0]; y < e[1]; ++y)
+            if (p.row_start[static_cast<size_t>(y)] != origin) return;
+        if (origin < 0 || origin + p.fs > p.g.src_h) return;
+        jinc::PeriodicArgs ra = pa;
+        ra.quad = nullptr, ra.row_trim = nullptr, ra.coeffs = nullptr, ra.rows_ny = 0;
+        ra.edge = jinc::PeriodicArgs::EdgeColumns{};
+        ra.py = m, ra.iy0 = e[0], ra.nj = 1;
+        ra.rowpair_strip_phases = (m + (m + 7) / 8 - 1) / ((m + 7) / 8);  // groups of at most eight rows (a row per wave), evenly: 17 -> 6 + 6 + 5
+        for (int q = 0; q < 8; ++q) ra.start_y[q] = origin;
+        ra.min_sy = origin;
+        std::vector<const float*> sets;
+        for (int q = 0; q < m; ++q)
+            for (int px = 0; px < 2; ++px) sets.push_back(p.set_ptr(p.set_of(pa.ix0 + px, e[0] + q)));
+        attach_rowpair(t, ra, p.fs, p.fs, sets, integer_samples);
+        if (!ra.rowpair) return;
+        launches.push_back(ra);
+    }
+    t.rowpair_rows = launches;
+}
+
+// Border columns on ewa_colpair_kernel (round 5; kernels.h ColPairArgs): exactly periodic plans at source step 1 whose border columns
+// repeat their sets with the interior's period (strips_ok) and share one window origin per side.
+void plan_colpair(const jinc::PlanePlan& p, DeviceTable& t) {
+    t.use_colpair = false;
+    t.colpair = jinc::ColPairArgs{};
+    if (!t.use_direct || !t.strips_ok || p.sy != 1 || p.py > 4) return;
+    const jinc::DirectArgs& da = t.direct;
+    jinc::ColPairArgs ca;
+    ca.fs = p.fs, ca.py = p.py, ca.iy0 = da.iy0, ca.nj = da.nj;
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int q = 0; q < p.py; ++q) {
+        ca.start_y[q] = da.start_y[q];
+        lo = std::min(lo, da.start_y[q]), hi = std::max(hi, da.start_y[q]);
+    }
+    ca.min_sy = lo, ca.spread = hi - lo;
+    if (!jinc::colpair_supported(p.fs, p.py, p.sy, ca.spread)) return;
+    ca.src_w = p.g.src_w, ca.src_h = p.g.src_h, ca.dst_h = p.g.dst_h;
+    const int fs = p.fs, x_end = da.ix0 + da.px * da.ni, W = p.g.dst_w;
+    const int side_x0[2] = {0, x_end}, side_n[2] = {da.ix0, W - x_end};
+    constexpr int kMaxGroups = jinc::ColPairArgs::kMaxGroups;
+    const size_t block = static_cast<size_t>(fs) * 4 * fs;  // floats per (side, group, q)
+    std::vector<float> blob(static_cast<size_t>(2) * kMaxGroups * p.py * block, 0.f);
+    bool any = false;
+    for (int s = 0; s < 2; ++s) {
+        const int n = side_n[s];
+        if (n <= 0) continue;
+        if (n > 4 * kMaxGroups) return;
+        const int origin = p.col_start[static_cast<size_t>(side_x0[s])];
+        for (int k = 1; k < n; ++k)
+            if (p.col_start[static_cast<size_t>(side_x0[s] + k)] != origin) return;
+        if (origin < 0 || origin + fs > p.g.src_w) return;
+        for (int k = 0; k < n; ++k)
+            for (int q = 0; q < p.py; ++q) {
+                const float* set = p.set_ptr(p.set_of(side_x0[s] + k, da.iy0 + q));
+                float* dst = &blob[(static_cast<size_t>(s * kMaxGroups + k / 4) * p.py + q) * block];
+                for (int ly = 0; ly < fs; ++ly)
+                    for (int lx = 0; lx < fs; ++lx) dst[(static_cast<size_t>(ly) * fs + lx) * 4 + k % 4] = set[ly * fs + lx];
+            }
+        ca.n[s] = n, ca.x0[s] = side_x0[s], ca.origin[s] = origin;
+        any = true;
+    }
+    if (!any) return;
+    void* dev = nullptr;
+    hip_check(hipMalloc(&dev, blob.size() * sizeof(float)), "hipMalloc(column pair coefficients)");
+    t.lane_blobs.push_back(dev);  // freed with the table
+    hip_check(hipMemcpy(dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice), "column pair coefficient upload");
+    ca.coeffs = static_cast<const float*>(dev);
+    t.colpair = ca;
+    t.use_colpair = true;
+}
+
 // Border columns inside the interior kernel (ewa_periodic_quad2_kernel / ewa_periodic_quad2x8_kernel, integer planes): the columns left and right of the
 // interior, interior rows only (the corners stay with the corner kernel), are computed by the first and the last tile column of the
 // interior launch from the source tile it has staged anyway.  As kernels of their own these 7 + 5 columns of C2 cost 0.28 ms of a
@@ -875,6 +979,8 @@ void init_device(jinc_filter& f, int device) {
         plan_direct(f.plans[i], f.tables[i]);
         trim_direct(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
         plan_edge_columns(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
+        plan_rowpair_rows(f.plans[i], f.tables[i], f.vi_in.component_size < 4);
+        plan_colpair(f.plans[i], f.tables[i]);
         plan_runs(f.plans[i], f.tables[i]);
         {   // every interior variant of a table must cover the same extent: the border frame is laid out once
             const DeviceTable& t = f.tables[i];

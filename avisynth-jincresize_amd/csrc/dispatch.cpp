@@ -581,9 +581,15 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             const int lds_knob = knobs::geti(JINC_KNOB_STRIP_LDS, 1);
             const bool lds_strips = f.border_strips >= 3 || (lds_knob != 0 && f.border_strips < 0 && f.kernel_mode != 3);
             const bool strip_rows = lds_strips && t.use_strip_rows;
-            const bool strip_cols = !edge_fused && lds_strips && t.use_strip_cols &&
+            // Columns on packed column pairs (ewa_colpair_kernel) wherever configured (odd filter sizes 7 .. 17 at source step 1): C3
+            // 0.24 -> 0.08 ms per step against ewa_colstrip_kernel (+3.7 %), tap 6 at 2x +2.9 %, two 8K float frames per call +16 %,
+            // level elsewhere (round5/colpair_ab.log).  Knob COLPAIR: 0 never, 1 (default) this rule, 3 filter sizes from 11 on only.
+            const int colpair_knob = knobs::geti(JINC_KNOB_COLPAIR, 1);
+            const bool pair_cols = !edge_fused && t.use_colpair && (f.border_strips < 0 || f.border_strips == 4) && f.kernel_mode != 3 &&
+                                   (colpair_knob == 1 || colpair_knob == 2 || (colpair_knob == 3 && t.plan.fs >= 11));
+            const bool strip_cols = !edge_fused && !pair_cols && lds_strips && t.use_strip_cols &&
                                     (f.border_strips >= 3 || lds_knob == 2 || !(t.use_fl_cols && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames));
-            const bool fl_cols = !edge_fused && !strip_cols && t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
+            const bool fl_cols = !edge_fused && !pair_cols && !strip_cols && t.use_fl_cols && f.border_strips != 2 && fl_cols_min_frames > 0 && nframes >= fl_cols_min_frames &&
                                  (f.kernel_mode == 0 || f.kernel_mode == 13 || f.kernel_mode == 2);
             if (fl_cols) {
                 auto aligned_to = [&](uintptr_t bytes) {
@@ -600,16 +606,22 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
                 else
                     timed(f.ev_gather, border_stream, "border column frame-lane kernel launch", [&](hipStream_t s) { return jinc::launch_framelane(fa, s); });
             }
-            t.last_border = (strip_rows ? 16 : 2) | (edge_fused ? 64 : strip_cols ? 32 : fl_cols ? 8 : (t.use_colstrip && f.border_strips != 2) ? 4 : 1);
-            if (strip_cols || strip_rows || edge_fused) {
-                if (t.corner_rects.n > 0 && (strip_cols || edge_fused))
+            // Rows of filter sizes 11 .. 17 at 2x: launches of ewa_periodic_rowpair_kernel (plan_rowpair_rows).  Knob ROWPAIR_ROWS = 0:
+            // ewa_direct_kernel's row strips.
+            const bool pair_rows = !strip_rows && !t.rowpair_rows.empty() && (f.border_strips < 0 || f.border_strips == 4) && f.kernel_mode != 3 &&
+                                   knobs::flag(JINC_KNOB_ROWPAIR_ROWS, true);
+            t.last_border = (strip_rows ? 16 : pair_rows ? 128 : 2) | (edge_fused ? 64 : pair_cols ? 256 : strip_cols ? 32 : fl_cols ? 8 : (t.use_colstrip && f.border_strips != 2) ? 4 : 1);
+            if (strip_cols || strip_rows || edge_fused || pair_cols) {
+                if (t.corner_rects.n > 0 && (strip_cols || edge_fused || pair_cols))
                     timed(f.ev_gather, border_stream, "corner kernel launch", [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
                 if (strip_rows)
                     timed(f.ev_gather, border_stream, "border row strip launch", [&](hipStream_t s) { return jinc::launch_strip(t.strip_rows, io, s); });
                 if (strip_cols)
                     timed(f.ev_gather, border_stream, "border column strip launch", [&](hipStream_t s) { return jinc::launch_strip(t.strip_cols, io, s); });
+                if (pair_cols)
+                    timed(f.ev_gather, border_stream, "border column pair launch", [&](hipStream_t s) { return jinc::launch_colpair(t.colpair, io, s); });
             }
-            const bool colstrip = !edge_fused && !strip_cols && !fl_cols && t.use_colstrip && f.border_strips != 2;
+            const bool colstrip = !edge_fused && !pair_cols && !strip_cols && !fl_cols && t.use_colstrip && f.border_strips != 2;
             // the corner kernel first: few workgroups with long latency-bound chains (per-lane coefficients); queued
             // last it would start when the interior kernel already holds every wave slot.  (Measured again in round 3 with
             // the corners last: no difference on any of eight configurations -- in a long batch the border kernels cost their
@@ -617,13 +629,20 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
             if (colstrip && t.corner_rects.n > 0)
                 timed(f.ev_gather, border_stream, "corner kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.corner_rects, s); });
-            if (!strip_rows)
+            if (pair_rows) {
+                for (const jinc::PeriodicArgs& ra : t.rowpair_rows)
+                    timed(f.ev_gather, border_stream, "border row pair launch", [&](hipStream_t s) {
+                        const int rc = jinc::launch_rowpair(ra, io, s);
+                        (void)knobs::take_instance();  // (the border's launch does not name the call)
+                        return rc;
+                    });
+            } else if (!strip_rows)
                 timed(f.ev_gather, border_stream, "border row kernel launch",
                       [&](hipStream_t s) { return jinc::launch_direct_row_strips(rs, io, s); });
             if (colstrip) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_colstrip(t.col_strips, io, s); });
-            } else if (!edge_fused && !fl_cols && !strip_cols && t.column_rects.n > 0) {
+            } else if (!edge_fused && !pair_cols && !fl_cols && !strip_cols && t.column_rects.n > 0) {
                 timed(f.ev_gather, border_stream, "border column kernel launch",
                       [&](hipStream_t s) { return jinc::launch_gather(t.plan, io, t.column_rects, s); });
             }

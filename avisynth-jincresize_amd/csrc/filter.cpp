@@ -407,8 +407,10 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
     if (rows_kernel == 4) {  // ewa_periodic_rowpair_kernel: the spans both phases p of a (q, kernel row) share
         const jinc::PeriodicArgs& pa = (trimmed && t.trim_nx == t.trim_fs) ? t.periodic_trim : t.periodic;
         double taps = 0;
-        for (int q = 0; q < pa.py; ++q)
-            for (int ly = 0; ly < pa.rowpair_ny; ++ly) taps += pa.rowpair_n - 2 * static_cast<int>((pa.rowpair_trim[q] >> (3 * ly)) & 7u);
+        for (int q = 0; q < pa.py; ++q) {
+            const int first = static_cast<int>(pa.rowpair_trim[q] >> 54) & 31, last = static_cast<int>(pa.rowpair_trim[q] >> 59) & 31;  // kernel rows executed
+            for (int ly = first; ly < (last ? last : pa.rowpair_ny); ++ly) taps += pa.rowpair_n - 2 * static_cast<int>((pa.rowpair_trim[q] >> (3 * ly)) & 7u);
+        }
         return pa.rowpair ? taps / pa.py : 0.0;
     }
     if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && trimmed) return 42.0;  // 6 rows x 7 columns

@@ -72,6 +72,9 @@ struct DeviceTable {
     jinc::FrameLaneArgs fl_cols;
     // ... or (round 5, filter sizes up to 9, source step 1) on kernel_strip.hip: one register window per lane for the strip's thickness
     bool use_strip_rows = false, use_strip_cols = false;
+    std::vector<jinc::PeriodicArgs> rowpair_rows;  // border rows as launches of ewa_periodic_rowpair_kernel (plan_rowpair_rows); empty: none
+    bool use_colpair = false;  // border columns on ewa_colpair_kernel (plan_colpair)
+    jinc::ColPairArgs colpair;
     bool use_edge_cols = false;  // border columns inside ewa_periodic_quad2_kernel's edge tiles (plan_edge_columns)
     jinc::PeriodicArgs::EdgeColumns edge_cols;
     jinc::StripArgs strip_rows, strip_cols;

@@ -98,10 +98,18 @@ struct PeriodicArgs {
     int rows_ny = 0;  // ewa_periodic_rows_kernel on a support with fewer kernel rows than taps per row: the row count (0: fs rows)
     // ewa_periodic_rowpair_kernel (2x up-scales with 12 .. 17 taps per kernel row whose two phases p share their window origin):
     // coefficient pairs rowpair[(q * rowpair_ny + ly) * rowpair_stride + 2 * lx + p] = set(p, q)[ly][lx], and per q the taps each
-    // kernel row leaves out on either side for BOTH p, three bits per kernel row (bits 3 * ly ...); nullptr: no such form
+    // kernel row leaves out on either side for BOTH p, three bits per kernel row (bits 3 * ly ...), and in bits 54 .. 58 / 59 .. 63 the
+    // first kernel row executed / the one behind the last (0: all rowpair_ny) -- the rows outside are zero for both p; nullptr: no such form
+    // Border rows as launches of the same kernel (device_plan.cpp plan_rowpair_rows): the border rows of one end of the plane are the
+    // py <= kRowPairMaxPhases "row phases" of a launch with nj = 1, every one with its own coefficient pairs and all with the window
+    // origin start_y[0] (py > 8: start_y[q] is not read).  rowpair_strip_phases > 0 marks such a launch: its grid's y counts groups of
+    // that many phases (a workgroup = one group x one tile column: 17 rows in one workgroup were three rounds of its eight waves on
+    // a chip the launch does not fill -- C3: 46 us per launch), not tile rows.
+    static constexpr int kRowPairMaxPhases = 24;
+    int rowpair_strip_phases = 0;
     const float* rowpair = nullptr;
     int rowpair_n = 0, rowpair_ny = 0, rowpair_stride = 0;
-    uint64_t rowpair_trim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t rowpair_trim[kRowPairMaxPhases] = {};
     // float planes on the trimmed support: frame_flags[frame] (kernel_scan.hip: 1 = the frame's plane holds a non-finite
     // sample) decides which of two launches computes a frame -- a launch returns at once for frames whose flag differs from
     // run_when.  nullptr: every frame.
@@ -325,10 +333,26 @@ struct StripArgs {
     int line0[4] = {0, 0, 0, 0}, nlines[4] = {0, 0, 0, 0}, origin[4] = {0, 0, 0, 0}, set_base[4] = {0, 0, 0, 0};
     int src_w = 0, src_h = 0, dst_h = 0;
 };
+// Border columns on packed column pairs (kernel_colpair.hip): side s (0 left, 1 right) = n[s] output columns from x0[s] on, all with the
+// source window columns origin[s] .. origin[s] + fs - 1; output row iy0 + py * j + q reads the source rows start_y[q] + j ...
+// coeffs[(((s * kMaxGroups + g) * py + q) * fs + ly) * 4 fs + 4 lx + k] = set(x0[s] + 4 g + k, q)[ly][lx] (0 beyond the side's last column).
+struct ColPairArgs {
+    static constexpr int kMaxGroups = 6;  // groups of four columns per side
+    const float* coeffs = nullptr;
+    int fs = 0, py = 1, iy0 = 0, nj = 0;
+    int start_y[4] = {0, 0, 0, 0};
+    int min_sy = 0, spread = 0;
+    int n[2] = {0, 0}, x0[2] = {0, 0}, origin[2] = {0, 0};
+    int src_w = 0, src_h = 0, dst_h = 0;
+};
+bool colpair_supported(int fs, int py, int sy, int spread);
+int launch_colpair(const ColPairArgs& args, const PlaneIO& io, void* stream);
+
 bool strip_supported(int fs, int period, int step, int spread);
 int launch_strip(const StripArgs& args, const PlaneIO& io, void* stream);
 // kernel_rowpair.hip: the row-streamed kernel in packed phase-pair form (PeriodicArgs::rowpair; 12 .. 17 taps per kernel row)
 bool rowpair_supported(int taps_per_row);
+bool rowpair_strip_supported(int taps_per_row);  // ... as strips of border rows (PeriodicArgs::rowpair_strip_phases)
 int launch_rowpair(const PeriodicArgs& args, const PlaneIO& io, void* stream);
 // kernel_scan.hip: flags[frame] = 1 where the frame's float source plane (w x h samples) holds an infinity or a NaN
 int launch_finite_scan(const PlaneIO& io, int w, int h, uint32_t* flags, void* stream);

@@ -133,6 +133,8 @@ typedef enum jinc_knob {
     JINC_KNOB_ROWPAIR_SMALL,          /* 1: ewa_periodic_rowpair_kernel also on 6 .. 9 taps per kernel row (default: the window / quad forms there) */
     JINC_KNOB_STRIP_LDS,              /* 0: border rows / columns of periodic plans on the round-4 kernels; 1 (default): ewa_strip_kernel by rule; 2: rows and columns on it always */
     JINC_KNOB_EDGE_COLS,              /* 0: border columns on the border kernels even where ewa_periodic_quad2_kernel's edge tiles could compute them (round 5) */
+    JINC_KNOB_ROWPAIR_ROWS,           /* 0: border rows of filter sizes 11 .. 17 at 2x on ewa_direct_kernel's row strips instead of ewa_periodic_rowpair_kernel launches (round 5) */
+    JINC_KNOB_COLPAIR,                /* border columns on ewa_colpair_kernel: 0 never, 1 (default) wherever configured, 3 filter sizes from 11 on only (round 5) */
     JINC_KNOB_COUNT
 } jinc_knob;
 JINC_API int jinc_debug_set_knob(int knob, double value);
@@ -191,7 +193,7 @@ JINC_API int jinc_debug_transport_counts(long long *by_shader, long long *by_dma
 JINC_API int jinc_filter_set_border_strips(jinc_filter *f, int enable);
 /* Which kernels computed the border frame of `table` in the most recent frame call, as bits: 1 gather kernel over the frame (or its
  * columns), 2 ewa_direct_kernel row strips, 4 ewa_colstrip_kernel, 8 frame-lane kernel over the columns, 16 / 32 ewa_strip_kernel
- * over the rows / the columns, 64 the columns inside the interior kernel's edge tiles (ewa_periodic_quad2_kernel, integer planes);
+ * over the rows / the columns, 256 ewa_colpair_kernel over the columns, 128 the rows as launches of ewa_periodic_rowpair_kernel, 64 the columns inside the interior kernel's edge tiles (ewa_periodic_quad2_kernel, integer planes);
  * 0: no border launch recorded (plans whose border is not a strip frame). */
 JINC_API int jinc_filter_last_border(const jinc_filter *f, int table);
 /* 1: the border kernels run on a side stream concurrently with the interior kernel (fork/join by events around

@@ -37,7 +37,7 @@ def test_no_fused_multiply_add_in_device_code(pkg):
     isa = "\n".join(open(p).read() for p in pkg.ISA_PATHS)
     kernels = re.findall(r"^(_ZN4jinc\S*kernel\S*):", isa, flags=re.M)
     for name in ("ewa_gather_kernel", "ewa_periodic_kernel", "ewa_periodic_rows_kernel", "ewa_periodic_pk_kernel", "ewa_periodic_quad_kernel", "ewa_periodic_quad2_kernel", "ewa_periodic_quad8_kernel", "ewa_periodic_quad2x8_kernel", "ewa_periodic_rowpair_kernel",
-                 "ewa_quasi_kernel", "ewa_framelane_kernel", "ewa_framelane_win_kernel", "ewa_framelane_win1k_kernel", "ewa_framelane_sub_kernel", "ewa_framelane_pair_kernel", "ewa_direct_kernel", "ewa_colstrip_kernel", "ewa_strip_kernel"):
+                 "ewa_quasi_kernel", "ewa_framelane_kernel", "ewa_framelane_win_kernel", "ewa_framelane_win1k_kernel", "ewa_framelane_sub_kernel", "ewa_framelane_pair_kernel", "ewa_direct_kernel", "ewa_colstrip_kernel", "ewa_strip_kernel", "ewa_colpair_kernel"):
         assert any(name in k for k in kernels), name
     fused = re.findall(r"^\s+(v_fma_f32|v_fmac_f32|v_mad_f32|v_mac_f32|v_pk_fma_f32|v_fma_mix\w*|v_mfma\w*)\b", isa, flags=re.M)
     assert fused == [], f"fused ops in device code: {sorted(set(fused))}"

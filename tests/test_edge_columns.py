@@ -61,14 +61,14 @@ def test_edge_columns_match_the_oracle_and_the_border_kernels(gpu_pkg, O, case, 
         pytest.skip("no table of this plan puts its border columns into the interior kernel")
     for t in fused:
         assert f.last_instance(t).startswith(("ewa_periodic_quad2_kernel<", "ewa_periodic_quad2x8_kernel<")), f.last_instance(t)
-        assert f.last_border(t) & (32 | 8 | 4 | 1) == 0, f.last_border(t)   # no column kernel beside it
+        assert f.last_border(t) & (256 | 32 | 8 | 4 | 1) == 0, f.last_border(t)   # no column kernel beside it
     with gpu_pkg.knobs(edge_cols=0):
         plain = run(4)
         assert all(f.last_border(t) & 64 == 0 for t in range(f.num_tables))
     gathered = run(0)
     for k in range(frames):
         assert_planes_equal(got[k], want[k], f.out_dims(), what=f"{_id(case)} frame {k}: edge columns vs oracle")
-        assert_planes_equal(got[k], plain[k], f.out_dims(), what=f"{_id(case)} frame {k}: edge columns vs ewa_strip_kernel's columns")
+        assert_planes_equal(got[k], plain[k], f.out_dims(), what=f"{_id(case)} frame {k}: edge columns vs the column kernel's")
         assert_planes_equal(got[k], gathered[k], f.out_dims(), what=f"{_id(case)} frame {k}: edge columns vs the gather kernel's border")
     f.close()
 

@@ -324,7 +324,15 @@ def test_lookahead_in_the_vapoursynth_shell(vs, O, pkg, case, kernel, monkeypatc
         assert err is None, err
         seen.add(pkg.last_call())
         got = [c.read_plane(fr, i, np.uint8) for i in range(fmt.planes)]
-        assert_planes_equal(got, want[n], fmt.plane_dims(tw, th), what=f"{fn} frame {n} grouped vs single")
+        try:
+            assert_planes_equal(got, want[n], fmt.plane_dims(tw, th), what=f"{fn} frame {n} grouped vs single")
+        except AssertionError as e:   # which of the two is it, and where: the oracle decides
+            ref = of.get_frame(frames[n], threads=8)
+            w, h = fmt.plane_dims(tw, th)[0]
+            bad = np.argwhere(got[0][:h, :w] != want[n][0][:h, :w])
+            sides = (int((got[0][:h, :w] != ref[0][:h, :w]).sum()), int((want[n][0][:h, :w] != ref[0][:h, :w]).sum()))
+            raise AssertionError(f"{e}; plane 0 differs in rows {bad[:, 0].min()}..{bad[:, 0].max()}, columns {bad[:, 1].min()}..{bad[:, 1].max()}; "
+                                 f"samples off the oracle: grouped {sides[0]}, single {sides[1]}; launches seen so far {sorted(seen)}") from None
         if n in (0, 41):
             assert_planes_equal(got, of.get_frame(frames[n], threads=8), fmt.plane_dims(tw, th), what=f"{fn} frame {n} vs oracle")
         assert c.prop(fr, "_MockFrameNumber") == n

@@ -52,8 +52,8 @@ def test_rowpair_kernel_matches_oracle_and_rows_kernel(gpu_pkg, O, case, lw):
                 continue
             inst = f.last_instance(t)
             assert inst.startswith("ewa_periodic_rowpair_kernel<"), inst
-            n, shape = [int(x) for x in inst.rstrip(">").split(",")[1:]]
-            assert n == taps[t] and (lw == 0 or shape == lw), inst
+            n, shape, rows = [int(x) for x in inst.rstrip(">").split(",")[1:]]   # taps per kernel row, lanes along x, period-rows per lane
+            assert n == taps[t] and (lw == 0 or shape == lw) and rows == 2, inst
     assert_planes_equal(got, want, f.out_dims(), what=_id(case))
     f.set_kernel_mode(gpu_pkg.KernelMode.ROWS)       # the un-packed kernel on the same support
     rows = f.get_frame(src)

@@ -93,17 +93,21 @@ def test_strip_kernel_is_the_automatic_choice_in_large_calls(gpu_pkg, O):
     assert f.last_border(0) == (16 | 64), f.last_border(0)       # rows on ewa_strip_kernel, columns inside ewa_periodic_quad2_kernel's edge tiles
     assert f.last_instance(0).startswith("ewa_periodic_quad2_kernel<unsigned char"), f.last_instance(0)
     with gpu_pkg.knobs(edge_cols=0):
+        pairs = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+        assert f.last_border(0) == (16 | 256), f.last_border(0)  # ... columns on ewa_colpair_kernel
+    with gpu_pkg.knobs(edge_cols=0, colpair=0):
         auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
         assert f.last_border(0) == (16 | 8), f.last_border(0)    # ... columns (24 frames) on the frame-lane kernel
-    with gpu_pkg.knobs(strip_lds=2, edge_cols=0):
+    with gpu_pkg.knobs(strip_lds=2, edge_cols=0, colpair=0):
         both = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
         assert f.last_border(0) == 48, f.last_border(0)
-    with gpu_pkg.knobs(strip_lds=0, edge_cols=0):
+    with gpu_pkg.knobs(strip_lds=0, edge_cols=0, colpair=0):
         old = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
         assert f.last_border(0) == (2 | 8), f.last_border(0)     # direct row strips + frame-lane columns
     for k in range(frames):
         assert_planes_equal(fused[k], old[k], f.out_dims(), what=f"frame {k}: border columns in the interior kernel vs the round-4 border kernels")
         assert_planes_equal(auto[k], old[k], f.out_dims(), what=f"frame {k}: ewa_strip_kernel vs the round-4 border kernels")
+        assert_planes_equal(pairs[k], old[k], f.out_dims(), what=f"frame {k}: ewa_colpair_kernel's columns vs the round-4 border kernels")
         assert_planes_equal(both[k], old[k], f.out_dims(), what=f"frame {k}: ewa_strip_kernel on rows and columns vs the round-4 border kernels")
         if k in (0, 11, frames - 1):
             assert_planes_equal(fused[k], of.get_frame(srcs[k], threads=16), f.out_dims(), what=f"frame {k} vs oracle")
