@@ -40,7 +40,9 @@ for cfg in ("C2", "C3", "C4", "A137", "N15", "N15T8", "N15T4"):
     # (Rounds 3-4 took the luma instantiation's launches alone, 2/3 of the step's bytes, against a third of the step's
     # algorithmic bytes: the "2.01 x" of VERDICT r4, an accounting error, not re-reads.)
     family = name.split("<")[0]
-    members = [(k, v) for k, v in (interior or cands) if k.split("<")[0] == family and "FETCH_SIZE_launches" in v]
+    # (round 5: the row-pair kernel's one-period-row form <.., N, 64, 1> is a BORDER launch -- the rows of an end of a plane -- not a plane's interior)
+    border_form = lambda k: k.startswith("ewa_periodic_rowpair_kernel<") and k.rstrip(">").endswith(", 1")
+    members = [(k, v) for k, v in (interior or cands) if k.split("<")[0] == family and "FETCH_SIZE_launches" in v and not border_form(k)]
     steps = e.get("FETCH_SIZE_launches") or 1
     per_step = sum((2 * v["FETCH_SIZE_bytes_mean"] + v["WRITE_SIZE_bytes_mean"]) * v["FETCH_SIZE_launches"] for _, v in members) / steps
     per_step_raw = sum(v["hbm_bytes_per_launch_raw"] * v["FETCH_SIZE_launches"] for _, v in members) / steps
