@@ -503,7 +503,7 @@ STRIP_CASES = [
 ]
 
 
-@pytest.mark.parametrize("strips", [1, 2, 3, 0], ids=["strips", "row_strips_only", "strip_kernel", "gather_border"])
+@pytest.mark.parametrize("strips", [1, 2, 3, 4, 0], ids=["strips", "row_strips_only", "strip_kernel", "round5_forms", "gather_border"])
 @pytest.mark.parametrize("case", STRIP_CASES, ids=_id)
 def test_border_strips_and_gather_border_agree_with_oracle(gpu_pkg, O, case, strips):
     """The border frame of exactly periodic plans runs as row/column strips on ewa_direct_kernel (+ corners on the
@@ -695,9 +695,14 @@ def test_randomised_arguments(gpu_pkg, O, seed, gen):
     # with a tile's phases split over several workgroups (what small calls do in automatic mode).
     # exactly periodic plans: the strip kernels over the border frame, which calls of this size no longer take by themselves
     if any(f.plan_info(t).periodic for t in range(f.num_tables)):
-        for strips in (1, 3):   # the round-4 strip kernels; ewa_strip_kernel (round 5) where the plan has it
-            f.set_border_strips(strips)
+        for strips in (1, 3, 4):   # the round-4 strip kernels; ewa_strip_kernel (round 5) where the plan has it; 4: round 5's other
+            f.set_border_strips(strips)   # forms where configured (column pairs, rows on the pair kernel; edge columns under mode 13 below)
             assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + f" border strips {strips}")
+        f.set_border_strips(4)
+        f.set_kernel_mode(13)         # the quad forms with the border columns in their edge tiles (integer planes at 2x with tap 3 / 4)
+        with gpu_pkg.knobs(quad2x8=1):
+            assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=what + " border strips 4, quad forms")
+        f.set_kernel_mode(0)
         f.set_border_strips(-1)
         # the periodic family on the trimmed support (integer planes) in each of its forms -- window, rows, quad -- and on the
         # reference's full window (15)

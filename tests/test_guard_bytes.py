@@ -31,8 +31,8 @@ def test_nothing_outside_the_rows_is_written(gpu_pkg, O, case, pad):
     sdims, ddims = ofmt.plane_dims(sw, sh), f.out_dims()
     frame = O.lcg_frame(ofmt, sw, sh, seed=99)
     sb = frame[0].dtype.itemsize
-    # every batch size under the automatic border form and, for exactly periodic plans, with ewa_strip_kernel forced (round 5)
-    for n, strips in [(n, st) for n in sizes for st in ((-1, 3) if f.plan_info(0).periodic else (-1,))]:
+    # every batch size under the automatic border form and, for exactly periodic plans, with ewa_strip_kernel (3) and round 5's other border forms (4) forced
+    for n, strips in [(n, st) for n in sizes for st in ((-1, 3, 4) if f.plan_info(0).periodic else (-1,))]:
         f.set_border_strips(strips)
         # source: frames of a plane back to back, pitch = row bytes rounded up to 4
         sp = [(w * sb + 3) // 4 * 4 for (w, h) in sdims]
