@@ -13,6 +13,21 @@ try:
 except Exception:  # pragma: no cover
     torch = None
 
+# The host planes of these tests come and go (numpy arrays, the mock hosts' malloc'ed frames), and the look-ahead tests let the
+# library pin them in place (hipHostRegister, cached by address range: csrc/pipeline.cpp -- what a host with a frame POOL gains
+# from).  glibc's malloc is not a pool: it returns freed memory to the kernel (heap trim, munmap of large chunks) and hands the
+# same addresses out again on other pages, and a registration that outlives its pages is a GPU mapping of memory that is gone --
+# seen in round 5 as a memory access fault on a heap address in a later, unrelated synchronous call (1 of 5 runs of
+# tests/test_p*.py) and as a frame with a stale stretch (1 of 4 full runs).  INTEGRATION.md states the requirement (frame memory
+# stays mapped while JINCRESIZE_PIN_FRAMES is on); here the process models such a host: nothing malloc hands out goes back.
+try:
+    import ctypes
+    _libc = ctypes.CDLL(None)
+    _libc.mallopt(-1, 0x7FFFFFFF)   # M_TRIM_THRESHOLD: never shrink the heap
+    _libc.mallopt(-4, 0)            # M_MMAP_MAX: no allocation of its own mapping (munmap on free)
+except Exception:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
