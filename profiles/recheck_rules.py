@@ -45,8 +45,16 @@ CHECKS = [
     ("quad forms, not the row-pair kernel, on 6 taps per kernel row", "C2", 64, {}, {"env": {"JINC_ROWPAIR_SMALL": "1"}}, "row-pair kernel"),
     ("quad forms, not the row-pair kernel, on 8 taps per kernel row (float)", "C4", 16, {}, {"env": {"JINC_ROWPAIR_SMALL": "1"}}, "row-pair kernel"),
     ("border rows on ewa_strip_kernel", "C2", 1024, {}, {"env": {"JINC_STRIP_LDS": "0"}}, "ewa_direct_kernel row strips"),
-    ("border columns stay on the frame-lane kernel in batches", "C2", 1024, {}, {"env": {"JINC_STRIP_LDS": "2"}}, "ewa_strip_kernel columns"),
-    ("border columns on ewa_strip_kernel below the frame-lane threshold", "C2", 8, {}, {"env": {"JINC_STRIP_LDS": "0"}}, "column-strip kernel"),
+    # round 5, second half: the border where it executes least
+    ("border columns inside the interior kernel's edge tiles (tap 3)", "C2", 1024, {}, {"env": {"JINC_EDGE_COLS": "0"}}, "column kernel beside the interior"),
+    ("border columns inside the interior kernel's edge tiles (tap 3, 16 frames)", "C2", 16, {}, {"env": {"JINC_EDGE_COLS": "0"}}, "column kernel beside the interior"),
+    ("border columns inside the interior kernel's edge tiles (tap 4)", "C2T4", 256, {}, {"env": {"JINC_EDGE_COLS": "0"}}, "column kernel beside the interior"),
+    ("border columns on ewa_colpair_kernel (filter size 17)", "C3", 32, {}, {"env": {"JINC_COLPAIR": "0"}}, "ewa_colstrip_kernel"),
+    ("border columns on ewa_colpair_kernel (filter size 9, float)", "C4", 16, {}, {"env": {"JINC_COLPAIR": "0"}}, "frame-lane kernel's sub-group form"),
+    ("border columns on ewa_colpair_kernel (filter size 9, two frames per call)", "C4", 2, {}, {"env": {"JINC_COLPAIR": "0"}}, "ewa_strip_kernel columns"),
+    ("border columns on ewa_colpair_kernel (filter size 7, float)", "C2F", 64, {}, {"env": {"JINC_COLPAIR": "0"}}, "frame-lane kernel"),
+    ("border rows of taps 5 .. 8 as strips of the row-pair kernel (tap 8)", "C3", 32, {}, {"env": {"JINC_ROWPAIR_ROWS": "0"}}, "ewa_direct_kernel row strips"),
+    ("border rows of taps 5 .. 8 as strips of the row-pair kernel (tap 6)", "T6", 64, {}, {"env": {"JINC_ROWPAIR_ROWS": "0"}}, "ewa_direct_kernel row strips"),
 ]
 
 
@@ -62,7 +70,8 @@ def run(cfg, frames, variant):
 
 def main():
     rows = []
-    for rule, cfg, frames, choice, other, other_name in CHECKS:
+    first = int(os.environ.get("RECHECK_FROM", "0"))   # (a call of gpurun lasts 20 minutes at most: the list in two or three parts)
+    for rule, cfg, frames, choice, other, other_name in CHECKS[first:int(os.environ.get("RECHECK_TO", str(len(CHECKS))))]:
         a = [run(cfg, frames, choice) for _ in range(2)]   # alternating: choice, alternative, choice, alternative
         b = [run(cfg, frames, other) for _ in range(2)]
         va, vb = max(v for v, _ in a), max(v for v, _ in b)
