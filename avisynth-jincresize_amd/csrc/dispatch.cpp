@@ -53,6 +53,8 @@ struct Rules {
     static constexpr int kRunsFrameLaneBorderMinFramesSub = 8;
     // calls of exactly periodic plans below this many taps: one gather launch over the border frame instead of the strip kernels
     static constexpr double kStripBorderMinTaps = 5.0e9;
+    // ... single-plane calls whose border columns the interior kernel takes itself (see wants_border_strips)
+    static constexpr double kStripBorderMinTapsEdgeCols = 2.4e9;
     // multi-plane calls whose first plane has at most this many output samples run their other planes on the side stream
     static constexpr double kPlaneForkMaxSamples = 1.0e7;
     // filter sizes from which the runs form is the automatic choice at every call size; below (the quasi-periodic kernel's plans)
@@ -386,7 +388,19 @@ struct Choice {
             const DeviceTable& t = f.tables[f.table_of_plane(i)];
             taps += static_cast<double>(t.plan.dst_w) * t.plan.dst_h * t.plan.fs * t.plan.fs;
         }
-        return taps * nframes >= Rules::kStripBorderMinTaps;
+        if (taps * nframes >= Rules::kStripBorderMinTaps) return true;
+        // Single-plane calls whose border columns the interior kernel computes in its edge tiles (round 5): what is left of the strip
+        // border is two small launches (rows, corners) against the gather launch over the whole frame -- ahead from half the size
+        // (round5/small_call_border_ab.log: C2 at 6 / 8 / 12 frames per call +3 / +13 / +11 %, C1 at 64 / 96 +3.6 / +8.6 %; C2 at 4 and
+        // C1 at 32 level / behind; calls with chroma planes -- three times the launches -- stay behind up to the limit above).
+        if (f.planecount == 1 && f.border_strips < 0) {
+            const DeviceTable& t = f.tables[f.table_of_plane(0)];
+            const bool edge_form = t.use_edge_cols && t.strips_ok && (f.kernel_mode == 0 || f.kernel_mode == 13) && trimmed(t) && quad_chosen(t) &&
+                                   (periodic_fs(t) == 6 || (periodic_fs(t) == 8 && quad2x8_chosen(t, f.vi_in.component_size))) &&
+                                   knobs::flag(JINC_KNOB_EDGE_COLS, true) && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) != 1;
+            if (edge_form) return taps * nframes >= Rules::kStripBorderMinTapsEdgeCols;
+        }
+        return false;
     }
     // Small calls with chroma planes (no border fork): the planes behind the first go to the side stream, interior and border, so
     // that luma and chroma run beside each other -- a single frame's planes fill the chip even less one by one.
@@ -563,7 +577,7 @@ void launch_plane(jinc_filter& f, const Choice& c, int i, const void* const src[
         const bool strips = c.wants_border_strips() && t.strips_ok && c.direct_ok(t, i);
         edge_fused = strips && periodic && t.use_edge_cols && (f.border_strips < 0 || f.border_strips == 4) && (f.kernel_mode == 0 || f.kernel_mode == 13) && c.trimmed(t) &&
                      c.quad_chosen(t) && (c.periodic_fs(t) == 6 || (c.periodic_fs(t) == 8 && c.quad2x8_chosen(t, sb))) &&
-                     knobs::flag(JINC_KNOB_EDGE_COLS, true);
+                     knobs::flag(JINC_KNOB_EDGE_COLS, true) && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) != 1;  // (that knob sends the launch to the row-pair kernel)
         if (strips) {
             jinc::DirectArgs rs = t.row_strips;
             rs.src_bytes = direct_src_bytes(

@@ -1864,7 +1864,7 @@ int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* s
     if (args.rowpair && knobs::flag(JINC_KNOB_ROWS_PAIR, true)) {
         const int taps = args.quad_taps ? args.quad_taps : fs;  // (6 rows x 7 columns: fs = 6 rows, 7 taps per row)
         const bool auto_variant = variant == 0 || variant == 2 || variant == 5 || variant == 6 || variant == 7;
-        if (args.rowpair_n == taps && ((fs >= 10 && variant == 0) || (fs < 10 && auto_variant && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) == 1)))
+        if (args.rowpair_n == taps && ((fs >= 10 && variant == 0) || (fs < 10 && auto_variant && !args.edge.coeffs && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) == 1)))  // (edge columns: the caller counts on a quad form)
             return launch_rowpair(args, io, stream);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -24,8 +24,8 @@ CHECKS = [
     ("kFlSub4MaxFrames = 48: 64-frame form above", "A137", 56, {}, {"env": {"JINC_FL_SUB": "4"}}, "4 sub-groups"),
     ("sub-group form at all (16 frames)", "D169", 16, {}, {"env": {"JINC_FL_SUB": "0"}}, "64-frame form"),
     ("frame-pair form for whole groups of 128", "A137", 128, {}, {"args": ["--kernel-mode", "11"]}, "64-frame form"),
-    ("kFlColsMinFrames = 16: border columns on the frame-lane kernel", "C2", 16, {}, {"env": {"JINC_FL_COLS_FRAMES": "0"}}, "column-strip kernel"),
-    ("kFlColsMinFrames = 16: column strips below", "C2", 8, {}, {"env": {"JINC_FL_COLS_FRAMES": "3"}}, "frame-lane kernel"),
+    # (kFlColsMinFrames -- border columns of periodic plans on the frame-lane kernel from 16 frames on -- no longer decides anything at
+    #  source step 1: since round 5 the interior kernel's edge tiles or ewa_colpair_kernel take those columns; rules further down)
     ("kRunsFrameLaneBorderMinFramesSub = 8", "N15T4", 8, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
     ("kRunsFrameLaneBorderMinFrames = 32 (tap 8)", "N15T8", 32, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
     ("kQuad2x8MinWorkgroups: two periods per lane on 8 x 8", "C2T4", 9, {}, {"env": {"JINC_QUAD2X8": "0"}}, "one period per lane"),
@@ -53,6 +53,10 @@ CHECKS = [
     ("border columns on ewa_colpair_kernel (filter size 9, float)", "C4", 16, {}, {"env": {"JINC_COLPAIR": "0"}}, "frame-lane kernel's sub-group form"),
     ("border columns on ewa_colpair_kernel (filter size 9, two frames per call)", "C4", 2, {}, {"env": {"JINC_COLPAIR": "0"}}, "ewa_strip_kernel columns"),
     ("border columns on ewa_colpair_kernel (filter size 7, float)", "C2F", 64, {}, {"env": {"JINC_COLPAIR": "0"}}, "frame-lane kernel"),
+    ("kStripBorderMinTapsEdgeCols = 2.4e9: strip border from 6 C2 frames per call", "C2", 8, {}, {"args": ["--border-strips", "0"]}, "gather kernel over the border frame"),
+    ("kStripBorderMinTapsEdgeCols = 2.4e9: gather border below (4 C2 frames)", "C2", 4, {}, {"args": ["--border-strips", "4"]}, "strip border"),
+    ("kStripBorderMinTapsEdgeCols: C1 at 64 frames", "C1", 64, {}, {"args": ["--border-strips", "0"]}, "gather kernel over the border frame"),
+    ("kStripBorderMinTaps = 5e9 with chroma planes: gather border at 8 frames", "C2YUV", 8, {}, {"args": ["--border-strips", "4"]}, "strip border"),
     ("border rows of taps 5 .. 8 as strips of the row-pair kernel (tap 8)", "C3", 32, {}, {"env": {"JINC_ROWPAIR_ROWS": "0"}}, "ewa_direct_kernel row strips"),
     ("border rows of taps 5 .. 8 as strips of the row-pair kernel (tap 6)", "T6", 64, {}, {"env": {"JINC_ROWPAIR_ROWS": "0"}}, "ewa_direct_kernel row strips"),
 ]

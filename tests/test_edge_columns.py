@@ -100,3 +100,23 @@ def test_edge_columns_write_nothing_outside_their_plane(gpu_pkg, O):
         guard = out[k].copy()
         guard[2:2 + th, 7:7 + tw] = 0xA5
         assert (guard == 0xA5).all(), f"frame {k}: bytes outside the plane were written"
+
+
+def test_the_knob_that_reroutes_the_interior_launch_takes_the_columns_back(gpu_pkg, O):
+    """ROWPAIR_SMALL = 1 sends a tap-3 interior to the row-pair kernel, which has no edge tiles: the border columns must then come
+    from the column kernel again (found by bench.py's self-check under profiles/recheck_rules.py: no line, exit code 1)."""
+    fmt, sw, sh, tw, th = "Y8", 263, 150, 526, 300
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    src = O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=5)
+    want = of.get_frame(src, threads=8)
+    f.set_border_strips(4)
+    f.set_kernel_mode(gpu_pkg.KernelMode.QUAD)
+    assert_planes_equal(f.get_frame(src), want, f.out_dims(), what="quad form with edge columns")
+    assert f.last_border(0) & 64
+    for mode in (gpu_pkg.KernelMode.QUAD, 0):
+        f.set_kernel_mode(mode)
+        with gpu_pkg.knobs(rowpair_small=1):
+            assert_planes_equal(f.get_frame(src), want, f.out_dims(), what=f"kernel mode {int(mode)}, interior rerouted to the row-pair kernel")
+            assert f.last_border(0) & 64 == 0, (int(mode), f.last_border(0), f.last_instance(0))
+    f.close()
