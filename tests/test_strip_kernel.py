@@ -112,3 +112,23 @@ def test_strip_kernel_is_the_automatic_choice_in_large_calls(gpu_pkg, O):
         if k in (0, 11, frames - 1):
             assert_planes_equal(fused[k], of.get_frame(srcs[k], threads=16), f.out_dims(), what=f"frame {k} vs oracle")
     f.close()
+
+
+def test_single_plane_calls_take_the_strip_border_earlier_where_the_interior_takes_the_columns(gpu_pkg, O):
+    """Rules::kStripBorderMinTapsEdgeCols (round 5): 8 frames of 1080p -> 4K Y8 per call are 3.3e9 taps -- below the 5e9 from which every
+    plan takes the strip border, above the 2.4e9 from which single-plane calls do whose border columns the interior kernel computes;
+    4 frames stay on the gather launch over the border frame.  Both bit-exact."""
+    torch = pytest.importorskip("torch")
+    from test_framelane_pair import _run_batch
+    fmt, sw, sh, tw, th = "Y8", 1920, 1080, 3840, 2160
+    ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+    of = O.OracleFilter(ofmt, sw, sh, tw, th)
+    f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0)
+    srcs = [O.lcg_frame(ofmt, sw, sh, seed=8800 + k) for k in range(8)]
+    want = [of.get_frame(s, threads=16) for s in srcs]
+    for frames, border in ((8, 16 | 64), (4, 1)):
+        got = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+        assert f.last_border(0) == border, (frames, f.last_border(0))
+        for k in range(frames):
+            assert_planes_equal(got[k], want[k], f.out_dims(), what=f"{frames} frames per call, frame {k}")
+    f.close()
