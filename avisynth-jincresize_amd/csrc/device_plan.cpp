@@ -202,6 +202,23 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         for (int q = 0; q < pa.py; ++q) tr.start_y[q] = pa.start_y[q] + r0;
         tr.min_sy = pa.min_sy + r0;
         tr.quad_taps = 7;
+        {   // per (kernel row, q): the zero coefficients in front of / behind the row's span for BOTH phases p (kernels.h quad_span7)
+            const bool off = !knobs::flag(JINC_KNOB_QUAD_INNER, true);  // A/B knob
+            uint64_t spans = 0;
+            for (int q = 0; q < 2 && !off; ++q)
+                for (int ly = 0; ly < 6; ++ly) {
+                    int lead = 3, trail = 3;
+                    for (int px = 0; px < 2; ++px) {
+                        const float* r = &dense[(static_cast<size_t>(q * 2 + px) * 6 + ly) * 7];
+                        int a = 0, b = 0;
+                        while (a < 7 && r[a] == 0.f) ++a;
+                        while (b < 7 - a && r[6 - b] == 0.f) ++b;
+                        lead = std::min(lead, a), trail = std::min(trail, b);
+                    }
+                    spans |= static_cast<uint64_t>(lead) << (4 * (2 * ly + q)) | static_cast<uint64_t>(trail) << (4 * (2 * ly + q) + 2);
+                }
+            tr.quad_span7 = spans;
+        }
         t.periodic_trim = tr;
         std::vector<const float*> sets;
         for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * 42);

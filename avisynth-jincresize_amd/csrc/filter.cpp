@@ -413,7 +413,11 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
         }
         return pa.rowpair ? taps / pa.py : 0.0;
     }
-    if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && trimmed) return 42.0;  // 6 rows x 7 columns
+    if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && trimmed)  // 6 rows x 7 columns; with the MPEG-2 chords 36 of the 42
+        return (jinc::quad_span7_fits(t.periodic_trim.quad_span7, jinc::PeriodicArgs::kQuadSpan7Mpeg2) ||
+                jinc::quad_span7_fits(t.periodic_trim.quad_span7, jinc::PeriodicArgs::kQuadSpan7Mpeg2Swapped))
+                   ? jinc::quad_span7_taps(jinc::PeriodicArgs::kQuadSpan7Mpeg2) / 2.0
+                   : 42.0;
     if (rows_kernel == 3 && t.trim_fs == 6 && trimmed &&  // ewa_periodic_quad2_kernel: chord rows on four taps (half the samples each)
         (t.periodic_trim.quad_inner & jinc::PeriodicArgs::kQuadInnerTap3) == jinc::PeriodicArgs::kQuadInnerTap3)
         return 34.0;

@@ -1050,6 +1050,41 @@ __device__ __forceinline__ void quad2_row6_inner(f32x2& acc_a, f32x2& acc_b, f32
 #undef JINC_ADD2
 }
 
+// quad2_row7 on a span of its taps: the chord of a (kernel row, q) of the 6-row x 7-column support -- form 1 = taps 1 .. 6, 2 = taps
+// 1 .. 5, 3 = taps 2 .. 5 (form 0: all seven, quad2_row7) -- for rows whose other taps carry zero coefficients for BOTH phases p.
+// Chroma planes sited as MPEG-2 at 2x with tap 3: 36 of the 42 taps per sample (PeriodicArgs::kQuadSpan7Mpeg2).
+#define JINC_Q7_EVEN(W, C) /* tap t even: period A = the low half of pair t / 2, B its high half */                         \
+    "v_pk_mul_f32 %2, " W ", " C " op_sel_hi:[0,1]\n\tv_pk_mul_f32 %3, " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\t" \
+    "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+#define JINC_Q7_ODD(W, WN, C) /* tap t odd: A = the high half of pair t / 2, B the low half of the next pair */             \
+    "v_pk_mul_f32 %2, " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\tv_pk_mul_f32 %3, " WN ", " C " op_sel_hi:[0,1]\n\t" \
+    "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+template <int FORM>
+__device__ __forceinline__ void quad2_row7_span(f32x2& acc_a, f32x2& acc_b, f32x2 w0, f32x2 w1, f32x2 w2, f32x2 w3, f32x2 c0, f32x2 c1, f32x2 c2, f32x2 c3,
+                                                f32x2 c4, f32x2 c5, f32x2 c6) {
+    static_assert(FORM >= 0 && FORM <= 3, "span forms of the seven-tap row");
+    f32x2 ta, tb;
+    if constexpr (FORM == 0) {
+        quad2_row7(acc_a, acc_b, w0, w1, w2, w3, c0, c1, c2, c3, c4, c5, c6);
+    } else if constexpr (FORM == 1) {  // taps 1 .. 6
+        asm(JINC_Q7_ODD("%4", "%5", "%8") JINC_Q7_EVEN("%5", "%9") JINC_Q7_ODD("%5", "%6", "%10") JINC_Q7_EVEN("%6", "%11")
+            JINC_Q7_ODD("%6", "%7", "%12") JINC_Q7_EVEN("%7", "%13") ""
+            : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+            : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5), "s"(c6));
+    } else if constexpr (FORM == 2) {  // taps 1 .. 5
+        asm(JINC_Q7_ODD("%4", "%5", "%8") JINC_Q7_EVEN("%5", "%9") JINC_Q7_ODD("%5", "%6", "%10") JINC_Q7_EVEN("%6", "%11")
+            JINC_Q7_ODD("%6", "%7", "%12") ""
+            : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+            : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(c1), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+    } else {                           // taps 2 .. 5
+        asm(JINC_Q7_EVEN("%4", "%7") JINC_Q7_ODD("%4", "%5", "%8") JINC_Q7_EVEN("%5", "%9") JINC_Q7_ODD("%5", "%6", "%10") ""
+            : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)
+            : "v"(w1), "v"(w2), "v"(w3), "s"(c2), "s"(c3), "s"(c4), "s"(c5));
+    }
+}
+#undef JINC_Q7_EVEN
+#undef JINC_Q7_ODD
+
 // Window slot SLOT <- eight source columns of one tile row (four aligned ds_read_b64).
 template <int SLOT>
 __device__ __forceinline__ void quad2_load_row(f32x2 (&w)[24], const float* p) {
@@ -1072,8 +1107,9 @@ __device__ __forceinline__ void quad2_pixel6(f32x2 (&acc)[4], const f32x2 (&w)[2
         constexpr int S = 4 * ((U + LY) % 6);                                                                                  \
         /* INNER: a compile-time mask (a run-time test here, however uniform, cost 8 % of the kernel: round4/quad_inner_ab.log) */ \
         if constexpr (NT == 7) { /* 6 rows x 7 columns: seven taps per kernel row */                                            \
-            quad2_row7(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6]); \
-            quad2_row7(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14]); \
+            /* (NT == 7: INNER holds the span form of every (kernel row, q), two bits each) */                              \
+            quad2_row7_span<(INNER >> (2 * (2 * LY))) & 3u>(acc[0], acc[1], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[0], CUR[1], CUR[2], CUR[3], CUR[4], CUR[5], CUR[6]); \
+            quad2_row7_span<(INNER >> (2 * (2 * LY + 1))) & 3u>(acc[2], acc[3], w[S], w[S + 1], w[S + 2], w[S + 3], CUR[8], CUR[9], CUR[10], CUR[11], CUR[12], CUR[13], CUR[14]); \
         } else {                                                                                                               \
         if constexpr ((INNER >> (2 * LY)) & 1u)                                                                                \
             quad2_row6_inner(acc[0], acc[1], w[S], w[S + 1], w[S + 2], CUR[1], CUR[2], CUR[3], CUR[4]);                        \
@@ -1771,7 +1807,13 @@ template <typename T, int RG>
 int launch_periodic_quad2_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
-    if (pa.quad_taps == 7) {
+    if (pa.quad_taps == 7 && quad_span7_fits(pa.quad_span7, PeriodicArgs::kQuadSpan7Mpeg2)) {  // the chords of MPEG-2 sited chroma at 2x: 36 of 42 taps
+        hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, PeriodicArgs::kQuadSpan7Mpeg2, 7>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+        knobs::note_instance("ewa_periodic_quad2_kernel", "%s, %d, %uu, 7", knobs::type_name<T>(), RG, PeriodicArgs::kQuadSpan7Mpeg2);
+    } else if (pa.quad_taps == 7 && quad_span7_fits(pa.quad_span7, PeriodicArgs::kQuadSpan7Mpeg2Swapped)) {
+        hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, PeriodicArgs::kQuadSpan7Mpeg2Swapped, 7>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+        knobs::note_instance("ewa_periodic_quad2_kernel", "%s, %d, %uu, 7", knobs::type_name<T>(), RG, PeriodicArgs::kQuadSpan7Mpeg2Swapped);
+    } else if (pa.quad_taps == 7) {
         hipLaunchKernelGGL((ewa_periodic_quad2_kernel<T, RG, 0u, 7>), grid, dim3(256, 1, 1), 0, stream, pa, io);
         knobs::note_instance("ewa_periodic_quad2_kernel", "%s, %d, 0u, 7", knobs::type_name<T>(), RG);
     } else if ((pa.quad_inner & kQuad2InnerTap3) == kQuad2InnerTap3) {

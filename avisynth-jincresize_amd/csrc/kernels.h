@@ -72,6 +72,7 @@ inline long long gather_item_count(int w, int h, int axis, int P) {
 
 // Phase-periodic interior (see plan.h): output pixel (ix0 + px*i + p, iy0 + py*j + q) reads the
 // source window at (start_x[p] + i, start_y[q] + j) with coefficient set set[q*px + p].
+constexpr uint32_t span7_form(int ly, int q, uint32_t form) { return form << (2 * (2 * ly + q)); }  // (PeriodicArgs::kQuadSpan7Mpeg2)
 struct PeriodicArgs {
     const float* coeffs = nullptr;
     int px = 1, py = 1;
@@ -88,6 +89,17 @@ struct PeriodicArgs {
     // ewa_periodic_quad2_kernel: bit 2 * ly + q set = taps 0 and 5 of kernel row ly carry zero coefficients for both phases p of q
     uint32_t quad_inner = 0;
     int quad_taps = 0;  // ewa_periodic_quad2_kernel: taps per kernel row when they differ from the row count (7: the 6 x 7 support), else 0
+    // the 6 x 7 support: zero coefficients in front of / behind the span of kernel row ly at row phase q for BOTH phases p, two bits each
+    // (capped at 3) at 4 * (2 * ly + q) and 4 * (2 * ly + q) + 2
+    uint64_t quad_span7 = 0;
+    // ... and the span FORM of every (ly, q) the kernel is instantiated for (kernel_periodic.hip quad2_row7_span: 0 = all seven taps, 1 =
+    // taps 1 .. 6, 2 = taps 1 .. 5, 3 = taps 2 .. 5), two bits at 2 * (2 * ly + q): chroma planes sited as MPEG-2 at 2x with tap 3 --
+    // q = 0: forms 3 1 0 0 0 2 for ly = 0 .. 5, q = 1: 2 0 0 0 1 3.  36 of 42 taps.
+    static constexpr uint32_t kQuadSpan7Mpeg2 = span7_form(0, 0, 3) | span7_form(1, 0, 1) | span7_form(5, 0, 2) | span7_form(0, 1, 2) |
+                                                span7_form(4, 1, 1) | span7_form(5, 1, 3);
+    // (which output row is q = 0 follows from the parity of the interior's first row: the same pattern with the row phases exchanged)
+    static constexpr uint32_t kQuadSpan7Mpeg2Swapped = span7_form(0, 1, 3) | span7_form(1, 1, 1) | span7_form(5, 1, 2) | span7_form(0, 0, 2) |
+                                                       span7_form(4, 0, 1) | span7_form(5, 0, 3);
     static constexpr uint32_t kQuadInnerTap3 = (1u << (2 * 5 + 0)) | (1u << (2 * 0 + 1));  // the mask the kernel is instantiated for
     // quad forms on the 8 x 8 support: taps kernel row ly of q leaves out per side (0 .. 3), two bits at 2 * (2 * ly + q)
     uint32_t quad_trim8 = 0;
@@ -140,6 +152,21 @@ constexpr uint32_t quad8_bits(int ly, int q, int t) { return static_cast<uint32_
 constexpr uint32_t kQuad8TrimTap4Value = quad8_bits(0, 0, 1) | quad8_bits(6, 0, 1) | quad8_bits(7, 0, 2) | quad8_bits(0, 1, 2) |
                                          quad8_bits(1, 1, 1) | quad8_bits(7, 1, 1);
 inline constexpr uint32_t PeriodicArgs::kQuad8TrimTap4 = kQuad8TrimTap4Value;
+// Does the plan leave out at least what the span forms of `pattern` leave out?  (form -> taps left out in front / behind)
+inline bool quad_span7_fits(uint64_t plan, uint32_t pattern) {
+    constexpr int lead[4] = {0, 1, 1, 2}, trail[4] = {0, 0, 1, 1};
+    for (int k = 0; k < 12; ++k) {
+        const int form = static_cast<int>((pattern >> (2 * k)) & 3u);
+        if (static_cast<int>((plan >> (4 * k)) & 3u) < lead[form] || static_cast<int>((plan >> (4 * k + 2)) & 3u) < trail[form]) return false;
+    }
+    return true;
+}
+inline int quad_span7_taps(uint32_t pattern) {  // taps per sample the pattern executes, both q averaged x 2 (12 (ly, q) rows)
+    constexpr int n[4] = {7, 6, 5, 4};
+    int t = 0;
+    for (int k = 0; k < 12; ++k) t += n[(pattern >> (2 * k)) & 3u];
+    return t;
+}
 inline bool quad8_pattern_fits(uint32_t plan, uint32_t pattern) {  // the plan leaves out at least what the pattern leaves out
     for (int k = 0; k < 16; ++k)
         if (((plan >> (2 * k)) & 3u) < ((pattern >> (2 * k)) & 3u)) return false;

@@ -1055,14 +1055,24 @@ def test_chroma_sited_as_mpeg2_runs_on_six_rows_of_seven_taps(gpu_pkg, O):
     ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
     f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0)
     assert f.periodic_support(0) == 6 and f.periodic_support(1) == 6
-    assert f.periodic_taps(1, rows_kernel=3) == 42.0 and f.periodic_taps(0, rows_kernel=3) == 34.0
+    # (round 5: the chords of that support by a compile-time pattern -- per (kernel row, row phase) the taps that are zero for both
+    # column phases are not executed: 36 of the 42)
+    assert f.periodic_taps(1, rows_kernel=3) == 36.0 and f.periodic_taps(0, rows_kernel=3) == 34.0
     srcs = [O.lcg_frame(ofmt, sw, sh, seed=7700 + k) for k in range(frames)]
     auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
     assert f.last_kernel(1) == "ewa_periodic_quad2_kernel", f.last_kernel(1)
+    inst = f.last_instance(1)
+    assert inst.endswith(", 7>") and not inst.endswith(", 0u, 7>"), inst   # seven taps per kernel row, a chord pattern
     full = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 15)
+    with gpu_pkg.knobs(quad_inner=0):   # (read when the plan is built): all 42 taps of the 6 x 7 support
+        g = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0)
+        plain = _run_batch(torch, gpu_pkg, g, gfmt, srcs, frames, 0)
+        assert g.periodic_taps(1, rows_kernel=3) == 42.0 and g.last_instance(1).endswith(", 0u, 7>"), g.last_instance(1)
+        g.close()
     of = O.OracleFilter(ofmt, sw, sh, tw, th)
     for k in range(frames):
         assert_planes_equal(auto[k], full[k], f.out_dims(), what=f"frame {k}: 6 x 7 support vs full window")
+        assert_planes_equal(auto[k], plain[k], f.out_dims(), what=f"frame {k}: chord pattern vs all 42 taps")
         if k in (0, frames - 1):
             assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=8), f.out_dims(), what=f"frame {k} vs oracle")
     f.close()
