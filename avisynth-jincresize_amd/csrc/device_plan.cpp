@@ -187,32 +187,34 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
                 if (s[ly * fs + lx] != 0.f) r0 = std::min(r0, ly), r1 = std::max(r1, ly), c0 = std::min(c0, lx), c1 = std::max(c1, lx);
     }
     if (r1 < 0) return;  // nothing but zeros: leave it to the full window
-    // 6 rows x 7 columns (fs 7, four phases with one window origin): chroma planes sited as MPEG-2 at 2x -- the disc spans six
-    // source rows, and seven columns because the siting shifts it by an eighth of a sample.  Only the two-periods-per-lane quad
-    // form takes it (seven taps per kernel row: PeriodicArgs::quad_taps); every other kernel of the family keeps the full window.
-    if (fs == 7 && nphase == 4 && r1 - r0 + 1 == 6 && c1 - c0 + 1 == 7 && pa.px == 2 && pa.py == 2 && pa.start_x[0] == pa.start_x[1] &&
+    // (fs - 1) rows x fs columns (fs 7 / 9, four phases with one window origin): chroma planes sited as MPEG-2 at 2x with tap 3 / 4 -- the
+    // disc spans fs - 1 source rows, and fs columns because the siting shifts it by an eighth of a sample.  Only the two-periods-per-lane
+    // quad forms take it (fs taps per kernel row: PeriodicArgs::quad_taps; ewa_periodic_quad2_kernel / ewa_periodic_quad2x8_kernel);
+    // every other kernel of the family keeps the full window.
+    if ((fs == 7 || fs == 9) && nphase == 4 && r1 - r0 + 1 == fs - 1 && c1 - c0 + 1 == fs && pa.px == 2 && pa.py == 2 && pa.start_x[0] == pa.start_x[1] &&
         pa.start_y[0] == pa.start_y[1]) {
-        std::vector<float> dense(static_cast<size_t>(4) * 6 * 7, 0.f);
+        const int nr = fs - 1;
+        std::vector<float> dense(static_cast<size_t>(4) * nr * fs, 0.f);
         for (int ph = 0; ph < 4; ++ph)
-            for (int ly = 0; ly < 6; ++ly)
-                for (int lx = 0; lx < 7; ++lx) dense[(static_cast<size_t>(ph) * 6 + ly) * 7 + lx] = p.set_ptr(pa.set[ph])[(r0 + ly) * fs + lx];
+            for (int ly = 0; ly < nr; ++ly)
+                for (int lx = 0; lx < fs; ++lx) dense[(static_cast<size_t>(ph) * nr + ly) * fs + lx] = p.set_ptr(pa.set[ph])[(r0 + ly) * fs + lx];
         jinc::PeriodicArgs tr = pa;
-        tr.coeffs = nullptr;  // (no kernel but the quad form reads this variant)
+        tr.coeffs = nullptr;  // (no kernel but the quad forms reads this variant)
         tr.quad = nullptr;
         for (int q = 0; q < pa.py; ++q) tr.start_y[q] = pa.start_y[q] + r0;
         tr.min_sy = pa.min_sy + r0;
-        tr.quad_taps = 7;
+        tr.quad_taps = fs;
         {   // per (kernel row, q): the zero coefficients in front of / behind the row's span for BOTH phases p (kernels.h quad_span7)
             const bool off = !knobs::flag(JINC_KNOB_QUAD_INNER, true);  // A/B knob
             uint64_t spans = 0;
             for (int q = 0; q < 2 && !off; ++q)
-                for (int ly = 0; ly < 6; ++ly) {
+                for (int ly = 0; ly < nr; ++ly) {
                     int lead = 3, trail = 3;
                     for (int px = 0; px < 2; ++px) {
-                        const float* r = &dense[(static_cast<size_t>(q * 2 + px) * 6 + ly) * 7];
+                        const float* r = &dense[(static_cast<size_t>(q * 2 + px) * nr + ly) * fs];
                         int a = 0, b = 0;
-                        while (a < 7 && r[a] == 0.f) ++a;
-                        while (b < 7 - a && r[6 - b] == 0.f) ++b;
+                        while (a < fs && r[a] == 0.f) ++a;
+                        while (b < fs - a && r[fs - 1 - b] == 0.f) ++b;
                         lead = std::min(lead, a), trail = std::min(trail, b);
                     }
                     spans |= static_cast<uint64_t>(lead) << (4 * (2 * ly + q)) | static_cast<uint64_t>(trail) << (4 * (2 * ly + q) + 2);
@@ -221,12 +223,12 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
         }
         t.periodic_trim = tr;
         std::vector<const float*> sets;
-        for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * 42);
-        attach_rowpair(t, t.periodic_trim, 7, 6, sets, true);
-        attach_quad(t, t.periodic_trim, 6, sets, 7);
+        for (int ph = 0; ph < 4; ++ph) sets.push_back(dense.data() + static_cast<size_t>(ph) * nr * fs);
+        attach_rowpair(t, t.periodic_trim, fs, nr, sets, true);
+        attach_quad(t, t.periodic_trim, nr, sets, fs);
         if (t.periodic_trim.quad) {
-            t.trim_fs = 6;
-            t.trim_nx = 7;
+            t.trim_fs = nr;
+            t.trim_nx = fs;
         }
         return;
     }

@@ -311,6 +311,8 @@ struct Choice {
         if (t.trim_fs <= 0 || f.full_window || f.kernel_mode == 5 || f.kernel_mode == 6) return false;
         // the 6-row x 7-column support exists for the quad2 form only: where that form is not what runs, the full window
         if (t.trim_nx != t.trim_fs && !(f.kernel_mode == 13 || (f.kernel_mode == 0 && quad2_fills(t)))) return false;
+        // ... and the 8-row x 9-column one (chroma at tap 4) for ewa_periodic_quad2x8_kernel only
+        if (t.trim_nx != t.trim_fs && t.trim_fs == 8 && !(knobs::flag(JINC_KNOB_QUAD8, Rules::kQuad8) && quad2x8_chosen(t, f.vi_in.component_size))) return false;
         if (!t.trim_needs_finite) return true;
         // (Float planes: the trimmed launch is its own finite-sample scan -- launch_plane -- so what is left of the price is a cleared
         // flag set, a scan of the plane's rim and a second launch that returns at once: from kFloatTrimMinTaps taps per plane and call.

@@ -413,6 +413,10 @@ double jinc_filter_periodic_taps(const jinc_filter* f, int table, int rows_kerne
         }
         return pa.rowpair ? taps / pa.py : 0.0;
     }
+    if (rows_kernel == 3 && t.trim_fs == 8 && t.trim_nx == 9 && trimmed)  // 8 rows x 9 columns; with the MPEG-2 chords 60 of the 72
+        return (jinc::quad_span9_fits(t.periodic_trim.quad_span7, jinc::kQuadSpan9Mpeg2) || jinc::quad_span9_fits(t.periodic_trim.quad_span7, jinc::kQuadSpan9Mpeg2Swapped))
+                   ? jinc::quad_span9_taps(jinc::kQuadSpan9Mpeg2) / 2.0
+                   : 72.0;
     if (rows_kernel == 3 && t.trim_fs == 6 && t.trim_nx == 7 && trimmed)  // 6 rows x 7 columns; with the MPEG-2 chords 36 of the 42
         return (jinc::quad_span7_fits(t.periodic_trim.quad_span7, jinc::PeriodicArgs::kQuadSpan7Mpeg2) ||
                 jinc::quad_span7_fits(t.periodic_trim.quad_span7, jinc::PeriodicArgs::kQuadSpan7Mpeg2Swapped))

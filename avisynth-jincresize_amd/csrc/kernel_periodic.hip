@@ -1441,7 +1441,85 @@ __device__ __forceinline__ void quad2_pixel8(f32x2 (&acc)[4], const f32x2 (&w)[4
 #undef JINC_QUAD2X8_STEP
 }
 
-template <typename T, int RG, uint32_t TR8>
+// Nine taps per kernel row for both periods of a lane (the 8-row x 9-column support: chroma planes sited as MPEG-2 at 2x with tap 4):
+// period A reads columns 0 .. 8, period B columns 1 .. 9 of the row's five register pairs; FORM = the span of the row's taps that
+// is executed (0: all nine, 1: taps 1 .. 8, 2: 1 .. 7, 3: 2 .. 7, 4: 2 .. 6 -- the others carry zero coefficients for both phases p).
+#define JINC_Q9_EVEN(W, C) /* tap t even: period A = the low half of pair t / 2, B its high half */                         \
+    "v_pk_mul_f32 %2, " W ", " C " op_sel_hi:[0,1]\n\tv_pk_mul_f32 %3, " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\t" \
+    "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+#define JINC_Q9_ODD(W, WN, C) /* tap t odd: A = the high half of pair t / 2, B the low half of the next pair */             \
+    "v_pk_mul_f32 %2, " W ", " C " op_sel:[1,0] op_sel_hi:[1,1]\n\tv_pk_mul_f32 %3, " WN ", " C " op_sel_hi:[0,1]\n\t" \
+    "v_pk_add_f32 %0, %0, %2\n\tv_pk_add_f32 %1, %1, %3\n\t"
+#define JINC_Q9_T0 JINC_Q9_EVEN("%4", "%9")
+#define JINC_Q9_T1 JINC_Q9_ODD("%4", "%5", "%10")
+#define JINC_Q9_T2 JINC_Q9_EVEN("%5", "%11")
+#define JINC_Q9_T3 JINC_Q9_ODD("%5", "%6", "%12")
+#define JINC_Q9_T4 JINC_Q9_EVEN("%6", "%13")
+#define JINC_Q9_T5 JINC_Q9_ODD("%6", "%7", "%14")
+#define JINC_Q9_T6 JINC_Q9_EVEN("%7", "%15")
+#define JINC_Q9_T7 JINC_Q9_ODD("%7", "%8", "%16")
+#define JINC_Q9_T8 JINC_Q9_EVEN("%8", "%17")
+#define JINC_Q9_OPERANDS                                                                                                          \
+    : "+v"(acc_a), "+v"(acc_b), "=&v"(ta), "=&v"(tb)                                                                               \
+    : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), \
+      "s"(c[7]), "s"(c[8])
+template <int FORM>
+__device__ __forceinline__ void quad2_row9_span(f32x2& acc_a, f32x2& acc_b, const f32x2 (&w)[5], const f32x2 (&c)[10]) {
+    static_assert(FORM >= 0 && FORM <= 4, "span forms of the nine-tap row");
+    f32x2 ta, tb;
+    if constexpr (FORM == 0)
+        asm(JINC_Q9_T0 JINC_Q9_T1 JINC_Q9_T2 JINC_Q9_T3 JINC_Q9_T4 JINC_Q9_T5 JINC_Q9_T6 JINC_Q9_T7 JINC_Q9_T8 "" JINC_Q9_OPERANDS);
+    else if constexpr (FORM == 1)
+        asm(JINC_Q9_T1 JINC_Q9_T2 JINC_Q9_T3 JINC_Q9_T4 JINC_Q9_T5 JINC_Q9_T6 JINC_Q9_T7 JINC_Q9_T8 "" JINC_Q9_OPERANDS);
+    else if constexpr (FORM == 2)
+        asm(JINC_Q9_T1 JINC_Q9_T2 JINC_Q9_T3 JINC_Q9_T4 JINC_Q9_T5 JINC_Q9_T6 JINC_Q9_T7 "" JINC_Q9_OPERANDS);
+    else if constexpr (FORM == 3)
+        asm(JINC_Q9_T2 JINC_Q9_T3 JINC_Q9_T4 JINC_Q9_T5 JINC_Q9_T6 JINC_Q9_T7 "" JINC_Q9_OPERANDS);
+    else
+        asm(JINC_Q9_T2 JINC_Q9_T3 JINC_Q9_T4 JINC_Q9_T5 JINC_Q9_T6 "" JINC_Q9_OPERANDS);
+}
+#undef JINC_Q9_EVEN
+#undef JINC_Q9_ODD
+#undef JINC_Q9_T0
+#undef JINC_Q9_T1
+#undef JINC_Q9_T2
+#undef JINC_Q9_T3
+#undef JINC_Q9_T4
+#undef JINC_Q9_T5
+#undef JINC_Q9_T6
+#undef JINC_Q9_T7
+#undef JINC_Q9_T8
+#undef JINC_Q9_OPERANDS
+
+// One output row pair of both periods on the 8 x 9 support.  The ten coefficient pairs of a (kernel row, q) are 20 SGPRs: the two
+// row phases alternate through two sets (as quad_pixel9): the pairs of (ly, q = 1) are requested before the taps of (ly, q = 0) are
+// issued, those of (ly + 1, q = 0) before the taps of (ly, q = 1).  Layout: quad[ly][q][10 pairs][p] (device_plan.cpp attach_quad, NX = 9).
+template <int U, uint64_t SPAN9>
+__device__ __forceinline__ void quad2_pixel9(f32x2 (&acc)[4], const f32x2 (&w)[40], const JINC_CONSTANT f32x2* quad) {
+    f32x2 ca[10], cb[10];
+    quad_fetch10(ca, quad, 0);
+#define JINC_QUAD2X9_STEP(LY)                                                                                      \
+    quad_fetch10(cb, quad, 2 * LY + 1);                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    quad_arrived10(ca);                                                                                            \
+    {                                                                                                              \
+        constexpr int S = 5 * ((U + LY) % 8);                                                                      \
+        const f32x2 row[5] = {w[S], w[S + 1], w[S + 2], w[S + 3], w[S + 4]};                                       \
+        quad2_row9_span<static_cast<int>((SPAN9 >> (3 * (2 * LY))) & 7u)>(acc[0], acc[1], row, ca);                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        if constexpr (LY < 7) quad_fetch10(ca, quad, 2 * LY + 2);                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        quad_arrived10(cb);                                                                                        \
+        quad2_row9_span<static_cast<int>((SPAN9 >> (3 * (2 * LY + 1))) & 7u)>(acc[2], acc[3], row, cb);             \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);
+    JINC_QUAD2X9_STEP(0) JINC_QUAD2X9_STEP(1) JINC_QUAD2X9_STEP(2) JINC_QUAD2X9_STEP(3) JINC_QUAD2X9_STEP(4) JINC_QUAD2X9_STEP(5)
+    JINC_QUAD2X9_STEP(6) JINC_QUAD2X9_STEP(7)
+#undef JINC_QUAD2X9_STEP
+}
+
+// NT: taps per kernel row -- 8, or 9 for the 8-row x 9-column support (then SPAN9 = the span form of every (kernel row, q), TR8 unused).
+template <typename T, int RG, uint32_t TR8, int NT = 8, uint64_t SPAN9 = 0>
 __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const PeriodicArgs a, const PlaneIO io) {
     using Cfg = Quad2x8Cfg<RG>;
     constexpr int FS = Cfg::FS;
@@ -1535,7 +1613,8 @@ __global__ __launch_bounds__(256, 5) void ewa_periodic_quad2x8_kernel(const Peri
         f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};                                            \
         uint32_t zero;                                                                                              \
         asm volatile("s_mov_b32 %0, 0" : "=s"(zero)); /* opaque: keeps the coefficient loads inside the row loop */ \
-        quad2_pixel8<U, TR8>(acc, win, quad + zero);                                                                \
+        if constexpr (NT == 9) quad2_pixel9<U, SPAN9>(acc, win, quad + zero);                                       \
+        else quad2_pixel8<U, TR8>(acc, win, quad + zero);                                                           \
         const int j = j0 + g * FS + U;                                                                              \
         if (j < a.nj) {                                                                                             \
             const uint32_t so = static_cast<uint32_t>(a.iy0 + 2 * j) * io.dst_pitch;                                \
@@ -1794,12 +1873,23 @@ template <typename T, int RG>
 int launch_periodic_quad2x8_t(const PeriodicArgs& pa, const PlaneIO& io, hipStream_t stream) {
     using Cfg = Quad2x8Cfg<RG>;
     dim3 grid((pa.ni + Cfg::kTileCols - 1) / Cfg::kTileCols, (pa.nj + Cfg::kTileRows - 1) / Cfg::kTileRows, io.nframes);
+    if (pa.quad_taps == 9) {  // the 8-row x 9-column support (chroma at tap 4), by the chord pattern the plan's spans fit
+        const uint64_t span = quad_span9_fits(pa.quad_span7, kQuadSpan9Mpeg2) ? kQuadSpan9Mpeg2 : quad_span9_fits(pa.quad_span7, kQuadSpan9Mpeg2Swapped) ? kQuadSpan9Mpeg2Swapped : 0;
+        if (span == kQuadSpan9Mpeg2)
+            hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, 0u, 9, kQuadSpan9Mpeg2>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+        else if (span == kQuadSpan9Mpeg2Swapped)
+            hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, 0u, 9, kQuadSpan9Mpeg2Swapped>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+        else
+            hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, 0u, 9, 0>), grid, dim3(256, 1, 1), 0, stream, pa, io);
+        knobs::note_instance("ewa_periodic_quad2x8_kernel", "%s, %d, 0u, 9, %lluul", knobs::type_name<T>(), RG, static_cast<unsigned long long>(span));
+        return static_cast<int>(hipGetLastError());
+    }
     const bool pattern = quad8_pattern_fits(pa.quad_trim8, kQuad8TrimTap4);
     if (pattern)
         hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, kQuad8TrimTap4>), grid, dim3(256, 1, 1), 0, stream, pa, io);
     else
         hipLaunchKernelGGL((ewa_periodic_quad2x8_kernel<T, RG, 0u>), grid, dim3(256, 1, 1), 0, stream, pa, io);
-    knobs::note_instance("ewa_periodic_quad2x8_kernel", "%s, %d, %uu", knobs::type_name<T>(), RG, pattern ? kQuad8TrimTap4 : 0u);
+    knobs::note_instance("ewa_periodic_quad2x8_kernel", "%s, %d, %uu, 8, 0ul", knobs::type_name<T>(), RG, pattern ? kQuad8TrimTap4 : 0u);  // (as rocprofv3 spells it)
     return static_cast<int>(hipGetLastError());
 }
 

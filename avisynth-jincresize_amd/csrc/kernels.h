@@ -97,6 +97,7 @@ struct PeriodicArgs {
     // q = 0: forms 3 1 0 0 0 2 for ly = 0 .. 5, q = 1: 2 0 0 0 1 3.  36 of 42 taps.
     static constexpr uint32_t kQuadSpan7Mpeg2 = span7_form(0, 0, 3) | span7_form(1, 0, 1) | span7_form(5, 0, 2) | span7_form(0, 1, 2) |
                                                 span7_form(4, 1, 1) | span7_form(5, 1, 3);
+    // (the spans of the 8-row x 9-column support -- chroma at tap 4 -- use the same field: 16 (ly, q) entries of four bits)
     // (which output row is q = 0 follows from the parity of the interior's first row: the same pattern with the row phases exchanged)
     static constexpr uint32_t kQuadSpan7Mpeg2Swapped = span7_form(0, 1, 3) | span7_form(1, 1, 1) | span7_form(5, 1, 2) | span7_form(0, 0, 2) |
                                                        span7_form(4, 0, 1) | span7_form(5, 0, 3);
@@ -153,6 +154,29 @@ constexpr uint32_t kQuad8TrimTap4Value = quad8_bits(0, 0, 1) | quad8_bits(6, 0, 
                                          quad8_bits(1, 1, 1) | quad8_bits(7, 1, 1);
 inline constexpr uint32_t PeriodicArgs::kQuad8TrimTap4 = kQuad8TrimTap4Value;
 // Does the plan leave out at least what the span forms of `pattern` leave out?  (form -> taps left out in front / behind)
+// The 8-row x 9-column support (chroma planes sited as MPEG-2 at 2x with tap 4; ewa_periodic_quad2x8_kernel with nine taps per kernel
+// row): span FORM of every (ly, q), three bits at 3 * (2 * ly + q) -- 0 = all nine taps, 1 = taps 1 .. 8, 2 = 1 .. 7, 3 = 2 .. 7, 4 =
+// 2 .. 6 (kernel_periodic.hip quad2_row9_span).  Blur 1: q = 0 forms 4 2 1 0 0 0 2 3 for ly = 0 .. 7, q = 1: 3 2 0 0 0 1 2 4 -- 60 of 72.
+constexpr uint64_t span9_form(int ly, int q, uint64_t form) { return form << (3 * (2 * ly + q)); }
+constexpr uint64_t kQuadSpan9Mpeg2 = span9_form(0, 0, 4) | span9_form(1, 0, 2) | span9_form(2, 0, 1) | span9_form(6, 0, 2) | span9_form(7, 0, 3) |
+                                     span9_form(0, 1, 3) | span9_form(1, 1, 2) | span9_form(5, 1, 1) | span9_form(6, 1, 2) | span9_form(7, 1, 4);
+constexpr uint64_t kQuadSpan9Mpeg2Swapped = span9_form(0, 1, 4) | span9_form(1, 1, 2) | span9_form(2, 1, 1) | span9_form(6, 1, 2) | span9_form(7, 1, 3) |
+                                            span9_form(0, 0, 3) | span9_form(1, 0, 2) | span9_form(5, 0, 1) | span9_form(6, 0, 2) | span9_form(7, 0, 4);
+inline bool quad_span9_fits(uint64_t plan, uint64_t pattern) {  // plan: lead / trail per (ly, q) as in PeriodicArgs::quad_span7
+    constexpr int lead[5] = {0, 1, 1, 2, 2}, trail[5] = {0, 0, 1, 1, 2};
+    for (int k = 0; k < 16; ++k) {
+        const int form = static_cast<int>((pattern >> (3 * k)) & 7u);
+        if (form > 4) return false;
+        if (static_cast<int>((plan >> (4 * k)) & 3u) < lead[form] || static_cast<int>((plan >> (4 * k + 2)) & 3u) < trail[form]) return false;
+    }
+    return true;
+}
+inline int quad_span9_taps(uint64_t pattern) {  // taps the pattern executes over the 16 (ly, q) rows: twice the taps per sample
+    constexpr int n[5] = {9, 8, 7, 6, 5};
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += n[(pattern >> (3 * k)) & 7u];
+    return t;
+}
 inline bool quad_span7_fits(uint64_t plan, uint32_t pattern) {
     constexpr int lead[4] = {0, 1, 1, 2}, trail[4] = {0, 0, 1, 1};
     for (int k = 0; k < 12; ++k) {

@@ -23,7 +23,7 @@ BENCHMARKED = {
     "C2": "ewa_periodic_quad2_kernel<unsigned char, 8, 1026u, 6>",
     "C2H": "ewa_periodic_quad2_kernel<unsigned short, 8, 1026u, 6>",
     "C4": "ewa_periodic_quad8_kernel<float, 8, %uu>",      # (the tap-4 chord pattern's value is filled in from a small call)
-    "C2T4": "ewa_periodic_quad2x8_kernel<unsigned char, 4, %uu>",
+    "C2T4": "ewa_periodic_quad2x8_kernel<unsigned char, 4, %uu, 8, 0ul>",
 }
 
 

@@ -1045,6 +1045,39 @@ def test_jinc64_at_2x_in_batches_takes_two_periods_per_lane(gpu_pkg, O, fmt):
     f.close()
 
 
+def test_chroma_sited_as_mpeg2_at_tap_4_runs_on_eight_rows_of_nine_taps(gpu_pkg, O):
+    """1080p -> 4K 4:2:0 with tap 4 (Jinc64Resize) and the default siting, 32 frames per call: the chroma table's disc spans eight source
+    rows and nine columns; ewa_periodic_quad2x8_kernel takes that support with nine taps per kernel row and the chords by a compile-time
+    pattern -- 60 of the window's 81 taps (round 5; the full window on ewa_periodic_kernel before).  Every frame against the full window
+    (kernel mode 15) and against all 72 taps of the support (knob quad_inner = 0), two against the oracle; 8- and 16-bit."""
+    torch = pytest.importorskip("torch")
+    from test_framelane_pair import _run_batch
+    for fmt in ("YUV420P8", "YUV420P16"):
+        sw, sh, tw, th, frames = 1920, 1080, 3840, 2160, 32   # (32 frames: the chroma planes' launches fill the chip with 128 x 32 tiles)
+        ofmt, gfmt = O.FORMATS[fmt], gpu_pkg.FORMATS[fmt]
+        f = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, tap=4)
+        assert f.periodic_support(0) == 8 and f.periodic_support(1) == 8
+        assert f.periodic_taps(1, rows_kernel=3) == 60.0 and f.periodic_taps(0, rows_kernel=3) == 56.0
+        srcs = [O.lcg_frame(ofmt, sw, sh, seed=7900 + k) for k in range(frames)]
+        auto = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 0)
+        inst = f.last_instance(1)
+        assert inst.startswith("ewa_periodic_quad2x8_kernel<") and ", 9, " in inst and not inst.endswith(", 9, 0ul>"), inst
+        assert f.last_border(1) & 64, f.last_border(1)     # ... and the plane's border columns in that kernel's edge tiles
+        full = _run_batch(torch, gpu_pkg, f, gfmt, srcs, frames, 15)
+        with gpu_pkg.knobs(quad_inner=0):   # (read when the plan is built): all 72 taps of the 8 x 9 support
+            g = gpu_pkg.Filter(gfmt, sw, sh, tw, th, device=0, tap=4)
+            plain = _run_batch(torch, gpu_pkg, g, gfmt, srcs, frames, 0)
+            assert g.periodic_taps(1, rows_kernel=3) == 72.0 and g.last_instance(1).endswith(", 9, 0ul>"), g.last_instance(1)
+            g.close()
+        of = O.OracleFilter(ofmt, sw, sh, tw, th, tap=4)
+        for k in range(frames):
+            assert_planes_equal(auto[k], full[k], f.out_dims(), what=f"{fmt} frame {k}: 8 x 9 support vs full window")
+            assert_planes_equal(auto[k], plain[k], f.out_dims(), what=f"{fmt} frame {k}: chord pattern vs all 72 taps")
+            if k in (0, frames - 1):
+                assert_planes_equal(auto[k], of.get_frame(srcs[k], threads=16), f.out_dims(), what=f"{fmt} frame {k} vs oracle")
+        f.close()
+
+
 def test_chroma_sited_as_mpeg2_runs_on_six_rows_of_seven_taps(gpu_pkg, O):
     """1080p -> 4K 4:2:0 with the default siting, 16 frames per call: the chroma table's disc spans six source rows and (shifted by an
     eighth of a sample) seven columns; ewa_periodic_quad2_kernel takes that support with seven taps per kernel row.  Every frame
