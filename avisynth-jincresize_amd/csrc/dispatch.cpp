@@ -83,7 +83,10 @@ struct Rules {
     // Gpix/s, eight frames 144 -> 164, 64 frames 174 -> 207 (round4/float_trim_ab.log)
     static constexpr double kFloatTrimMinTaps = 1.0e9;
     // ... and its two-periods-per-lane form on integer planes from this many workgroups per launch on
-    static constexpr long long kQuad2x8MinWorkgroups = 4096;
+    // (round 4: 4096.  Round 5: this form computes the plane's border columns in its edge tiles and is the only one with the chroma planes'
+    // 8 x 9 support, and it is ahead from two frames per call on: Jinc64 1080p -> 4K Y8 at 2 / 4 / 8 frames 236 -> 239 / 320 -> 332 / 353 ->
+    // 455 Gpix/s, level at one; 16-bit 4:2:0 at 8 / 16 frames 194 -> 255 / 270 -> 300; round5/chroma_span9_ab.log)
+    static constexpr long long kQuad2x8MinWorkgroups = 1024;
     // quad form on the trimmed 8 x 8 support (tap 4 at 2x) instead of the window kernel
     static constexpr bool kQuad8 = true;
     // two-periods-per-lane quad form on the trimmed 6 x 6 support from this many half-height workgroups per launch on
