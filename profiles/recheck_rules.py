@@ -28,7 +28,8 @@ CHECKS = [
     #  source step 1: since round 5 the interior kernel's edge tiles or ewa_colpair_kernel take those columns; rules further down)
     ("kRunsFrameLaneBorderMinFramesSub = 8", "N15T4", 8, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
     ("kRunsFrameLaneBorderMinFrames = 32 (tap 8)", "N15T8", 32, {}, {"env": {"JINC_RUNS_FL_BORDER_FRAMES": "0"}}, "gather kernel on the border"),
-    ("kQuad2x8MinWorkgroups: two periods per lane on 8 x 8", "C2T4", 9, {}, {"env": {"JINC_QUAD2X8": "0"}}, "one period per lane"),
+    ("kQuad2x8MinWorkgroups = 1024: two periods per lane on 8 x 8 from 2 frames", "C2T4", 4, {}, {"env": {"JINC_QUAD2X8": "0"}}, "one period per lane"),
+    ("kQuad2x8MinWorkgroups = 1024: one period per lane for one frame", "C2T4", 1, {}, {"env": {"JINC_QUAD2X8": "1"}}, "two periods per lane"),
     ("trimmed support, integer planes", "C2", 64, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
     ("trimmed support on float planes (8 x 8)", "C4", 16, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
     ("float planes on the 6 x 6 support (the trimmed launch its own scan)", "C2F", 64, {}, {"args": ["--kernel-mode", "15"]}, "full window"),
