@@ -85,7 +85,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error",
-           "jinc_filter_last_instance", "jinc_filter_last_border", "jinc_debug_last_instance", "jinc_debug_set_knob", "jinc_debug_clear_knob", "jinc_debug_get_knob", "jinc_debug_knob_name"]
+           "jinc_filter_last_instance", "jinc_filter_last_border", "jinc_debug_last_instance", "jinc_debug_set_knob", "jinc_debug_clear_knob", "jinc_debug_get_knob", "jinc_debug_knob_name", "jinc_debug_chord_pattern"]
 
 _lib = None
 _P4 = C.c_void_p * 4
@@ -169,6 +169,8 @@ def lib():
         L.jinc_debug_set_knob.argtypes = [C.c_int, C.c_double]
         L.jinc_debug_clear_knob.argtypes = [C.c_int]
         L.jinc_debug_get_knob.argtypes = [C.c_int, C.POINTER(C.c_double)]
+        L.jinc_debug_chord_pattern.argtypes = [C.c_int, C.c_uint64]
+        L.jinc_debug_chord_pattern.restype = C.c_int
         L.jinc_debug_knob_name.argtypes = [C.c_int]
         L.jinc_debug_knob_name.restype = C.c_char_p
         _lib = L

@@ -484,6 +484,12 @@ int jinc_debug_get_knob(int knob, double* value) {
 }
 
 const char* jinc_debug_knob_name(int knob) { return jinc::knobs::name(knob); }
+int jinc_debug_chord_pattern(int taps_per_row, uint64_t spans) {
+    if (taps_per_row == 7)
+        return jinc::quad_span7_fits(spans, jinc::PeriodicArgs::kQuadSpan7Mpeg2) ? 1 : jinc::quad_span7_fits(spans, jinc::PeriodicArgs::kQuadSpan7Mpeg2Swapped) ? 2 : 0;
+    if (taps_per_row == 9) return jinc::quad_span9_fits(spans, jinc::kQuadSpan9Mpeg2) ? 1 : jinc::quad_span9_fits(spans, jinc::kQuadSpan9Mpeg2Swapped) ? 2 : 0;
+    return -1;
+}
 
 // Shader-clock sampler beside the kernels being timed (kernel_probe.hip).
 struct jinc_clock_sampler {

@@ -140,6 +140,11 @@ typedef enum jinc_knob {
 JINC_API int jinc_debug_set_knob(int knob, double value);
 JINC_API int jinc_debug_clear_knob(int knob);               /* knob < 0: every knob back to unset */
 JINC_API int jinc_debug_get_knob(int knob, double *value);  /* 1: set (*value receives it), 0: unset, < 0: no such knob */
+/* Chord patterns of the (fs - 1)-row x fs-column supports (chroma planes sited as MPEG-2 at 2x; csrc/kernels.h quad_span7 / kQuadSpan9*):
+ * `spans` = per (kernel row ly, row phase q) the zero coefficients in front of / behind the row's span for both column phases, two bits each
+ * (capped at 3) at 4 * (2 * ly + q) and 4 * (2 * ly + q) + 2.  Returns 1 / 2 if the kernels' compile-time pattern / its row-phase-swapped twin
+ * leaves out no more than that, 0 if neither (all taps of the support then), -1 for a tap count without patterns.  Host only: no device call. */
+JINC_API int jinc_debug_chord_pattern(int taps_per_row, uint64_t spans);
 JINC_API const char *jinc_debug_knob_name(int knob);        /* lower-case name ("quad_rg"); NULL beyond the last knob */
 /* Taps per axis the periodic interior kernels of `table` execute under the current kernel mode: the plan's filter size, or
  * the side of the trimmed support on integer planes (kernel mode 15 switches trimming off); 0 when the table has no
