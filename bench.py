@@ -481,7 +481,20 @@ def cpu_baseline(cfg_name, scan_s=2.0, sample_s=6.0):
             "single_core_value": round(v1, 2), "single_core_sample": f"{n1} frames in {el1:.1f}s",
             "runs_at_chosen_count_Mpix_s": [round(x, 1) for x in vals],
             "opt0_port_value": round(o_best, 2), "opt0_port_single_core_value": round(o1, 2),
-            "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in scan.items()}}
+            "thread_scan_Mpix_s": {str(k): round(x, 1) for k, x in scan.items()},
+            "port_vs_reference_build_container": port_vs_reference_record()}
+
+
+def port_vs_reference_record():
+    """How the timed port compares with the reference's own AVX2 / AVX-512 code where both have run: the build container, one
+    thread, C2 (profiles/cpu_port_vs_reference.py wrote the record; the reference's figures in it are SURVEY.md section 6's
+    and the round-5 judge's -- this repository cannot build the reference).  A static record, not measured by this run."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "cpu_port_build_container.json")))
+    except (OSError, ValueError):
+        return None
+    rec.pop("per_round_Mpix_s", None)
+    return rec
 
 
 def cpu_frame_parallel(cfg_name, counts, seconds=2.0):

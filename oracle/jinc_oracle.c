@@ -348,6 +348,21 @@ int oracle_table_generate(const double *lut, const oracle_table_params *p, oracl
     }
 
     free(factor_map);
+    /* ref :6-21, :466-470: the reference keeps `factor` 64-byte aligned (its SIMD paths load coefficient rows with aligned
+     * loads); the growth above goes through realloc, so the finished array is moved once into aligned storage. */
+    {
+        void *aligned = NULL;
+        if (posix_memalign(&aligned, 64, (size_t)(top > 0 ? top : 1) * sizeof(float)) != 0) {
+            free(factor);
+            free(out->meta);
+            memset(out, 0, sizeof(*out));
+            return -1;
+        }
+        if (top > 0)
+            memcpy(aligned, factor, (size_t)top * sizeof(float));
+        free(factor);
+        factor = (float *)aligned;
+    }
     out->factor = factor;
     out->factor_count = top;
     return 0;
