@@ -82,7 +82,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_runs", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
            "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
-           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
+           "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_filter_release_host_range", "jinc_batch_set_affinity", "jinc_batch_device_cpus", "jinc_debug_numa_cpus", "jinc_debug_batch_set_registrars", "jinc_debug_batch_refused", "jinc_debug_host_registrations", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error",
            "jinc_filter_last_instance", "jinc_filter_last_border", "jinc_debug_last_instance", "jinc_debug_set_knob", "jinc_debug_clear_knob", "jinc_debug_get_knob", "jinc_debug_knob_name", "jinc_debug_chord_pattern"]
@@ -119,6 +119,13 @@ def lib():
         L.jinc_filter_flush.argtypes = [C.c_void_p]
         L.jinc_filter_direct_premise.argtypes = [C.c_void_p]
         L.jinc_filter_adopt_host_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jinc_filter_release_host_range.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.jinc_batch_set_affinity.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_batch_device_cpus.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.jinc_debug_batch_set_registrars.argtypes = [C.c_void_p, C.c_int]
+        L.jinc_debug_host_registrations.restype = C.c_longlong
+        L.jinc_debug_batch_refused.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.jinc_debug_numa_cpus.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.c_int]
         L.jinc_debug_clock_sampler_start.argtypes = [C.c_int, C.c_double, C.POINTER(C.c_void_p)]
         L.jinc_debug_clock_sampler_stop.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.jinc_debug_valu_pair_probe.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -215,6 +222,11 @@ def transport_counts(reset: bool = False) -> Tuple[int, int, int]:
     a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
     lib().jinc_debug_transport_counts(C.byref(a), C.byref(b), C.byref(c), int(reset))
     return a.value, b.value, c.value
+
+
+def host_registrations() -> int:
+    """Host ranges the library holds registered with hipHostRegister right now (registry and batch registrars; test header)."""
+    return int(lib().jinc_debug_host_registrations())
 
 
 def valu_pair_probe(device: int = 0, waves_per_simd: int = 8) -> Tuple[float, float]:
@@ -449,6 +461,16 @@ def _build_args(fmt, width, height, target_width, target_height, frame0_chroma_l
     return vi, a, keep
 
 
+PIN_NONE, PIN_IN_FLIGHT, PIN_POOL = 0, 1, 2   # register_host_buffers of set_pipeline / Batch (include/jincresize_hip.h)
+
+
+def numa_cpus(sysfs_root: str, bdf: str) -> List[int]:
+    """batch.cpp's NUMA lookup against a sysfs tree of the caller's (test header)."""
+    buf = (C.c_int * 4096)()
+    n = int(lib().jinc_debug_numa_cpus(sysfs_root.encode(), bdf.encode(), buf, 4096))
+    return [int(buf[i]) for i in range(max(0, min(n, 4096)))]
+
+
 class Batch:
     """Frames of one clip sharded over the node's HIP devices (jinc_batch_*: frame n -> device n mod G, a plan replica
     and `streams` frames in flight per device, no exchange between devices)."""
@@ -468,6 +490,25 @@ class Batch:
     @property
     def devices(self) -> int:
         return int(lib().jinc_batch_devices(self._h))
+
+    def set_affinity(self, on: bool) -> None:
+        """Workers / registrars of device d on the CPUs of d's NUMA node (default) or wherever the scheduler puts them."""
+        lib().jinc_batch_set_affinity(self._h, int(bool(on)))
+
+    def set_registrars(self, n: int) -> None:
+        """Test header: n registrar threads per process() call instead of one per device."""
+        if lib().jinc_debug_batch_set_registrars(self._h, int(n)) != 0:
+            raise JincError(-1, lib().jinc_batch_last_error().decode())
+
+    def refused(self) -> Tuple[int, str]:
+        """Test header: (host ranges hipHostRegister refused so far, what the first one was told)."""
+        buf = C.create_string_buffer(256)
+        return int(lib().jinc_debug_batch_refused(self._h, buf, len(buf))), buf.value.decode()
+
+    def device_cpus(self, device_index: int) -> List[int]:
+        buf = (C.c_int * 4096)()
+        n = int(lib().jinc_batch_device_cpus(self._h, int(device_index), buf, 4096))
+        return [int(buf[i]) for i in range(max(0, min(n, 4096)))]
 
     def device_of_frame(self, n: int) -> int:
         return int(lib().jinc_batch_device_of_frame(self._h, int(n)))
@@ -574,8 +615,10 @@ class Filter:
         return outs
 
     # -- look-ahead pipeline: several frames in flight per instance --
-    def set_pipeline(self, depth: int, register_host_buffers: bool = False, group: int = 0) -> None:
-        """Up to `depth` frames in flight; `group` of them coalesced into one launch (0: automatic = depth / 2)."""
+    def set_pipeline(self, depth: int, register_host_buffers: int = 0, group: int = 0) -> None:
+        """Up to `depth` frames in flight; `group` of them coalesced into one launch (0: automatic = depth / 2).
+        register_host_buffers: PIN_NONE (0), PIN_IN_FLIGHT (1 / True: pinned while their frame is in flight), PIN_POOL (2:
+        pinned and cached by address; the caller keeps the buffers allocated)."""
         self._check(lib().jinc_filter_set_pipeline_group(self._h, int(depth), int(group), int(register_host_buffers)))
 
     @property
@@ -583,8 +626,13 @@ class Filter:
         return int(lib().jinc_filter_pipeline_group(self._h))
 
     def adopt_host_range(self, base: int, nbytes: int) -> None:
-        """[base, base + nbytes) is pinned by the caller (hipHostMalloc / hipHostRegister) and stays so until close()."""
+        """[base, base + nbytes) is pinned by the caller (hipHostMalloc / hipHostRegister) and stays so until close() or
+        release_host_range()."""
         self._check(lib().jinc_filter_adopt_host_range(self._h, C.c_void_p(base), C.c_size_t(nbytes)))
+
+    def release_host_range(self, base: int, nbytes: int) -> None:
+        """The caller is about to unpin / free the range: frames in flight are waited for, adopted ranges touching it are forgotten."""
+        self._check(lib().jinc_filter_release_host_range(self._h, C.c_void_p(base), C.c_size_t(nbytes)))
 
     @property
     def direct_premise(self) -> int:

@@ -129,7 +129,7 @@ int jinc_filter_set_pipeline_group(jinc_filter* f, int depth, int group, int reg
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        configure_pipeline(*f, depth, group, register_host_buffers != 0);
+        configure_pipeline(*f, depth, group, register_host_buffers < 0 ? 0 : register_host_buffers > 2 ? 2 : register_host_buffers);
     });
 }
 
@@ -155,6 +155,15 @@ int jinc_filter_adopt_host_range(jinc_filter* f, void* base, size_t bytes) {
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
         adopt_host_range(*f, base, bytes);
+    });
+}
+
+int jinc_filter_release_host_range(jinc_filter* f, void* base, size_t bytes) {
+    if (!f || !base || !bytes) return fail(JINC_ERR_INVALID_ARG, "JincResize: null argument.");
+    if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
+    return guarded([&] {
+        hip_check(hipSetDevice(f->device), "hipSetDevice");
+        release_host_range(*f, base, bytes);
     });
 }
 

@@ -116,6 +116,11 @@ struct GroupFrame {
     int dst_pitch[4] = {0, 0, 0, 0};
     long long ticket = -1;
     int done_event = -1;  // index into FrameGroup::done, set at launch
+    // Registrations this frame holds for as long as it is in flight (pin mode 1: jinc_filter_set_pipeline's
+    // register_host_buffers = 1): ids of the process-wide registry, one per plane buffer at most, given back when the frame's
+    // wait returns or its group is finished (pipeline.cpp release_frame_pins).
+    unsigned long long pins[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int npins = 0;
 };
 
 struct FrameGroup {
@@ -145,6 +150,8 @@ struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-a
     unsigned long long stamp = 0;
     long long ticket = -1;  // latest frame whose copies use this range (may still be in flight)
     unsigned long long id = 0;  // the process-wide registry's entry this instance holds a reference to (0: adopted range)
+    int users = 0;              // frames in flight that hold this range (counted for `transient` ranges only)
+    bool transient = false;     // pin mode 1: the registration lives exactly as long as frames in flight use it
 };
 
 struct FailedTickets {  // a group whose launch failed: every wait on one of its frames reports `error`
@@ -205,7 +212,10 @@ struct jinc_filter {
     int open_group = -1;      // index of the group being filled, -1: none
     int last_group = 0;       // most recently opened group (the ring advances from here)
     long long next_ticket = 0;
-    bool register_host = false;
+    // How caller buffers travel: 1 (the default of a new instance) pinned by this library while their frame is in flight; 2 pinned
+    // and cached by address (a host with a frame pool); 0 handed to the HIP runtime as they are (pageable unless adopted) --
+    // see include/jincresize_hip.h for why 0 is no longer the default (the runtime's own cache of on-the-fly pins, keyed by address).
+    int register_host = 1;
     std::vector<jinc::host::PinnedRange> pinned;
     std::vector<jinc::host::FailedTickets> failed;  // groups whose launch failed and whose buffer has gone back into the ring
     unsigned long long pin_clock = 0;
@@ -273,10 +283,11 @@ const char* last_interior_kernel_in_process();
 int last_call_frames_in_process();
 const char* last_interior_instance_in_process();
 // pipeline.cpp: frames in flight on one instance
-void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host);  // drains first
+void configure_pipeline(jinc_filter& f, int depth, int group, int register_host);  // drains first; register_host: 0 / 1 / 2 as jinc_filter::register_host
 long long submit_frame(jinc_filter& f, const void* const src[4], const int src_pitch[4], void* const dst[4], const int dst_pitch[4]);
 void wait_frame(jinc_filter& f, long long ticket);  // flushes the open group if the frame is in it
 void adopt_host_range(jinc_filter& f, void* base, size_t bytes);  // caller-pinned memory: usable for async copies and shader transport
+void release_host_range(jinc_filter& f, void* base, size_t bytes);  // the caller is about to unpin / free it: drains, then forgets adopted ranges that touch it
 void launch_open_group(jinc_filter& f);             // the frames submitted so far leave now (a client that knows no more are coming)
 void drain_pipeline(jinc_filter& f);                // every submitted frame complete
 void transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, bool reset);  // process-wide (test header)

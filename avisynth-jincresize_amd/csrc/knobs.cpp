@@ -30,6 +30,12 @@ thread_local const char* t_kernel = nullptr;
 thread_local bool t_noted = false;
 }  // namespace
 
+namespace {
+std::atomic<long long> g_live_host_registrations{0};
+}
+void count_host_registration(int delta) { g_live_host_registrations += delta; }
+long long live_host_registrations() { return g_live_host_registrations.load(); }
+
 bool is_set(int id) { return id >= 0 && id < JINC_KNOB_COUNT && g_slots[id].set.load(std::memory_order_acquire); }
 
 double get(int id, double unset_value) { return is_set(id) ? g_slots[id].value.load(std::memory_order_relaxed) : unset_value; }

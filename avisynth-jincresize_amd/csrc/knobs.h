@@ -13,6 +13,11 @@ inline int geti(int id, int unset_value) { return is_set(id) ? static_cast<int>(
 // an on/off knob: `unset_value` while unset, otherwise value != 0
 inline bool flag(int id, bool unset_value) { return is_set(id) ? get(id, 0.0) != 0.0 : unset_value; }
 
+// hipHostRegister / hipHostUnregister calls of this library that succeeded, process-wide (pipeline.cpp's registry and batch.cpp's
+// registrars): registered - unregistered = host ranges the library holds pinned right now (test header: jinc_debug_host_registrations).
+void count_host_registration(int delta);
+long long live_host_registrations();
+
 void set(int id, double value);
 void clear(int id);  // id < 0: every knob
 const char* name(int id);  // lower-case name ("quad_rg"), nullptr outside 0 .. JINC_KNOB_COUNT - 1

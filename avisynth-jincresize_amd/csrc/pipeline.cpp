@@ -43,6 +43,7 @@ struct SharedPin {
     int refs = 0;
     bool owned = false;  // registered here (else: found pinned)
     bool dead = false;   // unregistered early because it turned out stale (see shared_pin_acquire); kept until its references are back
+    unsigned long long devices = 0;  // bit d: an instance on device d has held a reference (whose work may run through the range's mapping)
 };
 // The registry outlives every static destructor (a leaked function-local static): a host may free its filters -- and
 // with them release pins -- while the process's own statics are already being destroyed.
@@ -56,66 +57,96 @@ PinRegistry& pin_registry() {
     return r;
 }
 
-// Every device idle: before a registration that instances still hold references to is unregistered early (a transport kernel
-// or an asynchronous copy of one of them may still be going through the range's device mapping).
-void quiesce_devices() {
-    int n = 0, cur = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || hipGetDevice(&cur) != hipSuccess) {
+// The devices of `mask` idle: before a registration that instances still hold references to is unregistered early (a transport
+// kernel or an asynchronous copy of one of them may still be going through the range's device mapping).  Only devices whose
+// instances have held the range are touched (a rank of a one-process-per-GPU job must not create contexts on the
+// other seven), and never under the registry's lock.
+void quiesce_devices(unsigned long long mask) {
+    int cur = 0;
+    if (!mask || hipGetDevice(&cur) != hipSuccess) {
         (void)hipGetLastError();
         return;
     }
-    for (int d = 0; d < n; ++d)
-        if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
+    for (int d = 0; d < 64; ++d)
+        if ((mask >> d) & 1)
+            if (hipSetDevice(d) == hipSuccess) (void)hipDeviceSynchronize();
     (void)hipSetDevice(cur);
     (void)hipGetLastError();
 }
 std::atomic<long long> g_frames_by_shader{0}, g_frames_by_dma{0};  // how results left the device, process-wide (test header)
 
 // A reference to a live registered range that contains [c, c + bytes), registering it if need be; false: not pinnable.
-// STALE registrations: the host may free memory this registry still holds pinned (instances keep references for as long as
-// their caches do), and hand out the same addresses again in other sizes.  hipHostRegister refuses a range whose START lies
-// inside an existing registration; if that registration is one of ours and does not contain the new range, it can only be
-// stale -- two live buffers do not overlap -- so it is unregistered on the spot (marked dead: holders find out through
-// shared_pin_alive and let go) and the new range is registered in its place.  A range is taken for "pinned by somebody
-// else" only if NONE of our registrations touches it (two stale ranges under its ends with a hole between them would pass
-// the device-address probe and fault in the hole).
-bool shared_pin_acquire(char* c, size_t bytes, unsigned long long* id, char** base, size_t* len) {
-    std::lock_guard<std::mutex> lock(pin_registry().mutex);
-    for (auto& e : pin_registry().pins)
-        if (!e.dead && c >= e.base && c + bytes <= e.base + e.bytes) {
-            ++e.refs;
-            *id = e.id, *base = e.base, *len = e.bytes;
+// STALE registrations (pin mode 2 only: mode 1 lets go of a range with its last frame in flight): the host may free memory
+// this registry still holds pinned (instances keep references for as long as their caches do), and hand out the same
+// addresses again in other sizes.  hipHostRegister refuses a range whose START lies inside an existing registration; if that
+// registration is one of ours and does not contain the new range, it can only be stale -- two live buffers do not overlap --
+// so it is marked dead (holders find out through shared_pin_alive and let go), unregistered once the devices that used it are
+// idle, and the new range is registered in its place.  A range is taken for "pinned by somebody else" only if NONE of our
+// registrations touches it (two stale ranges under its ends with a hole between them would pass the device-address probe and
+// fault in the hole).  What this cannot see is a range that came back at the SAME address and size: that is the promise of mode 2.
+bool shared_pin_acquire(char* c, size_t bytes, int device, unsigned long long* id, char** base, size_t* len) {
+    const unsigned long long dev_bit = device >= 0 && device < 64 ? 1ull << device : 0;
+    struct Stale {
+        char* base;
+        unsigned long long devices;
+        bool held;
+    };
+    std::vector<Stale> stale;
+    bool touches_ours = false;
+    {
+        std::lock_guard<std::mutex> lock(pin_registry().mutex);
+        for (auto& e : pin_registry().pins)
+            if (!e.dead && c >= e.base && c + bytes <= e.base + e.bytes) {
+                ++e.refs;
+                e.devices |= dev_bit;
+                *id = e.id, *base = e.base, *len = e.bytes;
+                return true;
+            }
+        if (hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
+            knobs::count_host_registration(+1);
+            pin_registry().pins.push_back({pin_registry().next_id++, c, bytes, 1, true, false, dev_bit});
+            *id = pin_registry().pins.back().id, *base = c, *len = bytes;
             return true;
         }
-    bool owned = true;
-    if (hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) {
         (void)hipGetLastError();
-        bool retry = false, touches_ours = false;
         for (auto& e : pin_registry().pins) {
             if (e.dead || !e.owned) continue;
             if (c >= e.base && c < e.base + e.bytes) {  // our registration under the new range's start, not containing it: stale
-                if (e.refs > 0) quiesce_devices();  // (holders learn of it only at their next pin_host_range: nothing of theirs may still be in flight)
-                (void)hipHostUnregister(e.base);
-                (void)hipGetLastError();  // (it may already be gone with its memory: the sticky error must not meet the next launch)
-                e.dead = true;
-                retry = true;
+                e.dead = true;  // from here on nobody takes a new reference to it
+                stale.push_back({e.base, e.devices, e.refs > 0});
             } else if (c + bytes > e.base && c < e.base + e.bytes) {
                 touches_ours = true;
             }
         }
-        bool ok = retry && hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
-        if (!ok) {
-            (void)hipGetLastError();
-            if (retry || touches_ours) return false;
-            void *d0 = nullptr, *d1 = nullptr;  // pinned by the host application itself?  Both ends must have a device address.
-            if (hipHostGetDevicePointer(&d0, c, 0) != hipSuccess || hipHostGetDevicePointer(&d1, c + bytes - 1, 0) != hipSuccess) {
-                (void)hipGetLastError();
-                return false;
-            }
-            owned = false;
-        }
     }
-    pin_registry().pins.push_back({pin_registry().next_id++, c, bytes, 1, owned, false});
+    // outside the lock: other threads' acquires and releases go on while the devices drain
+    for (const Stale& st : stale) {
+        if (st.held) quiesce_devices(st.devices);  // (holders learn of it only at their next pin_host_range: nothing of theirs may still be in flight)
+        if (hipHostUnregister(st.base) == hipSuccess) knobs::count_host_registration(-1);
+        (void)hipGetLastError();  // (it may already be gone with its memory: the sticky error must not meet the next launch)
+    }
+    bool owned = true;
+    const bool again = !stale.empty() && hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
+    if (again) knobs::count_host_registration(+1);
+    if (!again) {
+        (void)hipGetLastError();
+        if (!stale.empty() || touches_ours) return false;
+        // Pinned by the host application itself?  Then the WHOLE range lies inside one registered object: its first byte has a
+        // device address, and the allocation that address belongs to reaches past the range's last byte (two foreign ranges under
+        // the ends with unpinned pages between them must not pass: the transport kernel would fault in the hole).
+        void* d0 = nullptr;
+        hipDeviceptr_t obj = nullptr;
+        size_t obj_bytes = 0;
+        if (hipHostGetDevicePointer(&d0, c, 0) != hipSuccess || hipMemGetAddressRange(&obj, &obj_bytes, d0) != hipSuccess ||
+            static_cast<char*>(d0) < static_cast<char*>(obj) ||
+            static_cast<size_t>(static_cast<char*>(d0) - static_cast<char*>(obj)) + bytes > obj_bytes) {
+            (void)hipGetLastError();
+            return false;
+        }
+        owned = false;
+    }
+    std::lock_guard<std::mutex> lock(pin_registry().mutex);
+    pin_registry().pins.push_back({pin_registry().next_id++, c, bytes, 1, owned, false, dev_bit});
     *id = pin_registry().pins.back().id, *base = c, *len = bytes;
     return true;
 }
@@ -128,14 +159,22 @@ bool shared_pin_alive(unsigned long long id) {
 }
 
 void shared_pin_release(unsigned long long id) {
-    std::lock_guard<std::mutex> lock(pin_registry().mutex);
-    for (size_t i = 0; i < pin_registry().pins.size(); ++i)
-        if (pin_registry().pins[i].id == id) {
-            if (--pin_registry().pins[i].refs > 0) return;
-            if (pin_registry().pins[i].owned && !pin_registry().pins[i].dead && hipHostUnregister(pin_registry().pins[i].base) != hipSuccess) (void)hipGetLastError();
-            pin_registry().pins.erase(pin_registry().pins.begin() + static_cast<std::ptrdiff_t>(i));
-            return;
+    char* unregister = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(pin_registry().mutex);
+        for (size_t i = 0; i < pin_registry().pins.size(); ++i)
+            if (pin_registry().pins[i].id == id) {
+                if (--pin_registry().pins[i].refs > 0) return;
+                if (pin_registry().pins[i].owned && !pin_registry().pins[i].dead) unregister = pin_registry().pins[i].base;
+                pin_registry().pins.erase(pin_registry().pins.begin() + static_cast<std::ptrdiff_t>(i));
+                break;
+            }
+        // (unregistered under the lock: a concurrent acquire of the same range must either find the entry or find the range free)
+        if (unregister) {
+            if (hipHostUnregister(unregister) == hipSuccess) knobs::count_host_registration(-1);
+            else (void)hipGetLastError();
         }
+    }
 }
 
 void release_group(FrameGroup& g) {  // (the belts are idle: callers drain first)
@@ -224,6 +263,21 @@ void ensure_group(jinc_filter& f, FrameGroup& g) {
     g.capacity = f.group_frames;
 }
 
+// Pin mode 1: the frame's transfers are over, so are its registrations -- unless another frame in flight holds the same range.
+void release_frame_pins(jinc_filter& f, GroupFrame& fr) {
+    for (int k = 0; k < fr.npins; ++k)
+        for (size_t i = 0; i < f.pinned.size(); ++i) {
+            PinnedRange& r = f.pinned[i];
+            if (r.adopted || r.id != fr.pins[k]) continue;
+            if (--r.users <= 0 && r.transient) {
+                shared_pin_release(r.id);
+                f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
+            }
+            break;
+        }
+    fr.npins = 0;
+}
+
 // The group's previous use is over: every frame of it complete (or failed), the buffer free for the next run of frames.
 void finish_group(jinc_filter& f, FrameGroup& g) {
     // Launched: the event of the group's last frame closes everything the group has queued (the departures belt is in
@@ -232,6 +286,7 @@ void finish_group(jinc_filter& f, FrameGroup& g) {
         hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames.back().done_event)]), "hipEventSynchronize(group done)");
     else if (g.state != FrameGroup::Idle && h2d_of(f, g))
         hip_check(hipStreamSynchronize(h2d_of(f, g)), "stream sync");
+    for (GroupFrame& fr : g.frames) release_frame_pins(f, fr);  // nothing of the group is on the wire any more
 }
 
 void retire_group(jinc_filter& f, FrameGroup& g) {
@@ -344,6 +399,8 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
         if (d2h_of(f, g)) (void)hipStreamSynchronize(d2h_of(f, g));
         g.state = FrameGroup::Failed;
         g.error = e.what();
+        if (h2d_of(f, g)) (void)hipStreamSynchronize(h2d_of(f, g));
+        for (GroupFrame& fr : g.frames) release_frame_pins(f, fr);
         throw;
     }
 }
@@ -353,21 +410,37 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
 // nullptr if the range could not be pinned (the frame then takes the DMA / pageable path -- not an error).  The cache
 // holds at least every range the frames in flight can reference (frames x planes x (src + dst)), and a range whose frame
 // may still be in flight is never unregistered under its transfer: its group is finished first.
-char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket) {
+// Pin mode 1 (f.register_host == 1): no cache -- the registration is `transient`, held by the frames in flight that use it
+// (`fr`) and given back with the last of them (release_frame_pins), so that no registration outlives a buffer the host is
+// free to release once its frame's wait has returned.  Mode 2 keeps registrations cached by address (a host with a frame
+// pool that stays mapped); what a range costs to register again and again: profiles/round6/pin_modes.log.
+char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket, GroupFrame* fr) {
     char* c = const_cast<char*>(static_cast<const char*>(p));
+    auto hold = [&](PinnedRange& r) {  // the frame keeps a transient range alive until its transfers are over
+        if (!r.transient || !fr) return;
+        for (int k = 0; k < fr->npins; ++k)
+            if (fr->pins[k] == r.id) return;  // (two planes of the frame in one range: one hold)
+        if (fr->npins < 8) {
+            fr->pins[fr->npins++] = r.id;
+            ++r.users;
+        }
+    };
     for (size_t i = 0; i < f.pinned.size(); ++i) {
         PinnedRange& r = f.pinned[i];
         if (c < r.base || c + bytes > r.base + r.bytes) continue;
         if (!r.adopted && !shared_pin_alive(r.id)) {  // the registry found the range stale and let go of it: so does this instance
+            if (r.users > 0) return nullptr;          // (frames in flight still name it: they finish first; this plane goes pageable)
             shared_pin_release(r.id);
             f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
             break;
         }
         r.stamp = ++f.pin_clock;
         r.ticket = ticket;
+        hold(r);
         return r.dev ? r.dev + (c - r.base) : nullptr;
     }
     if (!f.register_host) return nullptr;  // only ranges the caller pinned are known: this one is pageable
+    const bool transient = f.register_host == 1;
     const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
     const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
     size_t own = 0;
@@ -375,25 +448,36 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
     if (own >= capacity) {
         size_t lru = f.pinned.size();
         for (size_t i = 0; i < f.pinned.size(); ++i)
-            if (!f.pinned[i].adopted && (lru == f.pinned.size() || f.pinned[i].stamp < f.pinned[lru].stamp)) lru = i;
+            if (!f.pinned[i].adopted && f.pinned[i].users == 0 && (lru == f.pinned.size() || f.pinned[i].stamp < f.pinned[lru].stamp)) lru = i;
+        if (lru == f.pinned.size()) return nullptr;  // every range is held by a frame in flight: this plane goes pageable
+        const long long lru_ticket = f.pinned[lru].ticket;
+        const unsigned long long lru_id = f.pinned[lru].id;
         for (auto& g : f.groups)  // its transfers may still run (a group being filled has its H2D copies queued already)
-            for (const GroupFrame& fr : g.frames)
-                if (fr.ticket == f.pinned[lru].ticket) {
+            for (size_t k = 0; k < g.frames.size(); ++k)
+                if (g.frames[k].ticket == lru_ticket) {
                     if (g.state == FrameGroup::Filling || g.state == FrameGroup::Launched) finish_group(f, g);
+                    break;
                 }
-        shared_pin_release(f.pinned[lru].id);
-        f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(lru));
+        for (size_t i = 0; i < f.pinned.size(); ++i)  // (finish_group may have let transient ranges go: look the entry up again)
+            if (!f.pinned[i].adopted && f.pinned[i].id == lru_id) {
+                shared_pin_release(lru_id);
+                f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
+                break;
+            }
     }
     char* base = nullptr;
     size_t len = 0;
     unsigned long long id = 0;
-    if (!shared_pin_acquire(c, bytes, &id, &base, &len)) return nullptr;  // e.g. the range straddles memory somebody else has registered
+    if (!shared_pin_acquire(c, bytes, f.device, &id, &base, &len)) return nullptr;  // e.g. the range straddles memory somebody else has registered
     void* dev = nullptr;
     if (hipHostGetDevicePointer(&dev, base, 0) != hipSuccess) {
         (void)hipGetLastError();
         dev = nullptr;
     }
-    f.pinned.push_back({base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket, id});
+    PinnedRange nr{base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket, id};
+    nr.transient = transient;
+    f.pinned.push_back(nr);
+    hold(f.pinned.back());
     return dev ? static_cast<char*>(dev) + (c - base) : nullptr;
 }
 
@@ -467,6 +551,14 @@ void adopt_host_range(jinc_filter& f, void* base, size_t bytes) {
     f.pinned.push_back(nr);
 }
 
+void release_host_range(jinc_filter& f, void* base, size_t bytes) {
+    drain_pipeline(f);  // nothing of this instance may still travel through the range's mapping
+    char* c = static_cast<char*>(base);
+    f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(),
+                                  [&](const PinnedRange& r) { return r.adopted && c < r.base + r.bytes && c + bytes > r.base; }),
+                   f.pinned.end());
+}
+
 void transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, bool reset) {
     if (by_shader) *by_shader = g_frames_by_shader.load();
     if (by_dma) *by_dma = g_frames_by_dma.load();
@@ -502,7 +594,7 @@ void drain_pipeline(jinc_filter& f) {
     for (auto& g : f.groups) finish_group(f, g);
 }
 
-void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host) {
+void configure_pipeline(jinc_filter& f, int depth, int group, int register_host) {
     drain_pipeline(f);
     for (auto& g : f.groups) retire_group(f, g);
     f.failed.clear();  // the explicit reset: failures of the previous configuration are not carried over
@@ -529,8 +621,8 @@ void configure_pipeline(jinc_filter& f, int depth, int group, bool register_host
     f.groups.resize(ring);
     f.open_group = -1;
     f.last_group = 0;
-    f.register_host = register_host;
-    if (!f.register_host) {  // ranges this instance pinned go; ranges the caller pinned stay known
+    f.register_host = std::max(0, std::min(2, register_host));
+    if (f.register_host != 2) {  // cached registrations go (the pipeline is drained: nothing holds a transient one); ranges the caller pinned stay known
         for (auto& p : f.pinned)
             if (!p.adopted) shared_pin_release(p.id);
         f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(), [](const PinnedRange& r) { return !r.adopted; }), f.pinned.end());
@@ -562,20 +654,26 @@ long long submit_frame(jinc_filter& f, const void* const src[4], const int src_p
     const long long ticket = f.next_ticket;
     GroupFrame fr;
     fr.ticket = ticket;
-    for (int i = 0; i < f.planecount; ++i) {
-        int sw, sh, dw, dh;
-        f.plane_dims(f.vi_in, i, sw, sh);
-        f.plane_dims(f.vi_out, i, dw, dh);
-        if (f.register_host || !f.pinned.empty()) {
-            (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket);
-            fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket);
+    try {
+        for (int i = 0; i < f.planecount; ++i) {
+            int sw, sh, dw, dh;
+            f.plane_dims(f.vi_in, i, sw, sh);
+            f.plane_dims(f.vi_out, i, dw, dh);
+            if (f.register_host || !f.pinned.empty()) {
+                (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket, &fr);
+                fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket, &fr);
+            }
+            if (debug_skip() != 1)
+                hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
+                                           static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
+                          "H2D copy");
+            fr.dst[i] = dst[i];
+            fr.dst_pitch[i] = dst_pitch[i];
         }
-        if (debug_skip() != 1)
-            hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
-                                       static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
-                      "H2D copy");
-        fr.dst[i] = dst[i];
-        fr.dst_pitch[i] = dst_pitch[i];
+    } catch (...) {  // the frame never joined its group: what it queued must be off the wire before its registrations go
+        if (h2d_of(f, g)) (void)hipStreamSynchronize(h2d_of(f, g));
+        release_frame_pins(f, fr);
+        throw;
     }
     g.frames.push_back(fr);
     ++f.next_ticket;
@@ -588,8 +686,12 @@ void wait_frame(jinc_filter& f, long long ticket) {
         for (size_t k = 0; k < g.frames.size(); ++k) {
             if (g.frames[k].ticket != ticket) continue;
             if (g.state == FrameGroup::Filling) launch_group(f, g);  // the client wants this frame now: no more company
-            if (g.state == FrameGroup::Failed) throw HipError(g.error);
+            if (g.state == FrameGroup::Failed) {
+                release_frame_pins(f, g.frames[k]);  // (the failed launch synchronised the group's streams)
+                throw HipError(g.error);
+            }
             hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames[k].done_event)]), "hipEventSynchronize(frame done)");
+            release_frame_pins(f, g.frames[k]);  // pin mode 1: the caller may free the frame's buffers from here on
             return;
         }
     }

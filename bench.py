@@ -565,16 +565,18 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
     return out
 
 
-def e2e_record(pkg, config, depth=128, seconds=1.5):
+def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
     """Host planes in, host planes out through the look-ahead pipeline (jinc_filter_submit / _wait, one host thread,
-    caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it."""
+    caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it.
+    pin_mode 2: registrations cached by address (this function's buffers live as long as the instance: a frame pool);
+    pin_mode 1: every plane registered at submit and given back at its frame's wait (safe with any host allocator)."""
     import numpy as np
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
     fmt = pkg.FORMATS[fmt_name]
     frame_bytes = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
     depth = max(2, min(depth, int((2 << 30) // max(1, frame_bytes))))   # at most ~2 GiB of host frames (C2: 128, C4: 4)
     f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
-    f.set_pipeline(depth, True)
+    f.set_pipeline(depth, pin_mode)
     rng = np.random.default_rng(3)
     nbuf = depth + 1
     srcs, dsts = [], []
@@ -607,10 +609,58 @@ def e2e_record(pkg, config, depth=128, seconds=1.5):
         f.wait(tickets.pop(0))
     el = time.perf_counter() - t0
     rec = {"what": "host planes -> jinc_filter_submit/_wait -> host planes, one host thread, buffers pinned in place; not `value`",
+           "pin_mode": {1: "1: pinned while the frame is in flight", 2: "2: pinned once, cached by address (frame pool)"}.get(pin_mode, str(pin_mode)),
            "frames_per_s": round(n / el, 1), "Mpix_per_s": round(n / el * dw * dh / 1e6, 1),
            "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2), "frames_in_flight": depth, "frames_per_launch": f.pipeline_group,
            "kernel": kernel, "seconds": round(el, 2)}
     f.close()
+    return rec
+
+
+def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32):
+    """The path a plugin or batch tool takes on a node: host planes -> jinc_batch_process (frame n -> device n mod G, one worker
+    and one registrar thread per device on the CPUs of the device's NUMA node, `streams` frames in flight per device, no
+    collective) -> host planes.  Total and per-device frames/s, GB/s per link.  PCIe-inclusive, NOT `value`.  Run by rank 0
+    from ONE process over the first `ndevices` visible devices after the timed region (VERDICT r5 Next 6a: the 1 -> 8 curve
+    of the device-resident kernels scales trivially; this is the leg with a serial stage in it)."""
+    import numpy as np
+    fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
+    fmt = pkg.FORMATS[fmt_name]
+    frame_bytes = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
+    ndevices = max(1, min(int(ndevices), pkg.device_count()))
+    in_flight = 2 * streams * ndevices
+    nbuf = max(2, min(in_flight + 16, int((6 << 30) // max(1, frame_bytes))))   # distinct host frames: at most ~6 GiB
+    streams = max(1, min(streams, nbuf // (2 * ndevices)))                       # a buffer is never in flight twice
+    per_call = max(nbuf, (256 * ndevices) // nbuf * nbuf)                         # frames per jinc_batch_process call (buffers cycle)
+    rng = np.random.default_rng(5)
+    srcs, dsts = [], []
+    for _ in range(nbuf):
+        planes = []
+        for (w, h) in fmt.plane_dims(sw, sh):
+            p = pkg.alloc_plane(w, h, fmt.dtype)
+            p[:] = (rng.random(p.shape) * (((1 << fmt.bits) - 1) if fmt.sample_bytes < 4 else 1)).astype(fmt.dtype)
+            planes.append(p)
+        srcs.append(planes)
+        dsts.append([pkg.alloc_plane(w, h, fmt.dtype) for (w, h) in fmt.plane_dims(dw, dh)])
+    b = pkg.Batch(fmt, sw, sh, dw, dh, ndevices=ndevices, streams=streams, register_host_buffers=pkg.PIN_POOL, **kw)
+    frames = [srcs[k % nbuf] for k in range(per_call)]
+    outs = [dsts[k % nbuf] for k in range(per_call)]
+    b.process(frames, outs)   # warm-up: group buffers, registration of the host frames
+    n, calls, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        b.process(frames, outs)
+        n += per_call
+        calls += 1
+    el = time.perf_counter() - t0
+    G = b.devices
+    rec = {"what": "host planes -> jinc_batch_process (frame n -> device n mod G; a worker and a registrar thread per device, NUMA-bound) -> host planes; not `value`",
+           "devices": G, "frames_per_s": round(n / el, 1), "frames_per_s_per_device": round(n / el / G, 1),
+           "Mpix_per_s": round(n / el * dw * dh / 1e6, 1), "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2),
+           "GB_per_s_per_link": round(n / el * frame_bytes / 1e9 / G, 2), "frames_in_flight_per_device": streams,
+           "frames_per_call": per_call, "calls": calls, "distinct_host_frames": nbuf, "pin_mode": "2: pinned once, kept until jinc_batch_free",
+           "cpus_of_device": {str(d): (lambda c: f"{len(c)} CPUs ({c[0]}..{c[-1]})" if c else "unknown: not bound")(b.device_cpus(d)) for d in range(G)},
+           "seconds": round(el, 2)}
+    b.close()
     return rec
 
 
@@ -1047,6 +1097,14 @@ def main(argv=None):
                 line["e2e"] = e2e_record(pkg, args.config)
             except Exception as exc:  # noqa: BLE001  (a record next to the value, never a reason to lose the line)
                 line["e2e"] = {"error": str(exc)}
+        # the host-to-host leg over ALL the job's devices, from this one process (rank 0), for every N -- the curve the
+        # driver draws from `value` is the device-resident one; this record is the path with host threads and the links in it
+        line["e2e_batch"] = None
+        if not args.no_e2e and not profiled:
+            try:
+                line["e2e_batch"] = e2e_batch_record(pkg, args.config, n_gpus)
+            except Exception as exc:  # noqa: BLE001
+                line["e2e_batch"] = {"error": str(exc)}
         if n_gpus == 1 and not args.no_cpu_baseline and not profiled:
             line["cpu_baseline"] = cpu_baseline(args.config)
         else:

@@ -176,10 +176,22 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 8; else 1): one group computes while the client collects
  * the previous one.  src and dst must stay valid and untouched until the frame's wait returns.  Frames are
  * independent, so neither grouping nor completion order changes results.
- * register_host_buffers != 0: every plane buffer seen is pinned with hipHostRegister (cached by address range,
- * least recently used out) so that the copies really are asynchronous and overlap; the caller then guarantees
- * that such buffers stay allocated until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0).  With pageable
- * buffers the pipeline still works but the copies serialise on the host.
+ * register_host_buffers: how the library treats the caller's plane buffers (a new instance starts in mode 1, also for
+ * jinc_filter_get_frame) --
+ *   0  handed to the HIP runtime as they are.  The pipeline works and the copies serialise on the host; but for pageable
+ *      memory the runtime pins the range on the fly and KEEPS its last few pins per stream, found again by address and
+ *      size: with a host allocator that returns freed frame memory to the kernel (glibc trims its heap) and hands the same
+ *      addresses out again, such a kept pin maps pages that are gone -- seen in this repository's tests as a GPU memory
+ *      access fault on a heap address inside a synchronous call that had registered nothing.  For hosts that know their
+ *      frame memory never goes back to the kernel, and for planes inside adopted ranges;
+ *   1  pinned (hipHostRegister) for exactly as long as their frame is in flight: registered at submit, given back when the
+ *      frame's wait returns -- the copies are asynchronous, the results are written by the shader, and NO registration
+ *      outlives a buffer the caller is free to release after the wait (safe with any allocator; costs a registration per
+ *      plane and frame);
+ *   2  pinned and CACHED by address range (least recently used out), no cost per frame once a buffer has been seen: for
+ *      hosts whose frame memory is a pool that stays mapped.  The caller guarantees that such buffers stay allocated
+ *      until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0 or 1): a cached registration that outlives its
+ *      pages is a GPU mapping of memory that is gone, which the library cannot detect when the addresses come back.
  * A failed launch is reported by the submit that triggered it and by every wait on a frame of that group.
  * jinc_filter_get_frame == submit + wait (after draining frames still in flight). */
 JINC_API int jinc_filter_set_pipeline(jinc_filter *f, int depth, int register_host_buffers);
@@ -193,6 +205,9 @@ JINC_API int jinc_filter_flush(jinc_filter *f); /* launch the frames submitted s
  * copies, results written by the shader), with no registration cost per frame and whatever register_host_buffers
  * says; the instance never unregisters them. */
 JINC_API int jinc_filter_adopt_host_range(jinc_filter *f, void *base, size_t bytes);
+/* The counterpart: the caller is about to unpin or free [base, base + bytes).  Waits for the instance's frames in flight
+ * and forgets every adopted range that touches it (planes there are pageable again unless adopted anew). */
+JINC_API int jinc_filter_release_host_range(jinc_filter *f, void *base, size_t bytes);
 JINC_API int jinc_filter_wait(jinc_filter *f, long long ticket);
 
 /* Same computation on DEVICE-resident planes, asynchronously on `hip_stream` (a hipStream_t; NULL is
@@ -215,7 +230,12 @@ JINC_API int jinc_filter_sync(jinc_filter *f);
  * device holds a replica of the plan (one filter instance) and keeps `streams_per_device` (1..256) frames in flight
  * through the look-ahead pipeline above (frames coalesced into groups of streams_per_device / 2 per launch), driven by
  * one host thread per device.  No collective.
- * ndevices <= 0: all visible devices.  register_host_buffers: as for jinc_filter_set_pipeline.
+ * ndevices <= 0: all visible devices.  register_host_buffers: 0 pageable; 1 the planes of a jinc_batch_process call are
+ * pinned for the duration of that call (by one registrar thread per device running ahead of the submissions; the caller may
+ * free them afterwards); 2 they stay pinned until jinc_batch_free (a caller that re-uses its planes call after call and
+ * keeps them allocated).  The worker and the registrar of device d run on the CPUs of d's NUMA node (sysfs numa_node of the
+ * device's PCI function); jinc_batch_set_affinity(b, 0) leaves the threads where the scheduler puts them.
+ * jinc_batch_device_cpus: the CPUs found for the batch's device_index-th device (returns their number, 0 if unknown).
  * jinc_batch_process: src_planes / dst_planes hold 4 pointers per frame ([frame][plane], planes in the reference's
  * processing order, unused planes NULL), HOST buffers with the given pitches (bytes); returns when every frame is
  * complete.  Errors: first failure's status, message from jinc_batch_last_error(). */
@@ -224,6 +244,8 @@ JINC_API int jinc_shard_device(int frame, int ndevices);
 JINC_API int jinc_batch_create(const jinc_video_info *vi, const jinc_args *args, int ndevices, int streams_per_device,
                                int register_host_buffers, jinc_batch **out, char *err, size_t err_len);
 JINC_API int jinc_batch_devices(const jinc_batch *b);
+JINC_API int jinc_batch_set_affinity(jinc_batch *b, int on);
+JINC_API int jinc_batch_device_cpus(const jinc_batch *b, int device_index, int *cpus, int max_cpus);
 JINC_API int jinc_batch_device_of_frame(const jinc_batch *b, int frame);
 JINC_API int jinc_batch_process(jinc_batch *b, int nframes, const void *const *src_planes, const int src_pitch[4],
                                 void *const *dst_planes, const int dst_pitch[4]);

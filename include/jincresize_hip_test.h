@@ -44,6 +44,16 @@ JINC_API int jinc_filter_plan_runs(const jinc_filter *f, int table, int *n_runs,
 /* Copies the coefficient set `set` (filter_size^2 floats). */
 JINC_API int jinc_filter_plan_set(const jinc_filter *f, int table, int set, float *coeffs);
 /* The 1024-entry LUT (ref :265-275) as doubles. */
+/* batch.cpp's NUMA lookup against a sysfs tree given by the caller (a fake one in tests/test_batch_affinity.py): the CPUs of
+ * the NUMA node of PCI function `bdf` under `sysfs_root`; returns their number (0: unknown node, numa_node = -1, ...). */
+/* Registrar threads of jinc_batch_process (0: one per device, the default): lets a one-device box run several side by side. */
+struct jinc_batch;
+JINC_API int jinc_debug_batch_set_registrars(struct jinc_batch *b, int n);
+/* Host ranges hipHostRegister refused since the batch was created (their planes travel pageable); `first`: what the first was told. */
+JINC_API int jinc_debug_batch_refused(struct jinc_batch *b, char *first, size_t first_len);
+/* hipHostRegister minus hipHostUnregister calls of this library that succeeded: the host ranges it holds pinned right now. */
+JINC_API long long jinc_debug_host_registrations(void);
+JINC_API int jinc_debug_numa_cpus(const char *sysfs_root, const char *bdf, int *cpus, int max_cpus);
 JINC_API int jinc_filter_lut(const jinc_filter *f, double *lut1024);
 
 /* Kernel selection override for tests/benchmarks: 0 = automatic, 1 = force the generic gather

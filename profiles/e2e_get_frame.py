@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--pipeline", type=int, nargs="*", default=[], help="also time ONE host thread with these pipeline depths")
     ap.add_argument("--group", type=int, default=0, help="frames coalesced per launch (0: automatic = depth / 2)")
     ap.add_argument("--registered-only", action="store_true")
+    ap.add_argument("--pin-mode", type=int, default=-1, help="-1: the instance's default (1: planes pinned while the frame is in flight); 0 / 1 / 2: set_pipeline(1, mode)")
     a = ap.parse_args()
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, _ = bench.CONFIGS[a.config]
@@ -38,6 +39,8 @@ def main():
 
         def work(k):
             f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
+            if a.pin_mode >= 0:
+                f.set_pipeline(1, a.pin_mode)
             src = []
             for (w, h) in fmt.plane_dims(sw, sh):
                 p = pkg.alloc_plane(w, h, fmt.dtype)
