@@ -44,7 +44,7 @@ struct Instance {
     int next_submit = 0;          // frames of the window below this one have been submitted
     int resubmit = -1;            // a frame of the window that was served already and is wanted again
     std::mutex mutex;             // look-ahead state (hosts that honour MT_SERIALIZED never contend for it)
-    int pin_frames = 0;           // JINCRESIZE_PIN_FRAMES: 1 frame buffers pinned while their frame is in flight, 2 / "pool" pinned and cached by address
+    int pin_frames = 1;           // JINCRESIZE_PIN_FRAMES: 1 (default) frame buffers pinned while their frame is in flight, 2 / "pool" pinned and cached by address, 0 left to the runtime
     std::string error;            // storage for fi->error
 };
 
@@ -342,7 +342,7 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
         if (jinc_filter_set_pipeline_group(filter, inst->lookahead, inst->group, inst->pin_frames) != JINC_OK) inst->lookahead = 1;
         inst->ring.resize(static_cast<size_t>(inst->lookahead));
     }
-    if (inst->lookahead == 1 && inst->pin_frames) jinc_filter_set_pipeline(filter, 1, inst->pin_frames);
+    if (inst->lookahead == 1 && inst->pin_frames != 1) jinc_filter_set_pipeline(filter, 1, inst->pin_frames);  // (1 is the instance's default)
 
     jinc_video_info out_vi;
     jinc_filter_output_info(filter, &out_vi);  // ref :791-792
