@@ -321,8 +321,17 @@ class knobs:
 # JINC_<NAME> environment variables the profiles/ scripts and recheck_rules.py pass: translated into knobs by bench.py (the
 # library itself never reads the environment for them).
 def apply_env_knobs(environ=None) -> dict:
+    """Sets the knobs the environment names; JINC_* variables that name no knob are reported on stderr and returned under
+    "unknown_variables" (a script that still sets a variable whose knob is gone measures A against A without a word).
+    JINC_LIB and JINC_BENCH_* belong to the loader and to bench.py."""
     environ = os.environ if environ is None else environ
     applied = {}
+    known = {"JINC_" + n.upper() for n in knob_ids()}
+    unknown = sorted(k for k in environ if k.startswith("JINC_") and k not in known and k != "JINC_LIB" and not k.startswith("JINC_BENCH_"))
+    if unknown:
+        import sys
+        print("avisynth_jincresize_amd: environment variables that name no knob (ignored): " + ", ".join(unknown), file=sys.stderr, flush=True)
+        applied["unknown_variables"] = unknown
     for name in knob_ids():
         e = environ.get("JINC_" + name.upper())
         if e is None or e == "":

@@ -1939,6 +1939,11 @@ int launch_periodic_fs(const PeriodicArgs& pa, int fs, const PlaneIO& io, hipStr
     if ((variant == 5 || variant == 6) && fs == 6 && pa.quad)  // trimmed support, two periods per lane: 5 = tiles of 8 row groups, 6 = of 4
         return variant == 5 ? launch_periodic_quad2_t<T, 8>(pa, io, stream) : launch_periodic_quad2_t<T, 4>(pa, io, stream);
     if (variant == 7 && fs == 8 && pa.quad) return launch_periodic_quad2x8_t<T, 4>(pa, io, stream);  // two periods per lane
+    // Border columns handed over with the interior launch (PeriodicArgs::edge) are computed by the two launchers above and by
+    // nobody else: a caller that dropped its own column launches on the strength of them and then lands anywhere below -- a knob
+    // changed between its decision and this one, a rule edited on one side only -- must hear about it, not ship frames with
+    // unwritten columns.
+    if (pa.edge.coeffs) return static_cast<int>(hipErrorInvalidValue);
     if ((variant == 5 || variant == 6) && fs == 8 && pa.quad)  // trimmed 8 x 8 support: 5 = tiles of 8 row groups, 6 = of 4
         return variant == 5 ? launch_periodic_quad8_t<T, 8>(pa, io, stream) : launch_periodic_quad8_t<T, 4>(pa, io, stream);
     if ((variant == 5 || variant == 6) && fs == 7 && pa.quad)  // quad form: 5 = tiles of 8 row groups, 6 = of 4 (small calls)
@@ -1996,7 +2001,8 @@ int launch_periodic(const PeriodicArgs& args, int fs, const PlaneIO& io, void* s
     if (args.rowpair && knobs::flag(JINC_KNOB_ROWS_PAIR, true)) {
         const int taps = args.quad_taps ? args.quad_taps : fs;  // (6 rows x 7 columns: fs = 6 rows, 7 taps per row)
         const bool auto_variant = variant == 0 || variant == 2 || variant == 5 || variant == 6 || variant == 7;
-        if (args.rowpair_n == taps && ((fs >= 10 && variant == 0) || (fs < 10 && auto_variant && !args.edge.coeffs && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) == 1)))  // (edge columns: the caller counts on a quad form)
+        if (args.rowpair_n == taps && !args.edge.coeffs &&  // (edge columns: the caller counts on a two-periods quad form)
+            ((fs >= 10 && variant == 0) || (fs < 10 && auto_variant && knobs::geti(JINC_KNOB_ROWPAIR_SMALL, 0) == 1)))
             return launch_rowpair(args, io, stream);
     }
     hipStream_t s = static_cast<hipStream_t>(stream);

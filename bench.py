@@ -711,24 +711,35 @@ def known_answer(config):
     return None
 
 
+def check_positions(frames):
+    """Batch positions that carry the Appendix-A frame: the first frame, one in the middle of a 64-frame group and the last one
+    (kernels whose lanes are frames -- frame-lane, sub-group and frame-pair forms, border forms that depend on the
+    batch size -- can be wrong at other batch positions than 0)."""
+    return sorted({0, min(frames - 1, 37), frames - 1})
+
+
 def self_check(torch, config, fmt, dst_t, ddims):
-    """crc32 over frame 0 of the batch's OUTPUT (planes in processing order, rows truncated to the row size) against the known
-    answer: frame 0's input is the Appendix-A frame (make_workload), so the kernels the timed region ran -- at the batch size
-    it ran them -- have reproduced the reference's bytes, or the benchmark fails."""
+    """crc32 over the batch's OUTPUT at every position whose input is the Appendix-A frame (check_positions; planes in
+    processing order, rows truncated to the row size) against the known answer: the kernels the timed region ran -- at the
+    batch size it ran them -- have reproduced the reference's bytes at each of them, or the benchmark fails."""
     import zlib
     rec = known_answer(config)
     if rec is None:
         return {"status": "no known answer for this config", "crc32": None}
-    c, nbytes = 0, 0
-    for t, (w, h) in zip(dst_t, ddims):
-        if t.dtype == torch.uint16:
-            t = t.view(torch.int16)
-        host = t[0, :h, :w].contiguous().cpu().numpy()
-        c = zlib.crc32(host.tobytes(), c)
-        nbytes += host.nbytes
-    got = f"{c & 0xFFFFFFFF:08x}"
-    ok = got == rec["crc32"] and nbytes == rec["bytes"]
-    return {"status": "ok" if ok else "MISMATCH", "crc32": got, "expected": rec["crc32"], "bytes": nbytes, "frame": 0,
+    frames = int(dst_t[0].shape[0])
+    got, ok, nbytes = {}, True, 0
+    for pos in check_positions(frames):
+        c, nbytes = 0, 0
+        for t, (w, h) in zip(dst_t, ddims):
+            if t.dtype == torch.uint16:
+                t = t.view(torch.int16)
+            host = t[pos, :h, :w].contiguous().cpu().numpy()
+            c = zlib.crc32(host.tobytes(), c)
+            nbytes += host.nbytes
+        got[pos] = f"{c & 0xFFFFFFFF:08x}"
+        ok = ok and got[pos] == rec["crc32"] and nbytes == rec["bytes"]
+    return {"status": "ok" if ok else "MISMATCH", "crc32": got[0], "crc32_by_batch_position": {str(k): v for k, v in got.items()},
+            "expected": rec["crc32"], "bytes": nbytes, "frames_checked": sorted(got),
             "source": f"tests/golden/kat.json [{rec['name']}] (reference opt=0 on the Appendix-A LCG frame, seed 12345)"}
 
 
@@ -761,14 +772,16 @@ def make_workload(pkg, torch, config, frames, device, seed, lcg_first=False):
         if sb == 2:
             t = t.view(torch.uint16)
         src_t.append(t)
-    if lcg_first:   # frame 0 = the Appendix-A frame the known answers were recorded on (self_check)
+    if lcg_first:   # the Appendix-A frame the known answers were recorded on, at the batch positions self_check reads
         import numpy as np
         for t, plane, (w, h) in zip(src_t, lcg_planes(fmt, sw, sh), sdims):
             host = np.ascontiguousarray(plane)
-            if sb == 2:
-                t.view(torch.int16)[0, :h, :w] = torch.from_numpy(host.view(np.int16)).to("cuda")
-            else:
-                t[0, :h, :w] = torch.from_numpy(host).to("cuda")
+            dev_plane = torch.from_numpy(host.view(np.int16) if sb == 2 else host).to("cuda")
+            for pos in check_positions(frames):
+                if sb == 2:
+                    t.view(torch.int16)[pos, :h, :w] = dev_plane
+                else:
+                    t[pos, :h, :w] = dev_plane
     # A/B knob (measurements only): JINC_BENCH_DST_SHIFT = bytes the destination planes start beyond a 256-byte boundary (one spare
     # row per frame holds the overhang) -- which store alignment do the kernels meet?
     dst_shift = int(os.environ.get("JINC_BENCH_DST_SHIFT", "0"))
@@ -892,7 +905,7 @@ def main(argv=None):
                 raise SystemExit("C5: more ranks than frames")
         torch.cuda.set_device(dev)
         flt, step, stream, fmt, ddims = make_workload(pkg, torch, args.config, B, dev, 12345 + shard * B,
-                                                      lcg_first=(shard == 0 and not args.no_self_check))
+                                                      lcg_first=not args.no_self_check)   # every rank / device checks its own batch
         flt.set_kernel_mode(args.kernel_mode)
         if args.simd_order:
             flt.set_simd_order(args.simd_order)
@@ -938,9 +951,24 @@ def main(argv=None):
     per_ms, per_n, gat_ms, gat_n = flt.kernel_times()
     flt.set_profiling(False)
     dom_instance = flt.last_instance(0)   # the timed steps' interior kernel with its template arguments
-    check = None
-    if rank == 0 and getattr(loads[0]["step"], "checkable", False) and (not args.simd_order or FORCE_SELF_CHECK):
-        check = self_check(torch, args.config, fmt, loads[0]["step"].keepalive[1], ddims)
+    # every rank checks the batch of every device it drives; rank 0 reports its own detail and how many batches of the job failed
+    check, bad_here = None, 0
+    if not args.simd_order or FORCE_SELF_CHECK:
+        for w in loads:
+            if not getattr(w["step"], "checkable", False):
+                continue
+            torch.cuda.set_device(w["device"])
+            c = self_check(torch, args.config, fmt, w["step"].keepalive[1], ddims)
+            bad_here += c["status"] == "MISMATCH"
+            if check is None or c["status"] == "MISMATCH":
+                check = c
+        torch.cuda.set_device(devices[0])
+    _, bad_total, bad_by_rank = sync.reduce(0.0, float(bad_here))
+    if check is not None:
+        check["batches_failed_in_the_job"] = int(bad_total)
+        check["batches_failed_by_rank"] = [int(x) for x in bad_by_rank]
+        if bad_total:
+            check["status"] = "MISMATCH"
     # Shader clock under this load, in a SECOND, untimed pass of the same steps with eight single-lane samplers (one per XCD)
     # beside the kernels (kernel_probe.hip).  Not during the timed region: any second dispatch that stays active, however
     # small, costs kernels with short-lived workgroups 10-15 % (1080p -> 720p 253 -> 222 Gpix/s, C2 1 %;
@@ -1024,7 +1052,12 @@ def main(argv=None):
                 if "effective_clock_ghz" in rec:   # GRBM_GUI_ACTIVE / 8 / kernel time of the committed PMC pass
                     pmc_clock = {"ghz": rec["effective_clock_ghz"], "kernel_ms_in_that_pass": rec.get("clock_pass_kernel_ms"),
                                  "source": "profiles/traffic.json (rocprofv3 --pmc GRBM_GUI_ACTIVE pass of this command)"}
-                if "hbm_bytes_per_launch" in rec:  # PMC figure (2 x FETCH_SIZE + WRITE_SIZE), scaled to this run's frames per launch
+                # the PMC figure belongs to ONE kernel: when knobs or the kernel mode route the interior elsewhere it is not this run's
+                recorded = rec.get("kernel")
+                same_kernel = not recorded or dom_instance == recorded
+                if "hbm_bytes_per_launch" in rec and not same_kernel:
+                    traffic = traffic_raw = None
+                elif "hbm_bytes_per_launch" in rec:  # PMC figure (2 x FETCH_SIZE + WRITE_SIZE), scaled to this run's frames per launch
                     scale = B / (rec.get("frames_per_launch") or B)
                     traffic = int(rec["hbm_bytes_per_launch"] * scale)
                     traffic_raw = int(rec.get("hbm_bytes_per_launch_raw", 0) * scale) or None
