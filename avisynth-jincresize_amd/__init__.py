@@ -470,7 +470,7 @@ def _build_args(fmt, width, height, target_width, target_height, frame0_chroma_l
     return vi, a, keep
 
 
-PIN_NONE, PIN_IN_FLIGHT, PIN_POOL = 0, 1, 2   # register_host_buffers of set_pipeline / Batch (include/jincresize_hip.h)
+PIN_NONE, PIN_POOL = 0, 2   # register_host_buffers of set_pipeline / Batch (include/jincresize_hip.h): pageable / registered once and cached (any non-zero value)
 
 
 def numa_cpus(sysfs_root: str, bdf: str) -> List[int]:
@@ -626,8 +626,8 @@ class Filter:
     # -- look-ahead pipeline: several frames in flight per instance --
     def set_pipeline(self, depth: int, register_host_buffers: int = 0, group: int = 0) -> None:
         """Up to `depth` frames in flight; `group` of them coalesced into one launch (0: automatic = depth / 2).
-        register_host_buffers: PIN_NONE (0), PIN_IN_FLIGHT (1 / True: pinned while their frame is in flight), PIN_POOL (2:
-        pinned and cached by address; the caller keeps the buffers allocated)."""
+        register_host_buffers: PIN_NONE (0 / False) or PIN_POOL (non-zero / True: pinned once and cached by address; the caller keeps
+        the buffers allocated)."""
         self._check(lib().jinc_filter_set_pipeline_group(self._h, int(depth), int(group), int(register_host_buffers)))
 
     @property

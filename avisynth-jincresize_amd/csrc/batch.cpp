@@ -15,8 +15,8 @@
 // Round 6: ONE registrar served every device (~0.9 ms per 16-frame C2 chunk = 18 k frames/s in total,
 // three devices' worth) -- now one registrar per device, dealing the chunks round-robin, and every worker / registrar of
 // device d runs on the CPUs of d's NUMA node (sysfs: /sys/bus/pci/devices/<bdf>/numa_node; jinc_batch_set_affinity(b, 0)
-// switches the binding off).  register_host_buffers = 1 keeps a call's registrations for the duration of that call only
-// (the caller may free the planes afterwards); = 2 keeps them until jinc_batch_free (a caller that re-uses its planes).
+// switches the binding off).  Registrations stay until jinc_batch_free (a caller that re-uses its planes pays once; ending
+// them with every call was tried in round 6 and withdrawn with the per-frame form: registration churn, pipeline.cpp).
 // Built on the public C ABI (jinc_filter_create / _set_pipeline / _adopt_host_range / _release_host_range / _submit /
 // _flush / _wait) and hipHostRegister only.
 #include <hip/hip_runtime_api.h>
@@ -50,7 +50,7 @@ struct jinc_batch {
     std::vector<int> devices;
     int streams = 2;
     int planes = 0;
-    int register_host = 0;  // 0: pageable; 1: pinned for the duration of a jinc_batch_process call; 2: pinned until jinc_batch_free
+    int register_host = 0;  // 0: pageable; 2: the calls' planes are pinned and stay so until jinc_batch_free (1, pinned for the duration of a call, was built and withdrawn in round 6: registration churn, see pipeline.cpp pin_host_range)
     bool affinity = true;   // workers and registrars of device d run on the CPUs of d's NUMA node
     int registrars = 0;     // 0: one per device; > 0: that many (test header: several registrars on a one-device box)
     std::atomic<int> refused{0};  // ranges hipHostRegister would not take (their planes travel pageable), since creation
@@ -211,7 +211,7 @@ int jinc_batch_create(const jinc_video_info* vi, const jinc_args* args, int ndev
     if (!b) return batch_fail(JINC_ERR_NOMEM, "JincResize: out of memory.");
     b->streams = streams_per_device;
     b->planes = vi->num_components;
-    b->register_host = register_host_buffers < 0 ? 0 : register_host_buffers > 2 ? 2 : register_host_buffers;
+    b->register_host = register_host_buffers != 0 ? 2 : 0;
     b->vi_in = *vi;
     for (int d = 0; d < ndevices; ++d) {
         jinc_filter* f = nullptr;
@@ -318,7 +318,6 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
     std::condition_variable chunk_cv;
     std::vector<char> chunk_done(static_cast<size_t>(nchunks), 0);
     std::vector<std::vector<HostRange>> chunk_ranges(static_cast<size_t>(nchunks));  // what each chunk added (for adoption)
-    std::vector<HostRange> this_call;  // everything this call registered (mode 1: unregistered before it returns)
     // What each chunk has to register is settled HERE, in chunk order, before the registrars start (which range is "earlier"
     // must not depend on the order the threads get going); the registrars only make the expensive calls side by side.  Every
     // plane of chunk c lies inside one range of chunk c (or of an earlier chunk that already contains it), which the worker has
@@ -363,7 +362,6 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
                 }
                 {
                     std::lock_guard<std::mutex> lock(chunk_mutex);
-                    this_call.insert(this_call.end(), done.begin(), done.end());
                     chunk_ranges[static_cast<size_t>(c)] = std::move(done);
                     chunk_done[static_cast<size_t>(c)] = 1;
                 }
@@ -455,24 +453,6 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
     for (int d = 0; d < G; ++d) threads.emplace_back(worker, d);
     for (auto& t : threads) t.join();
     for (auto& t : registrars) t.join();
-    if (b->register_host == 1 && !this_call.empty()) {
-        // mode 1: the call's registrations end with the call (the workers have drained: nothing is in flight); the instances
-        // forget the ranges first
-        for (jinc_filter* f : b->filters)
-            for (const HostRange& r : this_call) (void)jinc_filter_release_host_range(f, r.base, r.bytes);
-        for (const HostRange& r : this_call) {
-            if (hipHostUnregister(r.base) == hipSuccess) jinc::knobs::count_host_registration(-1);
-            else (void)hipGetLastError();
-        }
-        std::lock_guard<std::mutex> lock(b->pin_mutex);
-        b->pinned.erase(std::remove_if(b->pinned.begin(), b->pinned.end(),
-                                       [&](const HostRange& p) {
-                                           for (const HostRange& r : this_call)
-                                               if (r.base == p.base) return true;
-                                           return false;
-                                       }),
-                        b->pinned.end());
-    }
     if (status.load() != JINC_OK) return batch_fail(status.load(), first_error);
     g_batch_error.clear();
     return JINC_OK;

@@ -1,10 +1,73 @@
 // device_plan.cpp -- device-resident plans of a filter instance: upload of the compact plan, and the launch planning
 // for every kernel family (which kernel computes which part of the output plane).  See DESIGN.md section 4.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
 #include "filter_internal.h"
 #include "knobs.h"
 
 namespace jinc {
 namespace host {
+
+namespace {
+
+// Tables leave the host through a pinned bounce buffer of the library's own (hipHostMalloc), never straight from the vectors
+// they were built in: handed a pageable pointer, the runtime maps that memory for the device on the fly, and in a process whose
+// allocator recycles pages (glibc trims its heap) such on-the-fly mappings of recycled heap pages have ended in GPU memory
+// access faults INSIDE these uploads (round 6: jinc_filter_create of test_framelane_pair, the library holding no registration
+// of its own at the time -- profiles/round6/README.md).  Create-time traffic: a CPU copy of a few hundred KB does not matter.
+struct Bounce {
+    std::mutex mutex;
+    void* host = nullptr;
+    static constexpr size_t kBytes = size_t(4) << 20;
+};
+Bounce& bounce() {
+    static Bounce& b = *new Bounce;  // (outlives static destruction, like the pin registry)
+    return b;
+}
+
+// `stream`: the instance's own stream where the caller has one (the copy is queued there and waited for: the device memory it
+// fills is then only ever touched from that stream -- with the copies on the null stream instead, create / frame / free cycles
+// without a device-wide synchronisation in between left freed plan memory unreturned: 18 MiB per cycle of a tap-12 plan,
+// profiles/round6/leak_ab.log); nullptr: a synchronous copy.
+void upload(void* dev, const void* host, size_t bytes, const char* what, hipStream_t stream = nullptr) {
+    if (!bytes) return;
+    auto copy = [&](void* d, const void* h, size_t n) {
+        if (stream) {
+            hip_check(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream), what);
+            hip_check(hipStreamSynchronize(stream), what);
+        } else {
+            hip_check(hipMemcpy(d, h, n, hipMemcpyHostToDevice), what);
+        }
+    };
+    if (!knobs::flag(JINC_KNOB_UPLOAD_BOUNCE, true)) {  // A/B: straight from the caller's (pageable) memory
+        copy(dev, host, bytes);
+        return;
+    }
+    Bounce& b = bounce();
+    std::lock_guard<std::mutex> lock(b.mutex);
+    if (!b.host) hip_check(hipHostMalloc(&b.host, Bounce::kBytes, hipHostMallocPortable), "hipHostMalloc(upload buffer)");
+    for (size_t at = 0; at < bytes; at += Bounce::kBytes) {
+        const size_t n = std::min(Bounce::kBytes, bytes - at);
+        std::memcpy(b.host, static_cast<const char*>(host) + at, n);
+        copy(static_cast<char*>(dev) + at, b.host, n);  // waited for: the buffer is free again
+    }
+}
+
+void download(void* host, const void* dev, size_t bytes, const char* what) {
+    if (!bytes) return;
+    Bounce& b = bounce();
+    std::lock_guard<std::mutex> lock(b.mutex);
+    if (!b.host) hip_check(hipHostMalloc(&b.host, Bounce::kBytes, hipHostMallocPortable), "hipHostMalloc(upload buffer)");
+    for (size_t at = 0; at < bytes; at += Bounce::kBytes) {
+        const size_t n = std::min(Bounce::kBytes, bytes - at);
+        hip_check(hipMemcpy(b.host, static_cast<const char*>(dev) + at, n, hipMemcpyDeviceToHost), what);
+        std::memcpy(static_cast<char*>(host) + at, b.host, n);
+    }
+}
+
+}  // namespace
 
 namespace {
 
@@ -63,8 +126,7 @@ void upload_table(const jinc::PlanePlan& p, DeviceTable& t, hipStream_t stream) 
     hip_check(hipMalloc(&t.blob, t.bytes), "hipMalloc(plan)");
     char* base = static_cast<char*>(t.blob);
     for (const Piece& pc : pieces)
-        if (pc.bytes) hip_check(hipMemcpyAsync(base + pc.offset, pc.host, pc.bytes, hipMemcpyHostToDevice, stream), "plan upload");
-    hip_check(hipStreamSynchronize(stream), "plan upload sync");
+        upload(base + pc.offset, pc.host, pc.bytes, "plan upload", stream);
 
     auto ptr_i = [&](size_t i) { return reinterpret_cast<const int32_t*>(base + pieces[i].offset); };
     t.plan.col_start = ptr_i(i_cs);
@@ -107,7 +169,7 @@ void attach_quad(DeviceTable& t, jinc::PeriodicArgs& pa, int FS, const std::vect
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, q.size() * sizeof(float)), "hipMalloc(quad coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table
-    hip_check(hipMemcpy(dev, q.data(), q.size() * sizeof(float), hipMemcpyHostToDevice), "quad coefficient upload");
+    upload(dev, q.data(), q.size() * sizeof(float), "quad coefficient upload");
     pa.quad = static_cast<const float*>(dev);
 }
 
@@ -155,7 +217,7 @@ void attach_rowpair(DeviceTable& t, jinc::PeriodicArgs& pa, int n, int ny, const
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, c.size() * sizeof(float)), "hipMalloc(row-pair coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table
-    hip_check(hipMemcpy(dev, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice), "row-pair coefficient upload");
+    upload(dev, c.data(), c.size() * sizeof(float), "row-pair coefficient upload");
     pa.rowpair = static_cast<const float*>(dev);
     pa.rowpair_n = n;
     pa.rowpair_ny = ny;
@@ -278,9 +340,8 @@ void trim_periodic(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sample
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, cut_bytes + row_trim.size() * sizeof(int32_t)), "hipMalloc(trimmed coefficient sets)");
     t.lane_blobs.push_back(dev);  // freed with the table
-    hip_check(hipMemcpy(dev, cut.data(), cut.size() * sizeof(float), hipMemcpyHostToDevice), "trimmed coefficient upload");
-    hip_check(hipMemcpy(static_cast<char*>(dev) + cut_bytes, row_trim.data(), row_trim.size() * sizeof(int32_t), hipMemcpyHostToDevice),
-              "row trim upload");
+    upload(dev, cut.data(), cut.size() * sizeof(float), "trimmed coefficient upload");
+    upload(static_cast<char*>(dev) + cut_bytes, row_trim.data(), row_trim.size() * sizeof(int32_t), "row trim upload");
     jinc::PeriodicArgs tr = pa;
     tr.coeffs = static_cast<const float*>(dev);
     tr.row_trim = reinterpret_cast<const int32_t*>(static_cast<char*>(dev) + cut_bytes);
@@ -489,8 +550,8 @@ void plan_runs(const jinc::PlanePlan& p, DeviceTable& t) {
     char* dev = nullptr;
     hip_check(hipMalloc(reinterpret_cast<void**>(&dev), run_bytes + item_bytes), "hipMalloc(direct runs)");
     t.lane_blobs.push_back(dev);  // freed with the table
-    hip_check(hipMemcpy(dev, runs.data(), run_bytes, hipMemcpyHostToDevice), "direct runs upload");
-    hip_check(hipMemcpy(dev + run_bytes, item_run.data(), item_bytes, hipMemcpyHostToDevice), "direct runs upload");
+    upload(dev, runs.data(), run_bytes, "direct runs upload");
+    upload(dev + run_bytes, item_run.data(), item_bytes, "direct runs upload");
     jinc::DirectArgs da;
     da.coeffs = t.plan.coeffs;
     da.fs = p.fs;
@@ -649,7 +710,7 @@ void plan_direct(const jinc::PlanePlan& p, DeviceTable& t) {
             void* dev = nullptr;
             hip_check(hipMalloc(&dev, sets.size() * sizeof(int32_t)), "hipMalloc(strip sets)");
             t.lane_blobs.push_back(dev);  // freed with the table
-            hip_check(hipMemcpy(dev, sets.data(), sets.size() * sizeof(int32_t), hipMemcpyHostToDevice), "strip set upload");
+            upload(dev, sets.data(), sets.size() * sizeof(int32_t), "strip set upload");
             sa.sets = static_cast<const int32_t*>(dev);
             return true;
         };
@@ -753,7 +814,7 @@ void plan_colpair(const jinc::PlanePlan& p, DeviceTable& t) {
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, blob.size() * sizeof(float)), "hipMalloc(column pair coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table
-    hip_check(hipMemcpy(dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice), "column pair coefficient upload");
+    upload(dev, blob.data(), blob.size() * sizeof(float), "column pair coefficient upload");
     ca.coeffs = static_cast<const float*>(dev);
     t.colpair = ca;
     t.use_colpair = true;
@@ -814,7 +875,7 @@ void plan_edge_columns(const jinc::PlanePlan& p, DeviceTable& t, bool integer_sa
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, blob.size() * sizeof(float)), "hipMalloc(edge column coefficients)");
     t.lane_blobs.push_back(dev);  // freed with the table
-    hip_check(hipMemcpy(dev, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice), "edge column coefficient upload");
+    upload(dev, blob.data(), blob.size() * sizeof(float), "edge column coefficient upload");
     e.coeffs = static_cast<const float*>(dev);
     t.edge_cols = e;
     t.use_edge_cols = true;
@@ -854,7 +915,7 @@ void trim_direct(const jinc::PlanePlan& p, DeviceTable& t, bool integer_samples)
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, cut.size() * sizeof(float)), "hipMalloc(trimmed coefficient sets of the direct kernel)");
     t.lane_blobs.push_back(dev);
-    hip_check(hipMemcpy(dev, cut.data(), cut.size() * sizeof(float), hipMemcpyHostToDevice), "trimmed coefficient upload");
+    upload(dev, cut.data(), cut.size() * sizeof(float), "trimmed coefficient upload");
     jinc::DirectArgs tr = da;
     tr.coeffs = static_cast<const float*>(dev) + slack_floats;
     tr.fs = n;
@@ -885,8 +946,14 @@ int buffer_range_check_covers_soffset(int device) {
         (void)hipFree(d);
         return -1;
     }
-    bool ok = hipMemcpy(d, h.data(), 2 * N, hipMemcpyHostToDevice) == hipSuccess &&
-              jinc::launch_soffset_probe(d, N, o, nullptr) == 0 && hipMemcpy(r.data(), o, 128 * 4, hipMemcpyDeviceToHost) == hipSuccess;
+    bool ok = true;
+    try {
+        upload(d, h.data(), 2 * N, "probe upload");
+        ok = jinc::launch_soffset_probe(d, N, o, nullptr) == 0;
+        if (ok) download(r.data(), o, 128 * 4, "probe download");
+    } catch (const std::exception&) {
+        ok = false;
+    }
     (void)hipFree(d);
     (void)hipFree(o);
     if (!ok) return -1;
@@ -953,8 +1020,7 @@ void attach_lane_coeffs(const jinc::PlanePlan& p, DeviceTable& t, jinc::RectList
     void* dev = nullptr;
     hip_check(hipMalloc(&dev, buf.size() * sizeof(float)), "hipMalloc(lane-major coefficients)");
     t.lane_blobs.push_back(dev);
-    hip_check(hipMemcpyAsync(dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, stream), "lane-major coefficient upload");
-    hip_check(hipStreamSynchronize(stream), "lane-major coefficient upload sync");
+    upload(dev, buf.data(), buf.size() * sizeof(float), "lane-major coefficient upload", stream);
     rects.lane_coeffs = static_cast<const float*>(dev);
 }
 

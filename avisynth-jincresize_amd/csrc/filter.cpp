@@ -129,7 +129,7 @@ int jinc_filter_set_pipeline_group(jinc_filter* f, int depth, int group, int reg
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        configure_pipeline(*f, depth, group, register_host_buffers < 0 ? 0 : register_host_buffers > 2 ? 2 : register_host_buffers);
+        configure_pipeline(*f, depth, group, register_host_buffers != 0 ? 2 : 0);
     });
 }
 

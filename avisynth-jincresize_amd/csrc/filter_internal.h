@@ -212,10 +212,10 @@ struct jinc_filter {
     int open_group = -1;      // index of the group being filled, -1: none
     int last_group = 0;       // most recently opened group (the ring advances from here)
     long long next_ticket = 0;
-    // How caller buffers travel: 1 (the default of a new instance) pinned by this library while their frame is in flight; 2 pinned
-    // and cached by address (a host with a frame pool); 0 handed to the HIP runtime as they are (pageable unless adopted) --
-    // see include/jincresize_hip.h for why 0 is no longer the default (the runtime's own cache of on-the-fly pins, keyed by address).
-    int register_host = 1;
+    // How caller buffers travel (include/jincresize_hip.h): 0 (the default) handed to the HIP runtime as they are -- the path every
+    // HIP application with pageable memory takes; 2 registered by this library and cached by address (register_host_buffers != 0:
+    // a host whose frame memory is a pool that stays mapped).
+    int register_host = 0;
     std::vector<jinc::host::PinnedRange> pinned;
     std::vector<jinc::host::FailedTickets> failed;  // groups whose launch failed and whose buffer has gone back into the ring
     unsigned long long pin_clock = 0;

@@ -410,10 +410,14 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
 // nullptr if the range could not be pinned (the frame then takes the DMA / pageable path -- not an error).  The cache
 // holds at least every range the frames in flight can reference (frames x planes x (src + dst)), and a range whose frame
 // may still be in flight is never unregistered under its transfer: its group is finished first.
-// Pin mode 1 (f.register_host == 1): no cache -- the registration is `transient`, held by the frames in flight that use it
-// (`fr`) and given back with the last of them (release_frame_pins), so that no registration outlives a buffer the host is
-// free to release once its frame's wait has returned.  Mode 2 keeps registrations cached by address (a host with a frame
-// pool that stays mapped); what a range costs to register again and again: profiles/round6/pin_modes.log.
+// Round 6 built and withdrew a second mode: `transient` registrations, made at submit, held by the frames in flight that use
+// the range (`fr`, GroupFrame::pins) and given back with the last of them (release_frame_pins) -- logically the safe form (no
+// registration outlives a buffer the host may release), and it passed every test of its own, buffers unmapped and mapped again
+// at the same addresses between frames included.  But a process that registers and unregisters host pages at frame rate saw
+// GPU memory access faults LATER, inside the runtime's own copies from pageable memory, in 4 of 9 full test runs, with no
+// registration of this library alive at the time (profiles/round6/README.md): whatever the unregister leaves behind in the
+// driver, it is the churn that provokes it.  The machinery stays (a frame's holds cost nothing while no range is transient);
+// register_host != 0 means cached registrations, as in rounds 3-5.
 char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket, GroupFrame* fr) {
     char* c = const_cast<char*>(static_cast<const char*>(p));
     auto hold = [&](PinnedRange& r) {  // the frame keeps a transient range alive until its transfers are over
@@ -440,7 +444,7 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
         return r.dev ? r.dev + (c - r.base) : nullptr;
     }
     if (!f.register_host) return nullptr;  // only ranges the caller pinned are known: this one is pageable
-    const bool transient = f.register_host == 1;
+    const bool transient = false;  // (round 6 tried registrations that live exactly as long as their frames -- see the note above pin_host_range)
     const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
     const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
     size_t own = 0;
@@ -621,8 +625,8 @@ void configure_pipeline(jinc_filter& f, int depth, int group, int register_host)
     f.groups.resize(ring);
     f.open_group = -1;
     f.last_group = 0;
-    f.register_host = std::max(0, std::min(2, register_host));
-    if (f.register_host != 2) {  // cached registrations go (the pipeline is drained: nothing holds a transient one); ranges the caller pinned stay known
+    f.register_host = register_host != 0 ? 2 : 0;
+    if (!f.register_host) {  // cached registrations go (the pipeline is drained); ranges the caller pinned stay known
         for (auto& p : f.pinned)
             if (!p.adopted) shared_pin_release(p.id);
         f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(), [](const PinnedRange& r) { return !r.adopted; }), f.pinned.end());

@@ -568,8 +568,8 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
 def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
     """Host planes in, host planes out through the look-ahead pipeline (jinc_filter_submit / _wait, one host thread,
     caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it.
-    pin_mode 2: registrations cached by address (this function's buffers live as long as the instance: a frame pool);
-    pin_mode 1: every plane registered at submit and given back at its frame's wait (safe with any host allocator)."""
+    pin_mode != 0: registrations cached by address (this function's buffers live as long as the instance: a frame pool);
+    0: the buffers go to the runtime as they are."""
     import numpy as np
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
     fmt = pkg.FORMATS[fmt_name]
@@ -609,7 +609,7 @@ def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
         f.wait(tickets.pop(0))
     el = time.perf_counter() - t0
     rec = {"what": "host planes -> jinc_filter_submit/_wait -> host planes, one host thread, buffers pinned in place; not `value`",
-           "pin_mode": {1: "1: pinned while the frame is in flight", 2: "2: pinned once, cached by address (frame pool)"}.get(pin_mode, str(pin_mode)),
+           "pin_mode": "pinned once, cached by address (frame pool)" if pin_mode else "pageable",
            "frames_per_s": round(n / el, 1), "Mpix_per_s": round(n / el * dw * dh / 1e6, 1),
            "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2), "frames_in_flight": depth, "frames_per_launch": f.pipeline_group,
            "kernel": kernel, "seconds": round(el, 2)}
@@ -657,7 +657,7 @@ def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32):
            "devices": G, "frames_per_s": round(n / el, 1), "frames_per_s_per_device": round(n / el / G, 1),
            "Mpix_per_s": round(n / el * dw * dh / 1e6, 1), "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2),
            "GB_per_s_per_link": round(n / el * frame_bytes / 1e9 / G, 2), "frames_in_flight_per_device": streams,
-           "frames_per_call": per_call, "calls": calls, "distinct_host_frames": nbuf, "pin_mode": "2: pinned once, kept until jinc_batch_free",
+           "frames_per_call": per_call, "calls": calls, "distinct_host_frames": nbuf, "pin_mode": "pinned once, kept until jinc_batch_free",
            "cpus_of_device": {str(d): (lambda c: f"{len(c)} CPUs ({c[0]}..{c[-1]})" if c else "unknown: not bound")(b.device_cpus(d)) for d in range(G)},
            "seconds": round(el, 2)}
     b.close()

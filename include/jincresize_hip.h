@@ -176,22 +176,20 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  * jinc_filter_flush.  group = 0 picks depth / 2 (depth >= 8; else 1): one group computes while the client collects
  * the previous one.  src and dst must stay valid and untouched until the frame's wait returns.  Frames are
  * independent, so neither grouping nor completion order changes results.
- * register_host_buffers: how the library treats the caller's plane buffers (a new instance starts in mode 1, also for
- * jinc_filter_get_frame) --
- *   0  handed to the HIP runtime as they are.  The pipeline works and the copies serialise on the host; but for pageable
- *      memory the runtime pins the range on the fly and KEEPS its last few pins per stream, found again by address and
- *      size: with a host allocator that returns freed frame memory to the kernel (glibc trims its heap) and hands the same
- *      addresses out again, such a kept pin maps pages that are gone -- seen in this repository's tests as a GPU memory
- *      access fault on a heap address inside a synchronous call that had registered nothing.  For hosts that know their
- *      frame memory never goes back to the kernel, and for planes inside adopted ranges;
- *   1  pinned (hipHostRegister) for exactly as long as their frame is in flight: registered at submit, given back when the
- *      frame's wait returns -- the copies are asynchronous, the results are written by the shader, and NO registration
- *      outlives a buffer the caller is free to release after the wait (safe with any allocator; costs a registration per
- *      plane and frame);
- *   2  pinned and CACHED by address range (least recently used out), no cost per frame once a buffer has been seen: for
- *      hosts whose frame memory is a pool that stays mapped.  The caller guarantees that such buffers stay allocated
- *      until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0 or 1): a cached registration that outlives its
- *      pages is a GPU mapping of memory that is gone, which the library cannot detect when the addresses come back.
+ * register_host_buffers: how the library treats the caller's plane buffers --
+ *   0 (a new instance's state)  handed to the HIP runtime as they are: the path every HIP application with pageable memory
+ *      takes.  The pipeline works and the copies serialise on the host;
+ *   != 0  registered once with hipHostRegister (exactly the plane's bytes) and CACHED by address range, least recently used out:
+ *      asynchronous copies, results written by the shader, no cost per frame once a buffer has been seen.  For hosts whose
+ *      frame memory is a pool that STAYS MAPPED: the caller guarantees that such buffers stay allocated until jinc_filter_free
+ *      or jinc_filter_set_pipeline(f, depth, 0).  The runtime consults its table of registered ranges for every host pointer it
+ *      is handed, so a registration that outlives its pages makes a later buffer at those addresses travel through a dead
+ *      mapping (a GPU memory access fault) or be refused (hipErrorInvalidValue when it starts inside the range and runs past
+ *      its end) -- and the library cannot see a range that came back at the same addresses.
+ *   Round 6 built, measured and withdrew a third mode (registered at submit, unregistered when the frame's wait returns: no
+ *   registration outlives a buffer the host may release; 4 508 C2 frames/s against 6 092 cached and 4 329 pageable): on this
+ *   ROCm build a process that registers and unregisters host pages at frame rate later saw GPU memory access faults inside the
+ *   RUNTIME's own copies from pageable memory, with no registration of this library alive.
  * A failed launch is reported by the submit that triggered it and by every wait on a frame of that group.
  * jinc_filter_get_frame == submit + wait (after draining frames still in flight). */
 JINC_API int jinc_filter_set_pipeline(jinc_filter *f, int depth, int register_host_buffers);
@@ -230,10 +228,10 @@ JINC_API int jinc_filter_sync(jinc_filter *f);
  * device holds a replica of the plan (one filter instance) and keeps `streams_per_device` (1..256) frames in flight
  * through the look-ahead pipeline above (frames coalesced into groups of streams_per_device / 2 per launch), driven by
  * one host thread per device.  No collective.
- * ndevices <= 0: all visible devices.  register_host_buffers: 0 pageable; 1 the planes of a jinc_batch_process call are
- * pinned for the duration of that call (by one registrar thread per device running ahead of the submissions; the caller may
- * free them afterwards); 2 they stay pinned until jinc_batch_free (a caller that re-uses its planes call after call and
- * keeps them allocated).  The worker and the registrar of device d run on the CPUs of d's NUMA node (sysfs numa_node of the
+ * ndevices <= 0: all visible devices.  register_host_buffers: 0 pageable; != 0 the planes of a jinc_batch_process call are
+ * pinned by one registrar thread per device running ahead of the submissions (exact byte ranges, planes that follow each
+ * other merged) and stay pinned until jinc_batch_free: the caller keeps them allocated until then (a caller that re-uses its
+ * planes call after call pays once).  The worker and the registrar of device d run on the CPUs of d's NUMA node (sysfs numa_node of the
  * device's PCI function); jinc_batch_set_affinity(b, 0) leaves the threads where the scheduler puts them.
  * jinc_batch_device_cpus: the CPUs found for the batch's device_index-th device (returns their number, 0 if unknown).
  * jinc_batch_process: src_planes / dst_planes hold 4 pointers per frame ([frame][plane], planes in the reference's

@@ -145,6 +145,7 @@ typedef enum jinc_knob {
     JINC_KNOB_EDGE_COLS,              /* 0: border columns on the border kernels even where ewa_periodic_quad2_kernel's edge tiles could compute them (round 5) */
     JINC_KNOB_ROWPAIR_ROWS,           /* 0: border rows of filter sizes 11 .. 17 at 2x on ewa_direct_kernel's row strips instead of ewa_periodic_rowpair_kernel launches (round 5) */
     JINC_KNOB_COLPAIR,                /* border columns on ewa_colpair_kernel: 0 never, 1 (default) wherever configured, 3 filter sizes from 11 on only (round 5) */
+    JINC_KNOB_UPLOAD_BOUNCE,          /* create-time table uploads: 1 (default) through the library's pinned buffer, 0 straight from the host vectors (round 6 A/B) */
     JINC_KNOB_COUNT
 } jinc_knob;
 JINC_API int jinc_debug_set_knob(int knob, double value);

@@ -72,7 +72,7 @@ struct Instance {
     int next_submit = 0;          // frames of the window below this one have been submitted
     int resubmit = -1;            // a frame of the window that was served already and is wanted again
     std::mutex mutex;             // look-ahead state (hosts that honour MT_SERIALIZED never contend for it)
-    int pin_frames = 1;           // JINCRESIZE_PIN_FRAMES: 1 (default) frame buffers pinned while their frame is in flight, 2 / "pool" pinned and cached by address, 0 left to the runtime
+    int pin_frames = 0;           // JINCRESIZE_PIN_FRAMES: 0 (default) buffers go to the runtime as they are; 1 / "pool": pinned once, cached by address
     std::string error;            // storage for fi->error
 };
 
@@ -360,17 +360,17 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
     }
     if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("JINCRESIZE_GROUP")) inst->group = std::max(0, std::min(inst->lookahead, std::atoi(e)));
-    // JINCRESIZE_PIN_FRAMES=1: the host's frame buffers are pinned in place while their frame is in flight (registered at
-    // submit, given back when the frame is served: safe whatever the host does with its frame memory afterwards);
-    // =pool (or 2): pinned once and cached by address -- for a host whose frame pool stays mapped.
+    // JINCRESIZE_PIN_FRAMES=1 (or "pool"): the host's frame buffers are pinned in place, once, and the registrations cached by
+    // address -- for a host whose frame pool stays mapped.  Unset / 0: the buffers go to the HIP
+    // runtime as they are.
     // Either way copies are asynchronous and results travel by the shader (process-wide registry in the library: the
     // instances of a script share the host's frames).
-    if (const char* e = std::getenv("JINCRESIZE_PIN_FRAMES")) inst->pin_frames = std::strcmp(e, "pool") == 0 ? 2 : std::max(0, std::min(2, std::atoi(e)));
+    if (const char* e = std::getenv("JINCRESIZE_PIN_FRAMES")) inst->pin_frames = (std::strcmp(e, "pool") == 0 || std::atoi(e) != 0) ? 2 : 0;
     if (inst->lookahead > 1) {
         if (jinc_filter_set_pipeline_group(filter, inst->lookahead, inst->group, inst->pin_frames) != JINC_OK) inst->lookahead = 1;
         inst->ring.resize(static_cast<size_t>(inst->lookahead));
     }
-    if (inst->lookahead == 1 && inst->pin_frames != 1) jinc_filter_set_pipeline(filter, 1, inst->pin_frames);  // (1 is the instance's default)
+    if (inst->lookahead == 1 && inst->pin_frames) jinc_filter_set_pipeline(filter, 1, inst->pin_frames);
 
     jinc_video_info out_vi;
     jinc_filter_output_info(filter, &out_vi);  // ref :791-792

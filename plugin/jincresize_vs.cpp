@@ -340,12 +340,12 @@ void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* c
     if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) d->lookahead = std::max(1, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("JINCRESIZE_GROUP")) d->group = std::max(0, std::min(d->lookahead, std::atoi(e)));
     const char* pin = std::getenv("JINCRESIZE_PIN_FRAMES");
-    const int pin_frames = !pin ? 1 : std::strcmp(pin, "pool") == 0 ? 2 : std::max(0, std::min(2, std::atoi(pin)));  // 1: while in flight; 2 / "pool": cached
+    const int pin_frames = !pin ? 0 : (std::strcmp(pin, "pool") == 0 || std::atoi(pin) != 0) ? 2 : 0;  // 1: while in flight; 2 / "pool": cached
     if (d->lookahead > 1) {
         if (jinc_filter_set_pipeline_group(filter, d->lookahead, d->group, pin_frames) != JINC_OK) d->lookahead = 1;
         d->ring.resize(static_cast<size_t>(d->lookahead));
     }
-    if (d->lookahead == 1 && pin_frames != 1) jinc_filter_set_pipeline(filter, 1, pin_frames);  // (1 is the instance's default)
+    if (d->lookahead == 1 && pin_frames) jinc_filter_set_pipeline(filter, 1, pin_frames);
     // depth 1: frame n of the output needs frame n of the input, nothing else; look-ahead asks for n .. n + depth - 1.
     // fmParallelRequests: arInitial from any thread, arAllFramesReady one call at a time (the instance is single-threaded).
     VSFilterDependency deps[1] = {{node, d->lookahead > 1 ? rpGeneral : rpStrictSpatial}};

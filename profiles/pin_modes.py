@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Host-to-host rate of one instance under the three ways of treating the caller's buffers (jinc_filter_set_pipeline's
-register_host_buffers: 0 pageable, 1 pinned while the frame is in flight, 2 pinned once and cached by address), C2 and two
-other plans, look-ahead 128 / 16 / 1.  Round 6 (VERDICT r5 Next 7): what the safe mode costs.  Output: one JSON line per point."""
+"""Host-to-host rate of one instance under the ways of treating the caller's buffers (jinc_filter_set_pipeline's
+register_host_buffers), C2 and two other plans, look-ahead 128 / 16 / 2.  Written in round 6 for THREE modes -- 0 pageable, 1 pinned
+while the frame is in flight, 2 pinned once and cached by address -- and run on the build that had all three
+(profiles/round6/pin_modes.log).  Mode 1 was withdrawn (registration churn: profiles/round6/README.md); on today's library every
+non-zero value means "cached", so the script's mode 1 rows repeat mode 2.  Output: one JSON line per point."""
 import json
 import os
 import sys

@@ -146,7 +146,7 @@ def test_no_environment_variable_steers_the_product(pkg):
         assert pkg.get_knob("quad_rg") == 8.0 and pkg.get_knob("fl_colw") == 0.25
     assert pkg.get_knob("quad_rg") is None and pkg.get_knob("fl_colw") is None
     env = {"JINC_QUAD_RG": "4", "JINC_PIPELINE_SKIP": "kernels", "JINC_UNRELATED": "1"}
-    assert pkg.apply_env_knobs(env) == {"quad_rg": 4.0, "pipeline_skip": 2.0}
+    assert pkg.apply_env_knobs(env) == {"quad_rg": 4.0, "pipeline_skip": 2.0, "unknown_variables": ["JINC_UNRELATED"]}  # (reported, not silently ignored: ADVICE r5)
     pkg.clear_knob()
     assert pkg.get_knob("quad_rg") is None
 
