@@ -323,11 +323,14 @@ class knobs:
 def apply_env_knobs(environ=None) -> dict:
     """Sets the knobs the environment names; JINC_* variables that name no knob are reported on stderr and returned under
     "unknown_variables" (a script that still sets a variable whose knob is gone measures A against A without a word).
-    JINC_LIB and JINC_BENCH_* belong to the loader and to bench.py."""
+    JINC_LIB, JINC_BENCH_* and the profiles/ scripts' own variables are not knobs by design."""
     environ = os.environ if environ is None else environ
     applied = {}
     known = {"JINC_" + n.upper() for n in knob_ids()}
-    unknown = sorted(k for k in environ if k.startswith("JINC_") and k not in known and k != "JINC_LIB" and not k.startswith("JINC_BENCH_"))
+    # (not knobs by design: the loader's JINC_LIB, bench.py's JINC_BENCH_*, the variables of the profiles/ scripts and of the tests)
+    own = ("JINC_LIB", "JINC_FRAMES_PER_LAUNCH")
+    own_prefixes = ("JINC_BENCH_", "JINC_PROFILE_", "JINC_LINE_", "JINC_TEST_")
+    unknown = sorted(k for k in environ if k.startswith("JINC_") and k not in known and k not in own and not k.startswith(own_prefixes))
     if unknown:
         import sys
         print("avisynth_jincresize_amd: environment variables that name no knob (ignored): " + ", ".join(unknown), file=sys.stderr, flush=True)
