@@ -116,11 +116,6 @@ struct GroupFrame {
     int dst_pitch[4] = {0, 0, 0, 0};
     long long ticket = -1;
     int done_event = -1;  // index into FrameGroup::done, set at launch
-    // Registrations this frame holds for as long as it is in flight (pin mode 1: jinc_filter_set_pipeline's
-    // register_host_buffers = 1): ids of the process-wide registry, one per plane buffer at most, given back when the frame's
-    // wait returns or its group is finished (pipeline.cpp release_frame_pins).
-    unsigned long long pins[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int npins = 0;
 };
 
 struct FrameGroup {
@@ -150,8 +145,6 @@ struct PinnedRange {  // a caller buffer registered with hipHostRegister (look-a
     unsigned long long stamp = 0;
     long long ticket = -1;  // latest frame whose copies use this range (may still be in flight)
     unsigned long long id = 0;  // the process-wide registry's entry this instance holds a reference to (0: adopted range)
-    int users = 0;              // frames in flight that hold this range (counted for `transient` ranges only)
-    bool transient = false;     // pin mode 1: the registration lives exactly as long as frames in flight use it
 };
 
 struct FailedTickets {  // a group whose launch failed: every wait on one of its frames reports `error`

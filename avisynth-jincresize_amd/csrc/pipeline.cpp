@@ -263,21 +263,6 @@ void ensure_group(jinc_filter& f, FrameGroup& g) {
     g.capacity = f.group_frames;
 }
 
-// Pin mode 1: the frame's transfers are over, so are its registrations -- unless another frame in flight holds the same range.
-void release_frame_pins(jinc_filter& f, GroupFrame& fr) {
-    for (int k = 0; k < fr.npins; ++k)
-        for (size_t i = 0; i < f.pinned.size(); ++i) {
-            PinnedRange& r = f.pinned[i];
-            if (r.adopted || r.id != fr.pins[k]) continue;
-            if (--r.users <= 0 && r.transient) {
-                shared_pin_release(r.id);
-                f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
-            }
-            break;
-        }
-    fr.npins = 0;
-}
-
 // The group's previous use is over: every frame of it complete (or failed), the buffer free for the next run of frames.
 void finish_group(jinc_filter& f, FrameGroup& g) {
     // Launched: the event of the group's last frame closes everything the group has queued (the departures belt is in
@@ -286,7 +271,6 @@ void finish_group(jinc_filter& f, FrameGroup& g) {
         hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames.back().done_event)]), "hipEventSynchronize(group done)");
     else if (g.state != FrameGroup::Idle && h2d_of(f, g))
         hip_check(hipStreamSynchronize(h2d_of(f, g)), "stream sync");
-    for (GroupFrame& fr : g.frames) release_frame_pins(f, fr);  // nothing of the group is on the wire any more
 }
 
 void retire_group(jinc_filter& f, FrameGroup& g) {
@@ -399,8 +383,6 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
         if (d2h_of(f, g)) (void)hipStreamSynchronize(d2h_of(f, g));
         g.state = FrameGroup::Failed;
         g.error = e.what();
-        if (h2d_of(f, g)) (void)hipStreamSynchronize(h2d_of(f, g));
-        for (GroupFrame& fr : g.frames) release_frame_pins(f, fr);
         throw;
     }
 }
@@ -410,41 +392,27 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
 // nullptr if the range could not be pinned (the frame then takes the DMA / pageable path -- not an error).  The cache
 // holds at least every range the frames in flight can reference (frames x planes x (src + dst)), and a range whose frame
 // may still be in flight is never unregistered under its transfer: its group is finished first.
-// Round 6 built and withdrew a second mode: `transient` registrations, made at submit, held by the frames in flight that use
-// the range (`fr`, GroupFrame::pins) and given back with the last of them (release_frame_pins) -- logically the safe form (no
-// registration outlives a buffer the host may release), and it passed every test of its own, buffers unmapped and mapped again
-// at the same addresses between frames included.  But a process that registers and unregisters host pages at frame rate saw
-// GPU memory access faults LATER, inside the runtime's own copies from pageable memory, in 4 of 9 full test runs, with no
-// registration of this library alive at the time (profiles/round6/README.md): whatever the unregister leaves behind in the
-// driver, it is the churn that provokes it.  The machinery stays (a frame's holds cost nothing while no range is transient);
-// register_host != 0 means cached registrations, as in rounds 3-5.
-char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket, GroupFrame* fr) {
+// Round 6 built and withdrew a second mode -- registrations made at submit, held by the frames in flight that use the range and
+// given back with the last of them: logically the safe form (no registration outlives a buffer the host may release), and it
+// passed every test of its own, buffers unmapped and mapped again at the same addresses between frames included.  But a process
+// that registers and unregisters host pages at frame rate saw GPU memory access faults LATER, inside the runtime's own copies from
+// pageable memory, in 4 of 9 full test runs, with no registration of this library alive at the time (profiles/round6/README.md;
+// the code: profiles/experiments/pin_while_in_flight.diff).  register_host != 0 means cached registrations, as in rounds 3-5.
+char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket) {
     char* c = const_cast<char*>(static_cast<const char*>(p));
-    auto hold = [&](PinnedRange& r) {  // the frame keeps a transient range alive until its transfers are over
-        if (!r.transient || !fr) return;
-        for (int k = 0; k < fr->npins; ++k)
-            if (fr->pins[k] == r.id) return;  // (two planes of the frame in one range: one hold)
-        if (fr->npins < 8) {
-            fr->pins[fr->npins++] = r.id;
-            ++r.users;
-        }
-    };
     for (size_t i = 0; i < f.pinned.size(); ++i) {
         PinnedRange& r = f.pinned[i];
         if (c < r.base || c + bytes > r.base + r.bytes) continue;
         if (!r.adopted && !shared_pin_alive(r.id)) {  // the registry found the range stale and let go of it: so does this instance
-            if (r.users > 0) return nullptr;          // (frames in flight still name it: they finish first; this plane goes pageable)
             shared_pin_release(r.id);
             f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
             break;
         }
         r.stamp = ++f.pin_clock;
         r.ticket = ticket;
-        hold(r);
         return r.dev ? r.dev + (c - r.base) : nullptr;
     }
     if (!f.register_host) return nullptr;  // only ranges the caller pinned are known: this one is pageable
-    const bool transient = false;  // (round 6 tried registrations that live exactly as long as their frames -- see the note above pin_host_range)
     const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
     const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
     size_t own = 0;
@@ -452,8 +420,7 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
     if (own >= capacity) {
         size_t lru = f.pinned.size();
         for (size_t i = 0; i < f.pinned.size(); ++i)
-            if (!f.pinned[i].adopted && f.pinned[i].users == 0 && (lru == f.pinned.size() || f.pinned[i].stamp < f.pinned[lru].stamp)) lru = i;
-        if (lru == f.pinned.size()) return nullptr;  // every range is held by a frame in flight: this plane goes pageable
+            if (!f.pinned[i].adopted && (lru == f.pinned.size() || f.pinned[i].stamp < f.pinned[lru].stamp)) lru = i;
         const long long lru_ticket = f.pinned[lru].ticket;
         const unsigned long long lru_id = f.pinned[lru].id;
         for (auto& g : f.groups)  // its transfers may still run (a group being filled has its H2D copies queued already)
@@ -462,7 +429,7 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
                     if (g.state == FrameGroup::Filling || g.state == FrameGroup::Launched) finish_group(f, g);
                     break;
                 }
-        for (size_t i = 0; i < f.pinned.size(); ++i)  // (finish_group may have let transient ranges go: look the entry up again)
+        for (size_t i = 0; i < f.pinned.size(); ++i)
             if (!f.pinned[i].adopted && f.pinned[i].id == lru_id) {
                 shared_pin_release(lru_id);
                 f.pinned.erase(f.pinned.begin() + static_cast<std::ptrdiff_t>(i));
@@ -478,10 +445,7 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
         (void)hipGetLastError();
         dev = nullptr;
     }
-    PinnedRange nr{base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket, id};
-    nr.transient = transient;
-    f.pinned.push_back(nr);
-    hold(f.pinned.back());
+    f.pinned.push_back({base, len, static_cast<char*>(dev), false, ++f.pin_clock, ticket, id});
     return dev ? static_cast<char*>(dev) + (c - base) : nullptr;
 }
 
@@ -658,26 +622,20 @@ long long submit_frame(jinc_filter& f, const void* const src[4], const int src_p
     const long long ticket = f.next_ticket;
     GroupFrame fr;
     fr.ticket = ticket;
-    try {
-        for (int i = 0; i < f.planecount; ++i) {
-            int sw, sh, dw, dh;
-            f.plane_dims(f.vi_in, i, sw, sh);
-            f.plane_dims(f.vi_out, i, dw, dh);
-            if (f.register_host || !f.pinned.empty()) {
-                (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket, &fr);
-                fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket, &fr);
-            }
-            if (debug_skip() != 1)
-                hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
-                                           static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
-                          "H2D copy");
-            fr.dst[i] = dst[i];
-            fr.dst_pitch[i] = dst_pitch[i];
+    for (int i = 0; i < f.planecount; ++i) {
+        int sw, sh, dw, dh;
+        f.plane_dims(f.vi_in, i, sw, sh);
+        f.plane_dims(f.vi_out, i, dw, dh);
+        if (f.register_host || !f.pinned.empty()) {
+            (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket);
+            fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket);
         }
-    } catch (...) {  // the frame never joined its group: what it queued must be off the wire before its registrations go
-        if (h2d_of(f, g)) (void)hipStreamSynchronize(h2d_of(f, g));
-        release_frame_pins(f, fr);
-        throw;
+        if (debug_skip() != 1)
+            hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
+                                       static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
+                      "H2D copy");
+        fr.dst[i] = dst[i];
+        fr.dst_pitch[i] = dst_pitch[i];
     }
     g.frames.push_back(fr);
     ++f.next_ticket;
@@ -690,12 +648,8 @@ void wait_frame(jinc_filter& f, long long ticket) {
         for (size_t k = 0; k < g.frames.size(); ++k) {
             if (g.frames[k].ticket != ticket) continue;
             if (g.state == FrameGroup::Filling) launch_group(f, g);  // the client wants this frame now: no more company
-            if (g.state == FrameGroup::Failed) {
-                release_frame_pins(f, g.frames[k]);  // (the failed launch synchronised the group's streams)
-                throw HipError(g.error);
-            }
+            if (g.state == FrameGroup::Failed) throw HipError(g.error);
             hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames[k].done_event)]), "hipEventSynchronize(frame done)");
-            release_frame_pins(f, g.frames[k]);  // pin mode 1: the caller may free the frame's buffers from here on
             return;
         }
     }
