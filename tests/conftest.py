@@ -24,8 +24,8 @@ except Exception:  # pragma: no cover
 # kernel and hand the addresses out again.  The product's answer: buffers go to the runtime as they are by default (mode 0, the
 # path every HIP application takes), pinning is for hosts whose frame memory stays mapped, tables are
 # uploaded through a pinned buffer of the library's own.  The tests' answer is this model of such a host, process-wide, because
-# ONE process runs the pinning tests and 1 600 others: nothing malloc hands out goes back to the kernel.
-# tests/test_pin_modes.py unmaps and maps its planes itself (mmap), which these options do not touch.
+# ONE process runs the pinning tests and 1 600 others: nothing malloc hands out goes back to the kernel.  (Mode 1 was withdrawn
+# with the tests that unmapped and re-mapped their planes under it; the diff is profiles/experiments/pin_while_in_flight.diff.)
 try:
     import ctypes
     _libc = ctypes.CDLL(None)
