@@ -81,7 +81,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_chroma_location", "jinc_filter_set_chroma_location_mode", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_runs", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_debug_staged_frames", "jinc_debug_copy_rows", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_filter_release_host_range", "jinc_batch_set_affinity", "jinc_batch_device_cpus", "jinc_debug_numa_cpus", "jinc_debug_batch_set_registrars", "jinc_debug_batch_refused", "jinc_debug_host_registrations", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error",
@@ -160,6 +160,9 @@ def lib():
         L.jinc_filter_periodic_taps.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.jinc_filter_periodic_taps.restype = C.c_double
         L.jinc_debug_transport_counts.argtypes = [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]
+        L.jinc_debug_staged_frames.restype = C.c_longlong
+        L.jinc_debug_copy_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+        L.jinc_debug_staged_frames.argtypes = []
         L.jinc_shard_device.argtypes = [C.c_int, C.c_int]
         L.jinc_batch_create.argtypes = [C.POINTER(VideoInfo), C.POINTER(Args), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                         C.c_char_p, C.c_size_t]
@@ -222,6 +225,19 @@ def transport_counts(reset: bool = False) -> Tuple[int, int, int]:
     a, b, c = C.c_longlong(), C.c_longlong(), C.c_longlong()
     lib().jinc_debug_transport_counts(C.byref(a), C.byref(b), C.byref(c), int(reset))
     return a.value, b.value, c.value
+
+
+def copy_rows(dst: np.ndarray, src: np.ndarray, row_bytes: int, rows: int, helpers: bool = True) -> None:
+    """host_copy.cpp's plane copy between two 2-D arrays (test header; no device needed)."""
+    rc = lib().jinc_debug_copy_rows(dst.ctypes.data, dst.strides[0], src.ctypes.data, src.strides[0], int(row_bytes), int(rows), int(helpers))
+    if rc != 0:
+        raise JincError(rc, lib().jinc_last_error().decode())
+
+
+def staged_frames() -> int:
+    """Frames whose planes went through the library's own pinned buffers (register_host_buffers = 0) since the last reset of
+    transport_counts."""
+    return int(lib().jinc_debug_staged_frames())
 
 
 def host_registrations() -> int:
@@ -473,7 +489,10 @@ def _build_args(fmt, width, height, target_width, target_height, frame0_chroma_l
     return vi, a, keep
 
 
-PIN_NONE, PIN_POOL = 0, 2   # register_host_buffers of set_pipeline / Batch (include/jincresize_hip.h): pageable / registered once and cached (any non-zero value)
+# register_host_buffers of set_pipeline / Batch (include/jincresize_hip.h): pageable planes copied by the CPU through pinned buffers of
+# the library's own (the default) / registered once and cached (any other non-zero value) / pageable planes handed to the HIP runtime
+# as they are (which maps them into the device itself behind every copy)
+PIN_NONE, PIN_POOL, PIN_RUNTIME = 0, 2, 3
 
 
 def numa_cpus(sysfs_root: str, bdf: str) -> List[int]:
@@ -629,8 +648,8 @@ class Filter:
     # -- look-ahead pipeline: several frames in flight per instance --
     def set_pipeline(self, depth: int, register_host_buffers: int = 0, group: int = 0) -> None:
         """Up to `depth` frames in flight; `group` of them coalesced into one launch (0: automatic = depth / 2).
-        register_host_buffers: PIN_NONE (0 / False) or PIN_POOL (non-zero / True: pinned once and cached by address; the caller keeps
-        the buffers allocated)."""
+        register_host_buffers: PIN_NONE (0 / False: the CPU copies the planes through the library's pinned buffers), PIN_POOL (non-zero /
+        True: pinned once and cached by address; the caller keeps the buffers allocated) or PIN_RUNTIME (3: handed to the runtime)."""
         self._check(lib().jinc_filter_set_pipeline_group(self._h, int(depth), int(group), int(register_host_buffers)))
 
     @property

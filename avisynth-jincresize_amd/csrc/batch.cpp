@@ -21,7 +21,6 @@
 // _flush / _wait) and hipHostRegister only.
 #include <hip/hip_runtime_api.h>
 #include <sched.h>
-#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -50,7 +49,7 @@ struct jinc_batch {
     std::vector<int> devices;
     int streams = 2;
     int planes = 0;
-    int register_host = 0;  // 0: pageable; 2: the calls' planes are pinned and stay so until jinc_batch_free (1, pinned for the duration of a call, was built and withdrawn in round 6: registration churn, see pipeline.cpp pin_host_range)
+    int register_host = 0;  // 0: pageable planes, copied by the CPU through the instances' own pinned buffers; 3: pageable planes handed to the HIP runtime as they are; 2: the calls' planes are pinned and stay so until jinc_batch_free (1, pinned for the duration of a call, was built and withdrawn in round 6: registration churn, see pipeline.cpp pin_host_range)
     bool affinity = true;   // workers and registrars of device d run on the CPUs of d's NUMA node
     int registrars = 0;     // 0: one per device; > 0: that many (test header: several registrars on a one-device box)
     std::atomic<int> refused{0};  // ranges hipHostRegister would not take (their planes travel pageable), since creation
@@ -211,12 +210,12 @@ int jinc_batch_create(const jinc_video_info* vi, const jinc_args* args, int ndev
     if (!b) return batch_fail(JINC_ERR_NOMEM, "JincResize: out of memory.");
     b->streams = streams_per_device;
     b->planes = vi->num_components;
-    b->register_host = register_host_buffers != 0 ? 2 : 0;
+    b->register_host = register_host_buffers == 0 || register_host_buffers == 3 ? register_host_buffers : 2;
     b->vi_in = *vi;
     for (int d = 0; d < ndevices; ++d) {
         jinc_filter* f = nullptr;
         int rc = jinc_filter_create(vi, args, d, &f, err, err_len);
-        if (rc == JINC_OK) rc = jinc_filter_set_pipeline(f, streams_per_device, 0);  // host memory is pinned here, not per instance
+        if (rc == JINC_OK) rc = jinc_filter_set_pipeline(f, streams_per_device, b->register_host == 3 ? 3 : 0);  // host memory is pinned here, not per instance
         if (rc != JINC_OK) {
             if (f) {
                 if (err && err_len) {
@@ -312,7 +311,7 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
     std::string first_error;
 
     // Registrars: one per device, chunk c belongs to registrar c mod R; chunk_done[c]: pinned and its ranges recorded.
-    const int nchunks = b->register_host ? (nframes + kPinChunk - 1) / kPinChunk : 0;
+    const int nchunks = b->register_host == 2 ? (nframes + kPinChunk - 1) / kPinChunk : 0;
     const int R = std::min(b->registrars > 0 ? b->registrars : G, nchunks);
     std::mutex chunk_mutex;
     std::condition_variable chunk_cv;
@@ -322,6 +321,11 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
     // must not depend on the order the threads get going); the registrars only make the expensive calls side by side.  Every
     // plane of chunk c lies inside one range of chunk c (or of an earlier chunk that already contains it), which the worker has
     // adopted by the time it submits the plane's frame.
+    std::vector<HostRange> known_before;  // what earlier calls registered (this call's claims are adopted chunk by chunk, once they ARE registered)
+    if (nchunks > 0) {
+        std::lock_guard<std::mutex> lock(b->pin_mutex);
+        known_before = b->pinned;
+    }
     std::vector<std::vector<HostRange>> chunk_todo(static_cast<size_t>(nchunks));
     for (int c = 0; c < nchunks; ++c)
         chunk_todo[static_cast<size_t>(c)] =
@@ -406,14 +410,7 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
             return rc;
         };
         int rc = JINC_OK, adopted_chunks = 0;
-        if (nchunks > 0) {  // ranges pinned by earlier calls
-            std::vector<HostRange> known;
-            {
-                std::lock_guard<std::mutex> lock(b->pin_mutex);
-                known = b->pinned;
-            }
-            for (const HostRange& r : known) (void)jinc_filter_adopt_host_range(f, r.base, r.bytes);
-        }
+        for (const HostRange& r : known_before) (void)jinc_filter_adopt_host_range(f, r.base, r.bytes);  // ranges pinned by earlier calls
         for (int n = d; n < nframes && rc == JINC_OK && status.load() == JINC_OK; n += G) {  // jinc_shard_device(n, G) == d
             if (nchunks > 0 && n / kPinChunk >= adopted_chunks) {  // the frame's planes have to be pinned and known to this instance
                 std::unique_lock<std::mutex> lock(chunk_mutex);

@@ -129,7 +129,7 @@ int jinc_filter_set_pipeline_group(jinc_filter* f, int depth, int group, int reg
     if (f->device < 0) return fail(JINC_ERR_NO_DEVICE, "JincResize: filter was created without a HIP device (device < 0).");
     return guarded([&] {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
-        configure_pipeline(*f, depth, group, register_host_buffers != 0 ? 2 : 0);
+        configure_pipeline(*f, depth, group, register_host_buffers);  // 0 staged, 3 the runtime's own mapping, anything else cached registrations
     });
 }
 
@@ -165,6 +165,14 @@ int jinc_filter_release_host_range(jinc_filter* f, void* base, size_t bytes) {
         hip_check(hipSetDevice(f->device), "hipSetDevice");
         release_host_range(*f, base, bytes);
     });
+}
+
+long long jinc_debug_staged_frames(void) { return staged_frames(); }
+
+int jinc_debug_copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes, int rows, int may_use_helpers) {
+    if (!dst || !src || rows < 0 || dst_pitch < row_bytes || src_pitch < row_bytes) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad copy.");
+    copy_plane_rows(static_cast<char*>(dst), dst_pitch, static_cast<const char*>(src), src_pitch, row_bytes, rows, may_use_helpers != 0);
+    return JINC_OK;
 }
 
 int jinc_debug_transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, int reset) {

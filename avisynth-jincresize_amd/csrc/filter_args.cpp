@@ -61,6 +61,7 @@ void configure(jinc_filter& f, const jinc_video_info& vi, const jinc_args& a) {
 
     const int threads = has(JINC_ARG_THREADS) ? a.threads : 0;
     if (threads < 0 || threads > 1) throw ArgError("JincResize: threads must be either 0 or 1.");
+    f.copy_helpers = threads != 1;  // the reference: 1 = this thread only, 0 = every core (ref :901); here: the copies of pageable planes
 
     double crop_left = has(JINC_ARG_SRC_LEFT) ? a.src_left : 0.0;
     double crop_width = has(JINC_ARG_SRC_WIDTH) ? a.src_width : static_cast<double>(vi.width);

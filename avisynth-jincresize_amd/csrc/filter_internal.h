@@ -116,6 +116,16 @@ struct GroupFrame {
     int dst_pitch[4] = {0, 0, 0, 0};
     long long ticket = -1;
     int done_event = -1;  // index into FrameGroup::done, set at launch
+    // Planes (bit i) whose result goes to the group's OWN pinned host buffer and is copied into dst[i] by the CPU once the frame's
+    // event has fired (deliver_frame): the caller's memory is pageable and the GPU never maps it (register_host == 0).
+    unsigned staged_out = 0;
+    bool delivered = false;
+    // A frame that travels alone (a group of one: jinc_filter_get_frame): its staged result planes leave the device in row bands,
+    // an event behind each, and the CPU copies a band out while the next ones are still on the wire.
+    struct Band {
+        int plane, y0, y1, event;  // rows [y0, y1) of `plane`, complete when FrameGroup::band_done[event] has fired
+    };
+    std::vector<Band> bands;
 };
 
 struct FrameGroup {
@@ -131,6 +141,12 @@ struct FrameGroup {
     hipStream_t own_stream = nullptr;  // small groups: everything of the group in order on this stream
     hipEvent_t h2d_ready = nullptr, kernels_done = nullptr;
     jinc::BlitEntry* table = nullptr;  // [capacity x planes], pinned host memory the device reads (hipHostMalloc)
+    // Pinned host buffers of the library's own (hipHostMalloc, allocated when the first pageable plane arrives), laid out like
+    // src_base / dst_base: pageable planes are copied through them by the CPU, so that no mapping of the CALLER's pages ever
+    // exists on the device -- neither one of this library nor one the HIP runtime makes behind a copy from pageable memory.
+    char* host_src = nullptr;
+    char* host_dst = nullptr;
+    std::vector<hipEvent_t> band_done;  // groups of one frame: events of GroupFrame::bands (created with the first banded frame)
     std::vector<hipEvent_t> done;    // [capacity]
     std::vector<GroupFrame> frames;  // frames of the current use of the buffer, in submission order
     enum State { Idle, Filling, Launched, Failed } state = Idle;
@@ -205,10 +221,12 @@ struct jinc_filter {
     int open_group = -1;      // index of the group being filled, -1: none
     int last_group = 0;       // most recently opened group (the ring advances from here)
     long long next_ticket = 0;
-    // How caller buffers travel (include/jincresize_hip.h): 0 (the default) handed to the HIP runtime as they are -- the path every
-    // HIP application with pageable memory takes; 2 registered by this library and cached by address (register_host_buffers != 0:
-    // a host whose frame memory is a pool that stays mapped).
+    // How caller buffers travel (include/jincresize_hip.h): 0 (the default) copied by the CPU through pinned buffers of the
+    // library's own -- the device never maps the caller's pages; 2 registered by this library and cached by address (a host whose
+    // frame memory is a pool that stays mapped); 3 handed to the HIP runtime as they are (which maps the caller's pages itself
+    // behind every copy: the default of rounds 1 - 5).
     int register_host = 0;
+    bool copy_helpers = true;  // pageable planes may be copied by the helper threads of host_copy.cpp (the script's threads != 1)
     std::vector<jinc::host::PinnedRange> pinned;
     std::vector<jinc::host::FailedTickets> failed;  // groups whose launch failed and whose buffer has gone back into the ring
     unsigned long long pin_clock = 0;
@@ -276,7 +294,7 @@ const char* last_interior_kernel_in_process();
 int last_call_frames_in_process();
 const char* last_interior_instance_in_process();
 // pipeline.cpp: frames in flight on one instance
-void configure_pipeline(jinc_filter& f, int depth, int group, int register_host);  // drains first; register_host: 0 / 1 / 2 as jinc_filter::register_host
+void configure_pipeline(jinc_filter& f, int depth, int group, int register_host);  // drains first; register_host: 0 / 2 / 3 as jinc_filter::register_host
 long long submit_frame(jinc_filter& f, const void* const src[4], const int src_pitch[4], void* const dst[4], const int dst_pitch[4]);
 void wait_frame(jinc_filter& f, long long ticket);  // flushes the open group if the frame is in it
 void adopt_host_range(jinc_filter& f, void* base, size_t bytes);  // caller-pinned memory: usable for async copies and shader transport
@@ -284,6 +302,10 @@ void release_host_range(jinc_filter& f, void* base, size_t bytes);  // the calle
 void launch_open_group(jinc_filter& f);             // the frames submitted so far leave now (a client that knows no more are coming)
 void drain_pipeline(jinc_filter& f);                // every submitted frame complete
 void transport_counts(long long* by_shader, long long* by_dma, long long* pinned_ranges, bool reset);  // process-wide (test header)
+// host_copy.cpp: rows between a pageable plane and a pinned buffer of the library's own; large planes are cut into row ranges for the
+// process-wide helper threads when may_use_helpers (the calling thread always takes part and returns when every row has been copied).
+void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t row_bytes, int rows, bool may_use_helpers);
+long long staged_frames();  // frames whose results went through the library's own pinned buffers since the last reset of transport_counts
 
 }  // namespace host
 }  // namespace jinc

@@ -74,6 +74,7 @@ void quiesce_devices(unsigned long long mask) {
     (void)hipGetLastError();
 }
 std::atomic<long long> g_frames_by_shader{0}, g_frames_by_dma{0};  // how results left the device, process-wide (test header)
+std::atomic<long long> g_frames_staged{0};  // frames whose results went through the library's own pinned buffers (register_host == 0)
 
 // A reference to a live registered range that contains [c, c + bytes), registering it if need be; false: not pinnable.
 // STALE registrations (pin mode 2 only: mode 1 lets go of a range with its last frame in flight): the host may free memory
@@ -186,6 +187,11 @@ void release_group(FrameGroup& g) {  // (the belts are idle: callers drain first
     g.done.clear();
     if (g.table) (void)hipHostFree(g.table);
     g.table = nullptr;
+    for (hipEvent_t e : g.band_done) (void)hipEventDestroy(e);
+    g.band_done.clear();
+    if (g.host_src) (void)hipHostFree(g.host_src);
+    if (g.host_dst) (void)hipHostFree(g.host_dst);
+    g.host_src = g.host_dst = nullptr;
     if (g.own_stream) (void)hipStreamDestroy(g.own_stream);
     g.own_stream = nullptr;
     for (hipEvent_t* e : {&g.h2d_ready, &g.kernels_done}) {
@@ -263,13 +269,74 @@ void ensure_group(jinc_filter& f, FrameGroup& g) {
     g.capacity = f.group_frames;
 }
 
+// ---- Pageable planes: through pinned buffers of the library's own ---------------------------------------------------
+// The default (register_host == 0).  Rounds 1 - 5 handed pageable planes to hipMemcpy2DAsync as they were; the runtime maps the
+// caller's pages into the device behind such a copy (2 MB in 46 us = 45 GB/s from "pageable" memory, first touch 77 - 126 us:
+// profiles/round6/pageable_rect_copy_probe.log) and the copy engine or a blit kernel reads them in place.  Full test runs of
+// round 6 ended in GPU memory access faults on HEAP addresses inside exactly those copies (5 of 13 runs, each time with no
+// registration of this library alive; profiles/round6/README.md), under every allocator setting tried, and the cause could not
+// be isolated (the probe's unmap / remap / register-over-it / many-streams scenarios all pass).  A library a video host loads
+// must not be able to take the host down with a GPU fault, so by default the device never sees the caller's pages at all:
+// the CPU copies source rows into host_src at submit and result rows out of host_dst once the frame's event has fired; the
+// DMA engines move whole contiguous planes between these buffers and the group's device buffers.  The price is the CPU's copy
+// rate; hosts that want the link's rate pin their frame memory (modes 2 / adopt_host_range) or accept the runtime's mapping (3).
+void ensure_host_staging(jinc_filter& f, FrameGroup& g) {
+    if (g.host_src && g.host_dst) return;
+    const size_t cap = static_cast<size_t>(g.capacity);
+    size_t src_total = 0, dst_total = 0;
+    for (int i = 0; i < f.planecount; ++i) src_total += g.src_fs[i] * cap, dst_total += g.dst_fs[i] * cap;
+    if (!g.host_src) hip_check(hipHostMalloc(reinterpret_cast<void**>(&g.host_src), src_total, hipHostMallocDefault), "hipHostMalloc(source planes of a frame group)");
+    if (!g.host_dst) hip_check(hipHostMalloc(reinterpret_cast<void**>(&g.host_dst), dst_total, hipHostMallocDefault), "hipHostMalloc(result planes of a frame group)");
+}
+
+char* host_src_plane(const FrameGroup& g, int i, size_t k) {
+    return g.host_src + (static_cast<const char*>(g.src[i]) - static_cast<const char*>(g.src_base)) + g.src_fs[i] * k;
+}
+char* host_dst_plane(const FrameGroup& g, int i, size_t k) {
+    return g.host_dst + (static_cast<const char*>(g.dst[i]) - static_cast<const char*>(g.dst_base)) + g.dst_fs[i] * k;
+}
+
+// The frame's event has fired: its staged result planes go to the caller's planes (once).
+void deliver_frame(jinc_filter& f, FrameGroup& g, size_t k) {
+    GroupFrame& fr = g.frames[k];
+    if (fr.delivered) return;
+    fr.delivered = true;
+    const int sb = f.vi_in.component_size;
+    if (!fr.bands.empty()) {  // (a frame that travelled alone: band by band, behind each band's event)
+        for (const GroupFrame::Band& b : fr.bands) {
+            hip_check(hipEventSynchronize(g.band_done[static_cast<size_t>(b.event)]), "hipEventSynchronize(band done)");
+            int dw, dh;
+            f.plane_dims(f.vi_out, b.plane, dw, dh);
+            copy_plane_rows(static_cast<char*>(fr.dst[b.plane]) + static_cast<size_t>(fr.dst_pitch[b.plane]) * b.y0, static_cast<size_t>(fr.dst_pitch[b.plane]),
+                            host_dst_plane(g, b.plane, k) + static_cast<size_t>(g.dst_pitch[b.plane]) * b.y0, static_cast<size_t>(g.dst_pitch[b.plane]),
+                            static_cast<size_t>(dw) * sb, b.y1 - b.y0, f.copy_helpers);
+        }
+        return;
+    }
+    for (int i = 0; i < f.planecount; ++i) {
+        if (!((fr.staged_out >> i) & 1)) continue;
+        int dw, dh;
+        f.plane_dims(f.vi_out, i, dw, dh);
+        copy_plane_rows(static_cast<char*>(fr.dst[i]), static_cast<size_t>(fr.dst_pitch[i]), host_dst_plane(g, i, k),
+                        static_cast<size_t>(g.dst_pitch[i]), static_cast<size_t>(dw) * sb, dh, f.copy_helpers);
+    }
+}
+
+// Row bands a staged plane of `bytes` bytes is cut into on its way between the CPU's copy and the DMA engine, so that one works
+// while the other does (2 MiB per band, at most 4; A/B knob STAGE_BANDS, 1 = whole planes).
+int stage_bands(size_t bytes, int rows) {
+    const int most = std::max(1, knobs::geti(JINC_KNOB_STAGE_BANDS, 4));
+    return static_cast<int>(std::max<size_t>(1, std::min<size_t>({static_cast<size_t>(most), bytes >> 21, static_cast<size_t>(std::max(rows, 1))})));
+}
+
 // The group's previous use is over: every frame of it complete (or failed), the buffer free for the next run of frames.
 void finish_group(jinc_filter& f, FrameGroup& g) {
     // Launched: the event of the group's last frame closes everything the group has queued (the departures belt is in
     // order).  Filling / Failed: its arrivals may still be on the wire.
-    if (g.state == FrameGroup::Launched && !g.frames.empty())
+    if (g.state == FrameGroup::Launched && !g.frames.empty()) {
         hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames.back().done_event)]), "hipEventSynchronize(group done)");
-    else if (g.state != FrameGroup::Idle && h2d_of(f, g))
+        for (size_t k = 0; k < g.frames.size(); ++k) deliver_frame(f, g, k);  // frames nobody waited for arrive all the same
+    } else if (g.state != FrameGroup::Idle && h2d_of(f, g))
         hip_check(hipStreamSynchronize(h2d_of(f, g)), "stream sync");
 }
 
@@ -362,18 +429,70 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
             }
             g_frames_by_shader += n;
         } else {
-            g_frames_by_dma += n;
-            for (int k = 0; k < n; ++k) {
-                GroupFrame& fr = g.frames[static_cast<size_t>(k)];
+            const unsigned every_plane = (1u << planes) - 1;
+            bool all_staged = true;
+            for (const GroupFrame& fr : g.frames) all_staged &= fr.staged_out == every_plane;
+            if (all_staged && n == 1) {
+                // a frame that travels alone: row bands with an event each (deliver_frame copies band j out while band j + 1 arrives)
+                GroupFrame& fr = g.frames[0];
+                fr.bands.clear();
                 for (int i = 0; i < planes; ++i) {
                     int dw, dh;
                     f.plane_dims(f.vi_out, i, dw, dh);
-                    hip_check(hipMemcpy2DAsync(fr.dst[i], fr.dst_pitch[i], static_cast<const char*>(g.dst[i]) + g.dst_fs[i] * k, g.dst_pitch[i],
-                                               static_cast<size_t>(dw) * sb, dh, hipMemcpyDeviceToHost, d2h),
-                              "D2H copy");
+                    const int nb = stage_bands(static_cast<size_t>(g.dst_pitch[i]) * dh, dh);
+                    for (int b = 0; b < nb; ++b) {
+                        const int y0 = dh * b / nb, y1 = dh * (b + 1) / nb;
+                        const size_t off = static_cast<size_t>(g.dst_pitch[i]) * y0;
+                        hip_check(hipMemcpyAsync(host_dst_plane(g, i, 0) + off, static_cast<const char*>(g.dst[i]) + off,
+                                                 static_cast<size_t>(g.dst_pitch[i]) * (y1 - y0), hipMemcpyDeviceToHost, d2h),
+                                  "D2H copy (staged band)");
+                        const size_t e = fr.bands.size();
+                        while (g.band_done.size() <= e) {
+                            hipEvent_t ev = nullptr;
+                            hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+                            g.band_done.push_back(ev);
+                        }
+                        hip_check(hipEventRecord(g.band_done[e], d2h), "hipEventRecord(band done)");
+                        fr.bands.push_back({i, y0, y1, static_cast<int>(e)});
+                    }
                 }
-                hip_check(hipEventRecord(g.done[static_cast<size_t>(k)], d2h), "hipEventRecord(frame done)");
-                fr.done_event = k;
+                hip_check(hipEventRecord(g.done[0], d2h), "hipEventRecord(frame done)");
+                fr.done_event = 0;
+                g_frames_staged += 1;
+            } else if (all_staged) {
+                // every result plane of the group goes to the library's own pinned buffer, which is laid out like the device
+                // buffer: one contiguous DMA copy per plane and share of the group, one event per share
+                const int shares = std::min(n, group_shares());
+                for (int s = 0; s < shares; ++s) {
+                    const int k0 = n * s / shares, k1 = n * (s + 1) / shares;
+                    for (int i = 0; i < planes; ++i)
+                        hip_check(hipMemcpyAsync(host_dst_plane(g, i, static_cast<size_t>(k0)), static_cast<const char*>(g.dst[i]) + g.dst_fs[i] * k0,
+                                                 g.dst_fs[i] * static_cast<size_t>(k1 - k0), hipMemcpyDeviceToHost, d2h),
+                                  "D2H copy (staged)");
+                    hip_check(hipEventRecord(g.done[static_cast<size_t>(s)], d2h), "hipEventRecord(share done)");
+                    for (int k = k0; k < k1; ++k) g.frames[static_cast<size_t>(k)].done_event = s;
+                }
+                g_frames_staged += n;
+            } else {
+                for (int k = 0; k < n; ++k) {
+                    GroupFrame& fr = g.frames[static_cast<size_t>(k)];
+                    for (int i = 0; i < planes; ++i) {
+                        int dw, dh;
+                        f.plane_dims(f.vi_out, i, dw, dh);
+                        const char* from = static_cast<const char*>(g.dst[i]) + g.dst_fs[i] * k;
+                        if ((fr.staged_out >> i) & 1)
+                            hip_check(hipMemcpyAsync(host_dst_plane(g, i, static_cast<size_t>(k)), from, static_cast<size_t>(g.dst_pitch[i]) * dh,
+                                                     hipMemcpyDeviceToHost, d2h),
+                                      "D2H copy (staged)");
+                        else  // registered by the host or by this library, or mode 3: the runtime's business
+                            hip_check(hipMemcpy2DAsync(fr.dst[i], fr.dst_pitch[i], from, g.dst_pitch[i], static_cast<size_t>(dw) * sb, dh,
+                                                       hipMemcpyDeviceToHost, d2h),
+                                      "D2H copy");
+                    }
+                    hip_check(hipEventRecord(g.done[static_cast<size_t>(k)], d2h), "hipEventRecord(frame done)");
+                    fr.done_event = k;
+                    (fr.staged_out ? g_frames_staged : g_frames_by_dma) += 1;
+                }
             }
         }
         g.state = FrameGroup::Launched;
@@ -412,7 +531,7 @@ char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long tick
         r.ticket = ticket;
         return r.dev ? r.dev + (c - r.base) : nullptr;
     }
-    if (!f.register_host) return nullptr;  // only ranges the caller pinned are known: this one is pageable
+    if (f.register_host != 2) return nullptr;  // only ranges the caller pinned are known: this one is pageable
     const size_t in_flight = f.groups.size() * static_cast<size_t>(f.group_frames);
     const size_t capacity = std::max<size_t>(64, in_flight * 8 + 8);
     size_t own = 0;
@@ -534,14 +653,23 @@ void transport_counts(long long* by_shader, long long* by_dma, long long* pinned
         std::lock_guard<std::mutex> lock(pin_registry().mutex);
         *pinned_ranges = static_cast<long long>(pin_registry().pins.size());
     }
-    if (reset) g_frames_by_shader = 0, g_frames_by_dma = 0;
+    if (reset) g_frames_by_shader = 0, g_frames_by_dma = 0, g_frames_staged = 0;
 }
+
+long long staged_frames() { return g_frames_staged.load(); }
 
 void release_pipeline(jinc_filter& f) {
     for (hipStream_t s : {f.h2d_stream, f.stream, f.d2h_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (auto& g : f.groups) {
         if (g.own_stream) (void)hipStreamSynchronize(g.own_stream);
+        if (g.state == FrameGroup::Launched)  // frames in flight when the instance goes: their results still arrive
+            for (size_t k = 0; k < g.frames.size(); ++k) {
+                try {
+                    deliver_frame(f, g, k);
+                } catch (const std::exception&) {  // (a device error: nothing to deliver, nobody to tell)
+                }
+            }
         release_group(g);
     }
     release_belts(f);
@@ -589,8 +717,8 @@ void configure_pipeline(jinc_filter& f, int depth, int group, int register_host)
     f.groups.resize(ring);
     f.open_group = -1;
     f.last_group = 0;
-    f.register_host = register_host != 0 ? 2 : 0;
-    if (!f.register_host) {  // cached registrations go (the pipeline is drained); ranges the caller pinned stay known
+    f.register_host = register_host == 0 || register_host == 3 ? register_host : 2;
+    if (f.register_host != 2) {  // cached registrations go (the pipeline is drained); ranges the caller pinned stay known
         for (auto& p : f.pinned)
             if (!p.adopted) shared_pin_release(p.id);
         f.pinned.erase(std::remove_if(f.pinned.begin(), f.pinned.end(), [](const PinnedRange& r) { return !r.adopted; }), f.pinned.end());
@@ -626,14 +754,31 @@ long long submit_frame(jinc_filter& f, const void* const src[4], const int src_p
         int sw, sh, dw, dh;
         f.plane_dims(f.vi_in, i, sw, sh);
         f.plane_dims(f.vi_out, i, dw, dh);
-        if (f.register_host || !f.pinned.empty()) {
-            (void)pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket);
+        bool src_mapped = f.register_host == 3;  // (mode 3: whatever the plane is, the runtime takes it as it is)
+        if (f.register_host == 2 || !f.pinned.empty()) {
+            src_mapped |= pin_host_range(f, src[i], static_cast<size_t>(src_pitch[i]) * (sh - 1) + static_cast<size_t>(sw) * sb, ticket) != nullptr;
             fr.dst_dev[i] = pin_host_range(f, dst[i], static_cast<size_t>(dst_pitch[i]) * (dh - 1) + static_cast<size_t>(dw) * sb, ticket);
         }
-        if (debug_skip() != 1)
-            hip_check(hipMemcpy2DAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, g.src_pitch[i], src[i], src_pitch[i],
-                                       static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice, h2d_of(f, g)),
+        if (!src_mapped || (!fr.dst_dev[i] && f.register_host != 3)) ensure_host_staging(f, g);
+        if (!fr.dst_dev[i] && f.register_host != 3) fr.staged_out |= 1u << i;
+        char* dev_plane = static_cast<char*>(g.src[i]) + g.src_fs[i] * k;
+        if (debug_skip() == 1) {
+        } else if (src_mapped) {
+            hip_check(hipMemcpy2DAsync(dev_plane, g.src_pitch[i], src[i], src_pitch[i], static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice,
+                                       h2d_of(f, g)),
                       "H2D copy");
+        } else {  // pageable: the CPU copies the rows into the group's pinned buffer (its previous use is over: retire_group)
+            char* staged = host_src_plane(g, i, k);
+            const int nb = stage_bands(static_cast<size_t>(g.src_pitch[i]) * sh, sh);  // (band j travels while the CPU copies band j + 1)
+            for (int b = 0; b < nb; ++b) {
+                const int y0 = sh * b / nb, y1 = sh * (b + 1) / nb;
+                const size_t off = static_cast<size_t>(g.src_pitch[i]) * y0;
+                copy_plane_rows(staged + off, static_cast<size_t>(g.src_pitch[i]), static_cast<const char*>(src[i]) + static_cast<size_t>(src_pitch[i]) * y0,
+                                static_cast<size_t>(src_pitch[i]), static_cast<size_t>(sw) * sb, y1 - y0, f.copy_helpers);
+                hip_check(hipMemcpyAsync(dev_plane + off, staged + off, static_cast<size_t>(g.src_pitch[i]) * (y1 - y0), hipMemcpyHostToDevice, h2d_of(f, g)),
+                          "H2D copy (staged)");
+            }
+        }
         fr.dst[i] = dst[i];
         fr.dst_pitch[i] = dst_pitch[i];
     }
@@ -649,7 +794,9 @@ void wait_frame(jinc_filter& f, long long ticket) {
             if (g.frames[k].ticket != ticket) continue;
             if (g.state == FrameGroup::Filling) launch_group(f, g);  // the client wants this frame now: no more company
             if (g.state == FrameGroup::Failed) throw HipError(g.error);
-            hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames[k].done_event)]), "hipEventSynchronize(frame done)");
+            if (g.frames[k].bands.empty() || g.frames[k].delivered)
+                hip_check(hipEventSynchronize(g.done[static_cast<size_t>(g.frames[k].done_event)]), "hipEventSynchronize(frame done)");
+            deliver_frame(f, g, k);  // (a banded frame: waits band by band; its last band's event is the frame's)
             return;
         }
     }

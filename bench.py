@@ -568,13 +568,14 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
 def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
     """Host planes in, host planes out through the look-ahead pipeline (jinc_filter_submit / _wait, one host thread,
     caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it.
-    pin_mode != 0: registrations cached by address (this function's buffers live as long as the instance: a frame pool);
-    0: the buffers go to the runtime as they are."""
+    pin_mode 2 (any non-zero value but 3): registrations cached by address (this function's buffers live as long as the instance: a
+    frame pool); 0: pageable planes, copied by the CPU through the library's own pinned buffers (the library's default); 3: pageable
+    planes handed to the HIP runtime as they are."""
     import numpy as np
     fmt_name, sw, sh, dw, dh, kw, _ = CONFIGS[config]
     fmt = pkg.FORMATS[fmt_name]
     frame_bytes = algorithmic_bytes_per_frame(fmt, sw, sh, dw, dh)
-    depth = max(2, min(depth, int((2 << 30) // max(1, frame_bytes))))   # at most ~2 GiB of host frames (C2: 128, C4: 4)
+    depth = max(1, min(depth, int((2 << 30) // max(1, frame_bytes))))   # at most ~2 GiB of host frames (C2: 128, C4: 4)
     f = pkg.Filter(fmt, sw, sh, dw, dh, device=0, **kw)
     f.set_pipeline(depth, pin_mode)
     rng = np.random.default_rng(3)
@@ -609,7 +610,8 @@ def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
         f.wait(tickets.pop(0))
     el = time.perf_counter() - t0
     rec = {"what": "host planes -> jinc_filter_submit/_wait -> host planes, one host thread, buffers pinned in place; not `value`",
-           "pin_mode": "pinned once, cached by address (frame pool)" if pin_mode else "pageable",
+           "pin_mode": {0: "pageable, copied by the CPU through the library's pinned buffers", 3: "pageable, handed to the HIP runtime as they are"}.get(
+               int(pin_mode), "pinned once, cached by address (frame pool)"),
            "frames_per_s": round(n / el, 1), "Mpix_per_s": round(n / el * dw * dh / 1e6, 1),
            "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2), "frames_in_flight": depth, "frames_per_launch": f.pipeline_group,
            "kernel": kernel, "seconds": round(el, 2)}

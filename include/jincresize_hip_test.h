@@ -146,6 +146,8 @@ typedef enum jinc_knob {
     JINC_KNOB_ROWPAIR_ROWS,           /* 0: border rows of filter sizes 11 .. 17 at 2x on ewa_direct_kernel's row strips instead of ewa_periodic_rowpair_kernel launches (round 5) */
     JINC_KNOB_COLPAIR,                /* border columns on ewa_colpair_kernel: 0 never, 1 (default) wherever configured, 3 filter sizes from 11 on only (round 5) */
     JINC_KNOB_UPLOAD_BOUNCE,          /* create-time table uploads: 1 (default) through the library's pinned buffer, 0 straight from the host vectors (round 6 A/B) */
+    JINC_KNOB_COPY_THREADS,           /* CPU threads that copy a large pageable plane to / from the library's pinned buffers: 1 = the calling thread only; default 6 on hosts with 12 CPUs or more, 4 from 8 on, 2 from 4 on (round 6) */
+    JINC_KNOB_STAGE_BANDS,            /* row bands a pageable plane is cut into between the CPU's copy and the DMA engine: default 4 (2 MiB each at least), 1 = whole planes (round 6) */
     JINC_KNOB_COUNT
 } jinc_knob;
 JINC_API int jinc_debug_set_knob(int knob, double value);
@@ -200,6 +202,13 @@ JINC_API const char *jinc_debug_last_instance(void);
  * (some plane was pageable); and how many host ranges the process-wide registry currently holds pinned.  For tests that
  * drive the plugin shell: several instances that share the host's frame pool must all keep the shader path. */
 JINC_API int jinc_debug_transport_counts(long long *by_shader, long long *by_dma, long long *pinned_ranges, int reset);
+/* ... and how many frames went through the library's OWN pinned buffers instead (register_host_buffers = 0: the caller's planes are
+ * pageable and only the CPU touches them); reset together with the counts above. */
+JINC_API long long jinc_debug_staged_frames(void);
+/* host_copy.cpp's plane copy (rows of row_bytes bytes between two pitched buffers, cut into row ranges for the process-wide helper
+ * threads when may_use_helpers and the plane is large): needs no device. */
+JINC_API int jinc_debug_copy_rows(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, int rows,
+                                  int may_use_helpers);
 /* Border frame of exactly periodic plans: -1 (default) = by call size (strip kernels from ~5e9 taps per call on, one gather
  * launch below); 1 = rows and columns on the round-4 strip kernels (ewa_direct_kernel's row strips, ewa_colstrip_kernel or, in batches,
  * the frame-lane kernel), corners on the gather kernel; 2 = rows on the strip kernel, columns and corners on the gather kernel;

@@ -48,6 +48,143 @@ def test_pool_mode_keeps_registrations_and_leaving_it_gives_them_back(gpu_pkg, O
     f.close()
 
 
+def _padded(planes, pad, fill):
+    """Copies of `planes` inside rows `pad` bytes longer, the padding filled with `fill`: (the views, the arrays that own them)."""
+    views, owners = [], []
+    for p in planes:
+        h, w = p.shape
+        big = np.full((h, w + pad // p.itemsize), fill, p.dtype)
+        big[:, :w] = p
+        views.append(big[:, :w])
+        owners.append(big)
+    return views, owners
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,sw,sh,tw,th", [("YUV420P8", 320, 180, 640, 360), ("Y16", 160, 90, 219, 123), ("YUV444PS", 96, 54, 144, 81)])
+def test_default_mode_keeps_the_callers_pages_off_the_device(gpu_pkg, O, fmt, sw, sh, tw, th):
+    """register_host_buffers = 0 (every new instance): pageable planes are copied by the CPU through pinned buffers of the
+    library's own -- no registration, no plane handed to the runtime -- at one frame in flight and at eight, waits out of order,
+    pitches that are not the row size (the bytes between the rows stay what they were), frames nobody waits for."""
+    ofmt = O.FORMATS[fmt]
+    of = O.OracleFilter(ofmt, sw, sh, tw, th)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    srcs = [O.lcg_frame(ofmt, sw, sh, seed=900 + k) for k in range(12)]
+    want = [of.get_frame(s, threads=4) for s in srcs]
+    dims = f.out_dims()
+    gpu_pkg.transport_counts(reset=True)
+    assert_planes_equal(f.get_frame(srcs[0]), want[0], dims, what="one synchronous frame")
+    assert gpu_pkg.staged_frames() == 1
+    for depth, group in ((1, 0), (8, 0), (8, 3), (16, 0)):
+        f.set_pipeline(depth, gpu_pkg.PIN_NONE, group)
+        padded = [_padded(s, 64, 7) for s in srcs]
+        dsts = []
+        for k in range(len(srcs)):
+            planes = [np.full((h, w + 48 // np.dtype(gpu_pkg.FORMATS[fmt].dtype).itemsize), 0x5A if fmt != "YUV444PS" else 0.25,
+                              gpu_pkg.FORMATS[fmt].dtype) for (w, h) in dims]
+            dsts.append(planes)
+        tickets = [f.submit([v for v in padded[k][0]], [d[:, :w] for d, (w, h) in zip(dsts[k], dims)]) for k in range(len(srcs))]
+        for k in (5, 0, 11, 3):
+            f.wait(tickets[k])
+            assert_planes_equal([d[:, :w] for d, (w, h) in zip(dsts[k], dims)], want[k], dims, what=f"depth {depth} group {group} frame {k}")
+        f.flush()
+        f.set_pipeline(1, gpu_pkg.PIN_NONE)      # drains: the frames nobody waited for have arrived as well
+        for k in range(len(srcs)):
+            assert_planes_equal([d[:, :w] for d, (w, h) in zip(dsts[k], dims)], want[k], dims, what=f"depth {depth} group {group} frame {k} after the drain")
+            for d, (w, h) in zip(dsts[k], dims):
+                assert (d[:, w:] == (0x5A if fmt != "YUV444PS" else 0.25)).all(), "bytes between the rows were written"
+    by_shader, by_dma, ranges = gpu_pkg.transport_counts()
+    assert (by_shader, by_dma, ranges) == (0, 0, 0) and gpu_pkg.host_registrations() == 0
+    assert gpu_pkg.staged_frames() == 1 + 4 * len(srcs)
+    f.close()
+
+
+@pytest.mark.gpu
+def test_threads_1_keeps_plane_copies_on_the_callers_thread_and_the_result_the_same(gpu_pkg, O):
+    """The reference's threads argument (1: this thread only) decides whether pageable planes may be copied by the helper threads;
+    planes of 0.9 / 3.7 MB here, large enough for them.  Same frames either way, and with the lanes knob at 2 and 7."""
+    fmt, sw, sh, tw, th = "Y8", 1280, 720, 2560, 1440
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=7 + k) for k in range(3)]
+    want = [of.get_frame(s, threads=8) for s in srcs]
+    for kw, lanes, bands, group in ((dict(threads=1), -1, -1, 2), ({}, -1, -1, 2), ({}, 2, -1, 2), ({}, 7, 3, 1), (dict(threads=0), 1, 1, 1),
+                                    (dict(threads=1), -1, 2, 1)):
+        gpu_pkg.set_knob("copy_threads", lanes)
+        gpu_pkg.set_knob("stage_bands", bands)
+        try:
+            f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
+            f.set_pipeline(4, gpu_pkg.PIN_NONE, group)     # group 1: frames travel alone, their results in row bands
+            dsts = [[gpu_pkg.alloc_plane(tw, th, np.uint8)] for _ in srcs]
+            for t in [f.submit(s, d) for s, d in zip(srcs, dsts)]:
+                f.wait(t)
+            for k in range(3):
+                assert_planes_equal(dsts[k], want[k], f.out_dims(), what=f"{kw} lanes {lanes} bands {bands} group {group} frame {k}")
+            assert_planes_equal(f.get_frame(srcs[1]), want[1], f.out_dims(), what=f"{kw} lanes {lanes} bands {bands}: synchronous frame")
+            f.close()
+        finally:
+            gpu_pkg.set_knob("copy_threads", -1)
+            gpu_pkg.set_knob("stage_bands", -1)
+
+
+@pytest.mark.gpu
+def test_frames_in_flight_when_the_instance_is_freed_still_arrive(gpu_pkg, O):
+    fmt, sw, sh, tw, th, of = _case(O)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    f.set_pipeline(4, gpu_pkg.PIN_NONE, 2)
+    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=40 + k) for k in range(4)]
+    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(4)]
+    dims = f.out_dims()
+    for s, d in zip(srcs, dsts):
+        f.submit(s, d)          # two full groups, launched; nobody waits
+    f.close()
+    for k in range(4):
+        assert_planes_equal(dsts[k], of.get_frame(srcs[k], threads=4), dims, what=f"frame {k}")
+
+
+@pytest.mark.gpu
+def test_runtime_mode_hands_pageable_planes_to_the_runtime(gpu_pkg, O):
+    """register_host_buffers = 3, the default of rounds 1 - 5: hipMemcpy2DAsync on the caller's planes as they are."""
+    fmt, sw, sh, tw, th, of = _case(O)
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    f.set_pipeline(8, gpu_pkg.PIN_RUNTIME, 4)
+    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=60 + k) for k in range(8)]
+    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(8)]
+    gpu_pkg.transport_counts(reset=True)
+    tickets = [f.submit(s, d) for s, d in zip(srcs, dsts)]
+    for t in tickets:
+        f.wait(t)
+    assert gpu_pkg.transport_counts()[:2] == (0, 8) and gpu_pkg.staged_frames() == 0 and gpu_pkg.host_registrations() == 0
+    for k in (0, 3, 7):
+        assert_planes_equal(dsts[k], of.get_frame(srcs[k], threads=4), f.out_dims(), what=f"frame {k}")
+    f.close()
+
+
+@pytest.mark.gpu
+def test_pageable_sources_with_results_into_memory_the_host_pinned(gpu_pkg, O):
+    """A host that pins only its OUTPUT pool (adopt_host_range): sources go through the library's buffers, results leave by the
+    shader straight into the pinned planes."""
+    torch = pytest.importorskip("torch")
+    fmt, sw, sh, tw, th = "Y8", 320, 180, 438, 246
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    n, dpitch = 8, 448
+    pool = torch.empty(n * dpitch * th, dtype=torch.uint8).pin_memory()
+    host = pool.numpy()
+    f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+    f.set_pipeline(8, gpu_pkg.PIN_NONE, 4)
+    f.adopt_host_range(pool.data_ptr(), pool.numel())
+    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=500 + k) for k in range(n)]
+    dsts = [[host[k * dpitch * th:(k + 1) * dpitch * th].reshape(th, dpitch)[:, :tw]] for k in range(n)]
+    gpu_pkg.transport_counts(reset=True)
+    tickets = [f.submit(s, d) for s, d in zip(srcs, dsts)]
+    for t in tickets:
+        f.wait(t)
+    assert gpu_pkg.transport_counts()[:2] == (n, 0) and gpu_pkg.staged_frames() == 0
+    for k in range(n):
+        assert_planes_equal(dsts[k], of.get_frame(srcs[k], threads=4), f.out_dims(), what=f"frame {k}")
+    f.close()
+    del host, pool
+
+
 def _batch_planes(gpu_pkg, O, fmt, sw, sh, tw, th, n, seed):
     ofmt = O.FORMATS[fmt]
     srcs = [O.lcg_frame(ofmt, sw, sh, seed=seed + k) for k in range(n)]
@@ -138,3 +275,39 @@ def test_numa_lookup_reads_the_node_of_the_pci_function_and_its_cpulist(pkg, tmp
     assert pkg.numa_cpus(str(root), "0000:e5:00.0") == []               # numa_node = -1: a machine without NUMA
     assert pkg.numa_cpus(str(root), "0000:aa:00.0") == []               # unknown device
     assert pkg.numa_cpus(str(tmp_path / "nothing"), "0000:05:00.0") == []
+
+
+def test_plane_copies_on_the_helper_threads_move_every_row_and_nothing_else(pkg):
+    """host_copy.cpp without a device: planes large enough for the helper threads, pitches that are not the row size, several
+    callers at once (one pool for the process), the one-thread path of threads = 1."""
+    import threading
+    rng = np.random.default_rng(11)
+
+    def one(rows, row_bytes, spitch, dpitch, helpers, seed):
+        src = rng.integers(0, 256, (rows, spitch), dtype=np.uint8)
+        dst = np.full((rows, dpitch), seed & 0xFF, np.uint8)
+        pkg.copy_rows(dst, src, row_bytes, rows, helpers)
+        assert np.array_equal(dst[:, :row_bytes], src[:, :row_bytes]), (rows, row_bytes, helpers)
+        assert (dst[:, row_bytes:] == (seed & 0xFF)).all(), "bytes between the rows were written"
+
+    for rows, row_bytes, spitch, dpitch in ((2160, 3840, 3840, 3840), (1080, 1920, 1984, 2048), (7, 1 << 20, 1 << 20, (1 << 20) + 64),
+                                            (2161, 1001, 1024, 1003), (1, 4 << 20, 4 << 20, 4 << 20), (300, 100, 128, 100)):
+        for helpers in (True, False):
+            one(rows, row_bytes, spitch, dpitch, helpers, rows)
+    errors = []
+
+    def many(seed):
+        try:
+            for k in range(6):
+                one(1080 + seed, 3840, 3840 + 64 * (k % 2), 3904, True, seed + k)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=many, args=(s,)) for s in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:1]
+    with pytest.raises(pkg.JincError):
+        pkg.copy_rows(np.zeros((4, 8), np.uint8), np.zeros((4, 16), np.uint8), 12, 4)   # rows longer than the destination's pitch
