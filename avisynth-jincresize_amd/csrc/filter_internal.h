@@ -171,6 +171,7 @@ struct FailedTickets {  // a group whose launch failed: every wait on one of its
 // Upper limits of the look-ahead pipeline: frames in flight per instance, and the device memory its staging may take.
 constexpr int kMaxPipelineDepth = 256;
 constexpr size_t kPipelineBudgetBytes = size_t(24) << 30;
+constexpr size_t kHostStagingBudgetBytes = size_t(4) << 30;  // pinned host memory of an instance whose planes are pageable (register_host == 0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -565,9 +565,20 @@ def cpu_frame_parallel(cfg_name, counts, seconds=2.0):
     return out
 
 
-def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
+def host_mode_name(pin_mode, batch=False):
+    return {0: "pageable, copied by the CPU through the library's pinned buffers (the library's default)",
+            3: "pageable, handed to the HIP runtime as they are"}.get(
+        int(pin_mode), "pinned once, kept until jinc_batch_free" if batch else "pinned once, cached by address (frame pool)")
+
+
+# How the host-to-host records treat the caller's planes (register_host_buffers): the library's default unless the environment says
+# otherwise (2: registered once and cached -- round 3 - 5's records and profiles/round6/host_modes.log; 3: handed to the runtime).
+E2E_MODE = int(os.environ.get("JINC_BENCH_E2E_MODE", "0"))
+
+
+def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=E2E_MODE):
     """Host planes in, host planes out through the look-ahead pipeline (jinc_filter_submit / _wait, one host thread,
-    caller buffers pinned in place): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it.
+    caller buffers treated as `pin_mode` says): frames/s and host GB/s.  PCIe-inclusive, therefore NOT `value`; recorded next to it.
     pin_mode 2 (any non-zero value but 3): registrations cached by address (this function's buffers live as long as the instance: a
     frame pool); 0: pageable planes, copied by the CPU through the library's own pinned buffers (the library's default); 3: pageable
     planes handed to the HIP runtime as they are."""
@@ -609,9 +620,8 @@ def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
     while tickets:
         f.wait(tickets.pop(0))
     el = time.perf_counter() - t0
-    rec = {"what": "host planes -> jinc_filter_submit/_wait -> host planes, one host thread, buffers pinned in place; not `value`",
-           "pin_mode": {0: "pageable, copied by the CPU through the library's pinned buffers", 3: "pageable, handed to the HIP runtime as they are"}.get(
-               int(pin_mode), "pinned once, cached by address (frame pool)"),
+    rec = {"what": "host planes -> jinc_filter_submit/_wait -> host planes, one host thread; not `value`",
+           "pin_mode": host_mode_name(pin_mode),
            "frames_per_s": round(n / el, 1), "Mpix_per_s": round(n / el * dw * dh / 1e6, 1),
            "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2), "frames_in_flight": depth, "frames_per_launch": f.pipeline_group,
            "kernel": kernel, "seconds": round(el, 2)}
@@ -619,7 +629,7 @@ def e2e_record(pkg, config, depth=128, seconds=1.5, pin_mode=2):
     return rec
 
 
-def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32):
+def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32, pin_mode=0):
     """The path a plugin or batch tool takes on a node: host planes -> jinc_batch_process (frame n -> device n mod G, one worker
     and one registrar thread per device on the CPUs of the device's NUMA node, `streams` frames in flight per device, no
     collective) -> host planes.  Total and per-device frames/s, GB/s per link.  PCIe-inclusive, NOT `value`.  Run by rank 0
@@ -644,7 +654,7 @@ def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32):
             planes.append(p)
         srcs.append(planes)
         dsts.append([pkg.alloc_plane(w, h, fmt.dtype) for (w, h) in fmt.plane_dims(dw, dh)])
-    b = pkg.Batch(fmt, sw, sh, dw, dh, ndevices=ndevices, streams=streams, register_host_buffers=pkg.PIN_POOL, **kw)
+    b = pkg.Batch(fmt, sw, sh, dw, dh, ndevices=ndevices, streams=streams, register_host_buffers=int(pin_mode), **kw)
     frames = [srcs[k % nbuf] for k in range(per_call)]
     outs = [dsts[k % nbuf] for k in range(per_call)]
     b.process(frames, outs)   # warm-up: group buffers, registration of the host frames
@@ -659,7 +669,7 @@ def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32):
            "devices": G, "frames_per_s": round(n / el, 1), "frames_per_s_per_device": round(n / el / G, 1),
            "Mpix_per_s": round(n / el * dw * dh / 1e6, 1), "host_GB_per_s": round(n / el * frame_bytes / 1e9, 2),
            "GB_per_s_per_link": round(n / el * frame_bytes / 1e9 / G, 2), "frames_in_flight_per_device": streams,
-           "frames_per_call": per_call, "calls": calls, "distinct_host_frames": nbuf, "pin_mode": "pinned once, kept until jinc_batch_free",
+           "frames_per_call": per_call, "calls": calls, "distinct_host_frames": nbuf, "pin_mode": host_mode_name(pin_mode, batch=True),
            "cpus_of_device": {str(d): (lambda c: f"{len(c)} CPUs ({c[0]}..{c[-1]})" if c else "unknown: not bound")(b.device_cpus(d)) for d in range(G)},
            "seconds": round(el, 2)}
     b.close()
@@ -1137,7 +1147,7 @@ def main(argv=None):
         line["e2e_batch"] = None
         if not args.no_e2e and not profiled:
             try:
-                line["e2e_batch"] = e2e_batch_record(pkg, args.config, n_gpus)
+                line["e2e_batch"] = e2e_batch_record(pkg, args.config, n_gpus, pin_mode=E2E_MODE)
             except Exception as exc:  # noqa: BLE001
                 line["e2e_batch"] = {"error": str(exc)}
         if n_gpus == 1 and not args.no_cpu_baseline and not profiled:

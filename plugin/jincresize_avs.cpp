@@ -72,7 +72,7 @@ struct Instance {
     int next_submit = 0;          // frames of the window below this one have been submitted
     int resubmit = -1;            // a frame of the window that was served already and is wanted again
     std::mutex mutex;             // look-ahead state (hosts that honour MT_SERIALIZED never contend for it)
-    int pin_frames = 0;           // JINCRESIZE_PIN_FRAMES: 0 (default) buffers go to the runtime as they are; 1 / "pool": pinned once, cached by address
+    int pin_frames = 0;           // JINCRESIZE_PIN_FRAMES: 0 (default) copied through the library's pinned buffers; 1 / "pool": pinned once, cached by address; "runtime": handed to the HIP runtime
     std::string error;            // storage for fi->error
 };
 
@@ -361,11 +361,12 @@ AVS_Value AVSC_CC create_jincresize(AVS_ScriptEnvironment* env, AVS_Value args, 
     if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) inst->lookahead = std::max(1, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("JINCRESIZE_GROUP")) inst->group = std::max(0, std::min(inst->lookahead, std::atoi(e)));
     // JINCRESIZE_PIN_FRAMES=1 (or "pool"): the host's frame buffers are pinned in place, once, and the registrations cached by
-    // address -- for a host whose frame pool stays mapped.  Unset / 0: the buffers go to the HIP
-    // runtime as they are.
-    // Either way copies are asynchronous and results travel by the shader (process-wide registry in the library: the
-    // instances of a script share the host's frames).
-    if (const char* e = std::getenv("JINCRESIZE_PIN_FRAMES")) inst->pin_frames = (std::strcmp(e, "pool") == 0 || std::atoi(e) != 0) ? 2 : 0;
+    // address -- for a host whose frame pool stays mapped: asynchronous copies, results written by the
+    // shader (process-wide registry in the library: the instances of a script share the host's frames).  Unset / 0: the CPU copies
+    // the planes through pinned buffers of the library's own and the device never maps the host's pages.  "runtime": the planes go
+    // to the HIP runtime as they are (the default of rounds 1 - 5).
+    if (const char* e = std::getenv("JINCRESIZE_PIN_FRAMES"))
+        inst->pin_frames = std::strcmp(e, "runtime") == 0 ? 3 : (std::strcmp(e, "pool") == 0 || std::atoi(e) != 0) ? 2 : 0;
     if (inst->lookahead > 1) {
         if (jinc_filter_set_pipeline_group(filter, inst->lookahead, inst->group, inst->pin_frames) != JINC_OK) inst->lookahead = 1;
         inst->ring.resize(static_cast<size_t>(inst->lookahead));

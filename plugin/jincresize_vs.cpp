@@ -340,7 +340,7 @@ void VS_CC jinc_vs_create(const VSMap* in, VSMap* out, void* userData, VSCore* c
     if (const char* e = std::getenv("JINCRESIZE_LOOKAHEAD")) d->lookahead = std::max(1, std::min(256, std::atoi(e)));
     if (const char* e = std::getenv("JINCRESIZE_GROUP")) d->group = std::max(0, std::min(d->lookahead, std::atoi(e)));
     const char* pin = std::getenv("JINCRESIZE_PIN_FRAMES");
-    const int pin_frames = !pin ? 0 : (std::strcmp(pin, "pool") == 0 || std::atoi(pin) != 0) ? 2 : 0;  // 1: while in flight; 2 / "pool": cached
+    const int pin_frames = !pin ? 0 : std::strcmp(pin, "runtime") == 0 ? 3 : (std::strcmp(pin, "pool") == 0 || std::atoi(pin) != 0) ? 2 : 0;  // 0: through the library's pinned buffers; 2: cached registrations; 3: handed to the runtime
     if (d->lookahead > 1) {
         if (jinc_filter_set_pipeline_group(filter, d->lookahead, d->group, pin_frames) != JINC_OK) d->lookahead = 1;
         d->ring.resize(static_cast<size_t>(d->lookahead));

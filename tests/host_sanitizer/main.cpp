@@ -1,4 +1,6 @@
 #include <cstdio>
+#include <cstring>
+#include <thread>
 #include <vector>
 #include "jincresize_hip_test.h"
 int main() {
@@ -32,6 +34,26 @@ int main() {
             std::printf("%dx%d->%dx%d table %d fs %d sets %d periodic %d quasi %d (%lld)\n", c.sw, c.sh, c.tw, c.th, t, info.filter_size, info.num_sets, info.periodic, info.quasi, sum);
         }
         jinc_filter_free(f);
+    }
+    // host_copy.cpp: plane copies cut into row ranges for the process-wide helper threads, from several callers at once
+    {
+        std::vector<std::thread> callers;
+        int wrong = 0;
+        for (int t = 0; t < 4; ++t)
+            callers.emplace_back([t, &wrong] {
+                const int rows = 1080 + t, row_bytes = 3840, spitch = 3840 + 64 * (t & 1), dpitch = 3904;
+                std::vector<unsigned char> src(size_t(rows) * spitch), dst(size_t(rows) * dpitch, 0xEE);
+                for (size_t i = 0; i < src.size(); ++i) src[i] = static_cast<unsigned char>(i * 31 + t);
+                for (int round = 0; round < 3; ++round) {
+                    if (jinc_debug_copy_rows(dst.data(), dpitch, src.data(), spitch, row_bytes, rows, round != 2) != 0) __atomic_add_fetch(&wrong, 1, __ATOMIC_RELAXED);
+                    for (int y = 0; y < rows; ++y)
+                        if (std::memcmp(&dst[size_t(y) * dpitch], &src[size_t(y) * spitch], row_bytes) != 0 || dst[size_t(y) * dpitch + row_bytes] != 0xEE)
+                            __atomic_add_fetch(&wrong, 1, __ATOMIC_RELAXED);
+                }
+            });
+        for (auto& c : callers) c.join();
+        std::printf("plane copies on the helper threads: %d wrong\n", wrong);
+        if (wrong) return 1;
     }
     return 0;
 }

@@ -80,7 +80,7 @@ def test_pieces_of_one_pool_adopted_one_by_one_become_one_range(gpu_pkg, O):
     f.close()
 
 
-def test_batch_registrar_on_one_contiguous_unaligned_pool_keeps_the_shader_transport(gpu_pkg, O):
+def test_batch_registrar_on_one_contiguous_unaligned_pool_keeps_the_shader_transport(gpu_pkg, O, pooling_host):
     """jinc_batch_process pins 16 frames at a time, clipped to what is pinned already; with one contiguous,
     unaligned frame pool every chunk boundary falls inside a plane.  Every frame must still leave by the shader."""
     fmt, sw, sh, tw, th = "Y8", 320, 180, 438, 246

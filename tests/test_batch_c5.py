@@ -40,7 +40,7 @@ def test_512_frames_sharded_over_the_visible_devices(gpu_pkg, O):
     assert len({_crc(o[0], tw, th) for o in outs}) == n        # 512 distinct inputs -> 512 distinct outputs
 
 
-def test_small_batches_and_stream_counts(gpu_pkg, O):
+def test_small_batches_and_stream_counts(gpu_pkg, O, pooling_host):
     """Batch sizes around the number of frames in flight (empty, fewer than streams, not a multiple), 4:2:0 planes."""
     fmt, sw, sh, tw, th = "YUV420P8", 160, 96, 320, 192
     ofmt = O.FORMATS[fmt]

@@ -739,7 +739,7 @@ def test_randomised_arguments(gpu_pkg, O, seed, gen):
 
 
 @pytest.mark.parametrize("register", [False, True], ids=["pageable", "registered"])
-def test_frame_pipeline(gpu_pkg, O, register):
+def test_frame_pipeline(gpu_pkg, O, register, pooling_host):
     """Look-ahead pipeline: several frames in flight per instance, collected out of order; every frame must
     equal the synchronous GetFrame result (and the oracle)."""
     fmt, sw, sh, tw, th = "YUV420P8", 200, 120, 400, 240

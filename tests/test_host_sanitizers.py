@@ -23,7 +23,7 @@ def test_host_code_is_clean_under_asan_ubsan(pkg, tmp_path):
         kernel_objs = sorted(p for p in glob.glob(os.path.join(PKG, "build", "kernel_*.o")) if "amdgcn" not in p)
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
     objs = []
-    for name in ("filter", "filter_args", "device_plan", "dispatch", "pipeline", "batch", "plan", "jinc_lut", "quasi_dispatch",
+    for name in ("filter", "filter_args", "device_plan", "dispatch", "pipeline", "host_copy", "batch", "plan", "jinc_lut", "quasi_dispatch",
                  "framelane_dispatch", "knobs"):
         o = str(tmp_path / f"{name}.o")
         subprocess.run([CXX, "-O1", "-g", "-std=c++17", "-fPIC", "-ffp-contract=off", *san, "-D__HIP_PLATFORM_AMD__",
@@ -42,3 +42,4 @@ def test_host_code_is_clean_under_asan_ubsan(pkg, tmp_path):
     assert r.returncode == 0, out[-4000:]
     assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out and "LeakSanitizer" not in out, out[-4000:]
     assert "periodic 1 quasi 1" in out and "smaller than the filter footprint" in out
+    assert "plane copies on the helper threads: 0 wrong" in out

@@ -142,7 +142,7 @@ def test_frames_in_flight_when_the_instance_is_freed_still_arrive(gpu_pkg, O):
 
 
 @pytest.mark.gpu
-def test_runtime_mode_hands_pageable_planes_to_the_runtime(gpu_pkg, O):
+def test_runtime_mode_hands_pageable_planes_to_the_runtime(gpu_pkg, O, pooling_host):
     """register_host_buffers = 3, the default of rounds 1 - 5: hipMemcpy2DAsync on the caller's planes as they are."""
     fmt, sw, sh, tw, th, of = _case(O)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)

@@ -35,7 +35,7 @@ def _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs):
     (A137, 64, 64, "ewa_framelane_win"),
     (N15T8, 64, 32, "ewa_direct_runs_kernel"),   # 1.5x with tap 8: since round 3 the runs form of the direct kernel, also in batches
 ], ids=["A137_auto", "A137_g64", "N15T8_g32"])
-def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg, O, case, depth, group, kernels):
+def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg, O, case, depth, group, kernels, pooling_host):
     fmt, sw, sh, tw, th, kw = case
     n = 64
     srcs = _frames(O, fmt, sw, sh, n, 7000)
@@ -57,7 +57,7 @@ def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg,
     f.close()
 
 
-def test_groups_of_every_fill_state_and_every_way_out(gpu_pkg, O):
+def test_groups_of_every_fill_state_and_every_way_out(gpu_pkg, O, pooling_host):
     """Full groups, a group forced out by a wait on one of its frames, by flush, by the synchronous call, by a change of
     the pipeline shape; waits in any order and twice; several planes; pageable and registered host buffers."""
     fmt, sw, sh, tw, th = "YUV420P8", 200, 120, 274, 164
@@ -144,7 +144,7 @@ def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframe
     f.close()
 
 
-def test_batch_sharder_hands_each_device_groups(gpu_pkg, O):
+def test_batch_sharder_hands_each_device_groups(gpu_pkg, O, pooling_host):
     """jinc_batch_process with 64 frames in flight per device: the device's frames leave in groups of 32 on the frame-lane
     kernel; every frame equals the single-frame result."""
     fmt, sw, sh, tw, th, kw = "Y8", 320, 180, 438, 246, {}

@@ -17,7 +17,7 @@ SHAPES = [(1, 0, False), (3, 0, True), (6, 2, False), (16, 0, True), (24, 12, Fa
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}_{c[1]}x{c[2]}to{c[3]}x{c[4]}")
-def test_many_frames_through_changing_pipeline_shapes(gpu_pkg, O, case):
+def test_many_frames_through_changing_pipeline_shapes(gpu_pkg, O, case, pooling_host):
     fmt, sw, sh, tw, th, kw = case
     ofmt = O.FORMATS[fmt]
     n = 160
