@@ -5,7 +5,7 @@
 // longer than its transfers (45 - 55 GB/s) and its kernels together.  The reference spreads its work over every core of the host
 // unless the script says threads = 1 (ref /root/reference/src/JincResize.cpp:758-760, :901: threads selects the single-threaded instantiation of resize_plane_*, 0 the parallel one); here
 // the same argument decides whether plane copies may use helper threads: threads = 1 keeps every copy on the caller's thread.
-// The helpers are a small process-wide pool (at most kHelpers threads, started with the first large copy, shared by every instance,
+// The helpers are a small process-wide pool (kHelpers threads per caller that copies at the same time, started on demand, shared by every instance,
 // idle on a condition variable otherwise); a copy is cut into row ranges, the calling thread takes the first and waits for the
 // rest.  Only memcpy runs on the helpers: no HIP call, no access to an instance.
 #include <algorithm>
@@ -40,6 +40,7 @@ struct Pool {
     std::condition_variable work, done;
     std::deque<Piece> queue;
     int threads = 0;
+    int callers = 0;  // copies being cut up right now (jinc_batch_process: one worker thread per device)
 };
 
 // Leaked on purpose, like the pin registry: instances may be freed -- and copy -- while the process's statics are being destroyed.
@@ -91,7 +92,12 @@ void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pi
     int mine = 0;
     {
         std::lock_guard<std::mutex> lock(p.mutex);
-        while (p.threads < want) {
+        // the pool grows with the callers that copy at the same time (each brings a thread of its own): `want` helpers per caller,
+        // at most half the host's CPUs all told
+        ++p.callers;
+        const int most = std::max(want, static_cast<int>(std::thread::hardware_concurrency() / 2) - p.callers);
+        const int pool_size = std::min({want * p.callers, most, 64});
+        while (p.threads < pool_size) {
             try {
                 std::thread(helper).detach();
             } catch (...) {
@@ -127,6 +133,7 @@ void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pi
         lock.lock();
         left.fetch_sub(1);
     }
+    --p.callers;
 }
 
 }  // namespace host

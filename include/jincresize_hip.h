@@ -96,7 +96,7 @@ typedef struct jinc_args {
     int tap;                /* [tap]i        default 3, 1..16 */
     double blur;            /* [blur]f       default (and 0) -> 1.0 (ref :772-774) */
     const char *cplace;     /* [cplace]s     "MPEG2" | "MPEG1" | "topleft", case-insensitive */
-    int threads;            /* [threads]i    0 or 1; advisory on the GPU path */
+    int threads;            /* [threads]i    0 or 1 (ref :758-760, :901): 1 keeps the copies of pageable planes on the calling thread, 0 lets large planes use the library's helper threads */
     int opt;                /* [opt]i        -1..3; validated as in the reference, advisory on the GPU path */
     int initial_capacity;   /* [initial_capacity]i > 0; validated, otherwise unused (scratch sizing only) */
     double initial_factor;  /* [initial_factor]f >= 1.0; validated, otherwise unused */
@@ -177,19 +177,29 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  * the previous one.  src and dst must stay valid and untouched until the frame's wait returns.  Frames are
  * independent, so neither grouping nor completion order changes results.
  * register_host_buffers: how the library treats the caller's plane buffers --
- *   0 (a new instance's state)  handed to the HIP runtime as they are: the path every HIP application with pageable memory
- *      takes.  The pipeline works and the copies serialise on the host;
- *   != 0  registered once with hipHostRegister (exactly the plane's bytes) and CACHED by address range, least recently used out:
- *      asynchronous copies, results written by the shader, no cost per frame once a buffer has been seen.  For hosts whose
- *      frame memory is a pool that STAYS MAPPED: the caller guarantees that such buffers stay allocated until jinc_filter_free
- *      or jinc_filter_set_pipeline(f, depth, 0).  The runtime consults its table of registered ranges for every host pointer it
- *      is handed, so a registration that outlives its pages makes a later buffer at those addresses travel through a dead
- *      mapping (a GPU memory access fault) or be refused (hipErrorInvalidValue when it starts inside the range and runs past
- *      its end) -- and the library cannot see a range that came back at the same addresses.
- *   Round 6 built, measured and withdrew a third mode (registered at submit, unregistered when the frame's wait returns: no
- *   registration outlives a buffer the host may release; 4 508 C2 frames/s against 6 092 cached and 4 329 pageable): on this
- *   ROCm build a process that registers and unregisters host pages at frame rate later saw GPU memory access faults inside the
- *   RUNTIME's own copies from pageable memory, with no registration of this library alive.
+ *   0 (a new instance's state)  pageable, and only the CPU ever touches them: source rows are copied into a pinned buffer of the
+ *      library's own at submit (the caller may reuse the source planes as soon as submit returns), result rows out of one when the
+ *      frame's event has fired (in jinc_filter_wait; frames nobody waits for arrive when their group buffer is reused, on
+ *      jinc_filter_set_pipeline and on jinc_filter_free).  The DMA engines move whole planes between those buffers and the
+ *      device; the device never maps the caller's pages.  Large planes are copied by up to six threads (a process-wide pool of
+ *      helpers, idle otherwise) unless the script said threads = 1.  Costs pinned host memory of the size of the device staging
+ *      (frames in flight x frame bytes, at most 4 GiB: larger groups are halved).  C2: 2 865 frames/s at one frame in flight,
+ *      5 941 at eight (profiles/round6/host_modes.log).
+ *   3  pageable planes handed to the HIP runtime as they are (hipMemcpy2DAsync on the caller's pointers): the default of rounds
+ *      1 - 5.  On this ROCm build the runtime maps the caller's pages into the device behind such a copy and keeps the mapping
+ *      for a while; C2 3 879 / 4 283 frames/s.  Full test runs and one measuring script of round 6 ended in GPU memory access
+ *      faults on heap addresses inside such copies; the cause was not established (profiles/round6/README.md).
+ *   any other value  registered once with hipHostRegister (exactly the plane's bytes) and CACHED by address range, least recently
+ *      used out: asynchronous copies, results written by the shader, no cost per frame once a buffer has been seen (C2 4 020 /
+ *      5 631 / 6 125 frames/s at 1 / 8 / 128 frames in flight).  For hosts whose frame memory is a pool that STAYS MAPPED: the
+ *      caller guarantees that such buffers stay allocated until jinc_filter_free or jinc_filter_set_pipeline(f, depth, 0).  The
+ *      runtime consults its table of registered ranges for every host pointer it is handed, so a registration that outlives its
+ *      pages makes a later buffer at those addresses travel through a dead mapping (a GPU memory access fault) or be refused
+ *      (hipErrorInvalidValue when it starts inside the range and runs past its end) -- and the library cannot see a range that
+ *      came back at the same addresses.
+ *   Planes inside a range the caller pinned itself (jinc_filter_adopt_host_range) travel through that mapping in every mode.
+ *   Round 6 also built, measured and withdrew "registered at submit, unregistered when the frame's wait returns" (4 508 C2
+ *   frames/s): registration at frame rate.
  * A failed launch is reported by the submit that triggered it and by every wait on a frame of that group.
  * jinc_filter_get_frame == submit + wait (after draining frames still in flight). */
 JINC_API int jinc_filter_set_pipeline(jinc_filter *f, int depth, int register_host_buffers);
@@ -228,7 +238,8 @@ JINC_API int jinc_filter_sync(jinc_filter *f);
  * device holds a replica of the plan (one filter instance) and keeps `streams_per_device` (1..256) frames in flight
  * through the look-ahead pipeline above (frames coalesced into groups of streams_per_device / 2 per launch), driven by
  * one host thread per device.  No collective.
- * ndevices <= 0: all visible devices.  register_host_buffers: 0 pageable; != 0 the planes of a jinc_batch_process call are
+ * ndevices <= 0: all visible devices.  register_host_buffers: 0 pageable, copied through the instances' own pinned buffers; 3 pageable,
+ * handed to the runtime; any other value: the planes of a jinc_batch_process call are
  * pinned by one registrar thread per device running ahead of the submissions (exact byte ranges, planes that follow each
  * other merged) and stay pinned until jinc_batch_free: the caller keeps them allocated until then (a caller that re-uses its
  * planes call after call pays once).  The worker and the registrar of device d run on the CPUs of d's NUMA node (sysfs numa_node of the

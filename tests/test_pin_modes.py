@@ -1,16 +1,17 @@
 """How the library treats the caller's host buffers (jinc_filter_set_pipeline's / jinc_batch_create's register_host_buffers).
 
-Round 6 (Next 6 / 7) built three modes and kept two: buffers go to the HIP runtime as
-they are (0, the default), or they are registered once and the registrations cached by address (non-zero: the promise of a host
-whose frame memory stays mapped -- the `pooling_host` fixture marks those tests).  The third, "registered while the frame is in
-flight", passed its own tests -- planes unmapped and mapped again at the same addresses between frames included -- but the
-registration churn it brings ended full test runs in GPU memory access faults inside the RUNTIME's copies from pageable memory
-(4 of 9 runs, no registration of the library alive; profiles/round6/README.md), so it was withdrawn and its tests with it.
+Round 6 ended with three modes: 0 (the default) pageable planes copied by the CPU through pinned buffers of the library's own -- the
+device never maps the caller's pages; any other value but 3: registered once, the registrations cached by address (the promise of a
+host whose frame memory stays mapped -- the `pooling_host` fixture models such a host for the test's duration); 3: pageable planes
+handed to the HIP runtime as they are (the default of rounds 1 - 5).  A fourth, "registered while the frame is in flight", was built
+and withdrawn (profiles/round6/README.md tells why, and why the default changed).
 
-What is tested here: cached registrations are kept and given back; jinc_batch_process pins with one registrar per device
+What is tested here: the default at every pipeline shape, with pitches that are not the row size, out-of-order waits and frames
+nobody waits for; the helper threads of the plane copies (and threads = 1, which keeps them off); mode 3; pageable sources with results
+into memory the host pinned; cached registrations are kept and given back; jinc_batch_process pins with one registrar per device
 (several on this one-device box through the test header) in exact byte ranges that cover every plane whole; the NUMA lookup of
-batch.cpp against a fake sysfs tree (CPU).  Every test of the suite ends with the registry empty and as many hipHostUnregister as
-hipHostRegister calls (tests/conftest.py)."""
+batch.cpp against a fake sysfs tree (CPU); host_copy.cpp's plane copy without a device (CPU).  Every test of the suite ends with the
+registry empty and as many hipHostUnregister as hipHostRegister calls (tests/conftest.py)."""
 import os
 
 import numpy as np
