@@ -511,12 +511,13 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
 // nullptr if the range could not be pinned (the frame then takes the DMA / pageable path -- not an error).  The cache
 // holds at least every range the frames in flight can reference (frames x planes x (src + dst)), and a range whose frame
 // may still be in flight is never unregistered under its transfer: its group is finished first.
-// Round 6 built and withdrew a second mode -- registrations made at submit, held by the frames in flight that use the range and
+// Round 6 built and withdrew another mode -- registrations made at submit, held by the frames in flight that use the range and
 // given back with the last of them: logically the safe form (no registration outlives a buffer the host may release), and it
-// passed every test of its own, buffers unmapped and mapped again at the same addresses between frames included.  But a process
-// that registers and unregisters host pages at frame rate saw GPU memory access faults LATER, inside the runtime's own copies from
-// pageable memory, in 4 of 9 full test runs, with no registration of this library alive at the time (profiles/round6/README.md;
-// the code: profiles/experiments/pin_while_in_flight.diff).  register_host != 0 means cached registrations, as in rounds 3-5.
+// passed every test of its own, buffers unmapped and mapped again at the same addresses between frames included.  Three of the
+// nine full test runs that had it ended in GPU memory access faults inside the runtime's own copies from pageable memory, with no
+// registration of this library alive at the time; later a run without it and a script with cached registrations faulted too
+// (profiles/round6/README.md; the code: profiles/experiments/pin_while_in_flight.diff), which is why pageable planes now avoid
+// the runtime's mapping altogether (ensure_host_staging above).  register_host == 2 means cached registrations, as in rounds 3-5.
 char* pin_host_range(jinc_filter& f, const void* p, size_t bytes, long long ticket) {
     char* c = const_cast<char*>(static_cast<const char*>(p));
     for (size_t i = 0; i < f.pinned.size(); ++i) {
