@@ -13,8 +13,14 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <fstream>
 #include <mutex>
+#include <sstream>
+#include <string>
 #include <thread>
+
+#include <sched.h>
+#include <unistd.h>
 
 #include "filter_internal.h"
 #include "knobs.h"
@@ -58,6 +64,10 @@ void rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t
 }
 
 void helper() {
+    // a helper serves every instance of the process: it runs where the process's main thread may run, not where the thread that
+    // happened to start it was bound (jinc_batch_process binds each device's worker to that device's NUMA node)
+    cpu_set_t everywhere;
+    if (sched_getaffinity(getpid(), sizeof(everywhere), &everywhere) == 0) (void)sched_setaffinity(0, sizeof(everywhere), &everywhere);
     Pool& p = pool();
     std::unique_lock<std::mutex> lock(p.mutex);
     for (;;) {
@@ -71,11 +81,62 @@ void helper() {
     }
 }
 
+// CPUs this process may keep busy: its affinity mask, cut down to the CFS quota of its cgroup where there is one (a container
+// with 256 CPUs in the mask and cpu.max = 16 cores is throttled as a whole once more than 16 threads run: eight client threads
+// with five helpers each fell from 3 812 to 2 347 C2 frames/s that way, profiles/round6/e2e_get_frame_modes.log).  Read once.
+int usable_cpus() {
+    static const int n = [] {
+        int cpus = static_cast<int>(std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        auto first_line = [](const std::string& path) {
+            std::ifstream in(path);
+            std::string line;
+            if (in) std::getline(in, line);
+            return line;
+        };
+        double quota = 0.0;  // cores; 0: none found
+        auto consider = [&](double q) {
+            if (q > 0.0 && (quota == 0.0 || q < quota)) quota = q;
+        };
+        std::ifstream groups("/proc/self/cgroup");
+        for (std::string line; groups && std::getline(groups, line);) {
+            const size_t a = line.find(':'), b = a == std::string::npos ? a : line.find(':', a + 1);
+            if (b == std::string::npos) continue;
+            const std::string controllers = line.substr(a + 1, b - a - 1);
+            std::string rel = line.substr(b + 1);
+            const bool v2 = controllers.empty();
+            if (!v2 && controllers.find("cpu") == std::string::npos) continue;
+            for (;;) {  // this group and its parents
+                if (v2) {
+                    std::istringstream f(first_line("/sys/fs/cgroup" + rel + "/cpu.max"));
+                    std::string q;
+                    double period = 0.0;
+                    if (f >> q >> period && q != "max" && period > 0.0) consider(std::atof(q.c_str()) / period);
+                } else {
+                    for (const char* ctl : {"cpu", "cpu,cpuacct"}) {
+                        const std::string base = std::string("/sys/fs/cgroup/") + ctl + rel;
+                        const double q = std::atof(first_line(base + "/cpu.cfs_quota_us").c_str());
+                        const double period = std::atof(first_line(base + "/cpu.cfs_period_us").c_str());
+                        if (q > 0.0 && period > 0.0) consider(q / period);
+                    }
+                }
+                if (rel.empty() || rel == "/") break;
+                const size_t cut = rel.find_last_of('/');
+                rel = cut == std::string::npos || cut == 0 ? "/" : rel.substr(0, cut);
+            }
+        }
+        if (quota > 0.0) cpus = std::min(cpus, std::max(1, static_cast<int>(quota + 0.5)));
+        return std::max(cpus, 1);
+    }();
+    return n;
+}
+
 int helpers_wanted() {
     const int knob = knobs::geti(JINC_KNOB_COPY_THREADS, -1);  // A/B: total lanes, 1 = the calling thread only
     if (knob >= 1) return std::min(knob - 1, 15);
-    const unsigned hw = std::thread::hardware_concurrency();
-    return hw >= 12 ? kHelpers : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;
+    const int cpus = usable_cpus();
+    return cpus >= 12 ? kHelpers : cpus >= 8 ? 3 : cpus >= 4 ? 1 : 0;
 }
 
 }  // namespace
@@ -93,9 +154,9 @@ void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pi
     {
         std::lock_guard<std::mutex> lock(p.mutex);
         // the pool grows with the callers that copy at the same time (each brings a thread of its own): `want` helpers per caller,
-        // at most half the host's CPUs all told
+        // at most half the CPUs this process may use all told (callers included)
         ++p.callers;
-        const int most = std::max(want, static_cast<int>(std::thread::hardware_concurrency() / 2) - p.callers);
+        const int most = std::max(knobs::geti(JINC_KNOB_COPY_THREADS, -1) >= 1 ? want : 0, usable_cpus() / 2 - p.callers);
         const int pool_size = std::min({want * p.callers, most, 64});
         while (p.threads < pool_size) {
             try {

@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--pipeline", type=int, nargs="*", default=[], help="also time ONE host thread with these pipeline depths")
     ap.add_argument("--group", type=int, default=0, help="frames coalesced per launch (0: automatic = depth / 2)")
     ap.add_argument("--registered-only", action="store_true")
-    ap.add_argument("--pin-mode", type=int, default=-1, help="-1: the instance's default (1: planes pinned while the frame is in flight); 0 / 1 / 2: set_pipeline(1, mode)")
+    ap.add_argument("--pin-mode", type=int, default=-1, help="-1: the instance's default (0); 0 / 2 / 3: set_pipeline(1, mode) -- through the library's pinned buffers / cached registrations / handed to the runtime")
     a = ap.parse_args()
     pkg = entry.load_package()
     fmt_name, sw, sh, dw, dh, kw, _ = bench.CONFIGS[a.config]
