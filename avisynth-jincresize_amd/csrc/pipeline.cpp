@@ -5,12 +5,15 @@
 // coalesced: consecutively submitted frames are staged into ONE strided device buffer per plane (a FrameGroup) and leave
 // as ONE enqueue(..., nframes = k, ...) -- so the batch kernels of dispatch.cpp (frame-lane / frame-pair forms, wide
 // tiles) serve the host-pointer entry points too.
-//   submit(frame)  H2D copy of the frame into slot k of the open group, queued at once; the group is launched when it
-//                  holds `group_frames` frames;
-//   launch         the kernels behind the group's copies, then the results to the callers' planes: by the shader straight
+//   submit(frame)  H2D copy of the frame into slot k of the open group, queued at once (pageable planes: the CPU copies the rows
+//                  into the group's own pinned buffer first, band by band); the group is launched when it holds `group_frames`
+//                  frames;
+//   launch         the kernels behind the group's copies, then the results towards the callers' planes: by the shader straight
 //                  into the pinned host planes (kernel_blit.hip, kGroupShares launches + events per group) when every
-//                  destination plane is pinned, else one DMA copy per plane and frame with an event per frame;
-//   wait(ticket)   launches the open group early if the frame sits in it, then waits for that frame's event only;
+//                  destination plane is pinned; pageable planes: contiguous DMA copies into the group's pinned buffer, one per
+//                  plane and share of the group (a lone frame: per row band), an event per share;
+//   wait(ticket)   launches the open group early if the frame sits in it, waits for that frame's event only, and copies the
+//                  frame's rows from the pinned buffer into pageable destination planes (deliver_frame);
 //   groups rotate through a ring of ceil(depth / group_frames) + 1 buffers; reusing a buffer waits for its previous use
 //   (back-pressure).  Streams: see FrameGroup in filter_internal.h (three belts: arrivals, kernels, departures).
 // Why the shader: one DMA copy per plane and frame costs ~17 us of engine turnaround besides the wire time (2 MB planes:

@@ -177,3 +177,11 @@ def test_reference_is_not_needed_at_runtime():
         if re.search(r"open\([^)]*root/reference|listdir\([^)]*root/reference", text):
             offenders.append(fn)
     assert offenders == []
+
+
+def test_library_is_not_unloadable(pkg):
+    """The library parks helper threads (csrc/host_copy.cpp) and keeps process-wide registries: dlclose() by a host that unloads its
+    plugins must not unmap it (-z nodelete, avisynth-jincresize_amd/Makefile)."""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", pkg.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "NODELETE" in out
