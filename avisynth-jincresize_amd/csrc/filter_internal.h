@@ -120,6 +120,11 @@ struct GroupFrame {
     // event has fired (deliver_frame): the caller's memory is pageable and the GPU never maps it (register_host == 0).
     unsigned staged_out = 0;
     bool delivered = false;
+    // Small pageable source planes (bit i) of a frame in a group of several: not copied at submit but with the rest of the group
+    // when it is launched -- one job for the copy lanes, one DMA copy per plane for the whole group (launch_group).
+    unsigned deferred_in = 0;
+    const void* src[4] = {nullptr, nullptr, nullptr, nullptr};
+    int src_pitch[4] = {0, 0, 0, 0};
     // A frame that travels alone (a group of one: jinc_filter_get_frame): its staged result planes leave the device in row bands,
     // an event behind each, and the CPU copies a band out while the next ones are still on the wire.
     struct Band {
@@ -306,6 +311,13 @@ void transport_counts(long long* by_shader, long long* by_dma, long long* pinned
 // host_copy.cpp: rows between a pageable plane and a pinned buffer of the library's own; large planes are cut into row ranges for the
 // process-wide helper threads when may_use_helpers (the calling thread always takes part and returns when every row has been copied).
 void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t row_bytes, int rows, bool may_use_helpers);
+struct PlaneCopy {
+    char* dst;
+    const char* src;
+    size_t dst_pitch, src_pitch, row_bytes;
+    int rows;
+};
+void copy_planes(const PlaneCopy* jobs, size_t njobs, bool may_use_helpers);  // several planes as ONE job for the lanes (the frames of a group's share)
 long long staged_frames();  // frames whose results went through the library's own pinned buffers since the last reset of transport_counts
 
 }  // namespace host

@@ -141,16 +141,16 @@ int helpers_wanted() {
 
 }  // namespace
 
-void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t row_bytes, int nrows, bool may_use_helpers) {
-    const size_t total = row_bytes * static_cast<size_t>(std::max(nrows, 0));
+void copy_planes(const PlaneCopy* jobs, size_t njobs, bool may_use_helpers) {
+    size_t total = 0;
+    for (size_t j = 0; j < njobs; ++j) total += jobs[j].row_bytes * static_cast<size_t>(std::max(jobs[j].rows, 0));
     const int want = may_use_helpers && total >= kParallelFrom ? helpers_wanted() : 0;
-    if (want <= 0 || nrows < 2 * (want + 1)) {
-        rows(dst, dst_pitch, src, src_pitch, row_bytes, nrows);
+    if (want <= 0) {
+        for (size_t j = 0; j < njobs; ++j) rows(jobs[j].dst, jobs[j].dst_pitch, jobs[j].src, jobs[j].src_pitch, jobs[j].row_bytes, jobs[j].rows);
         return;
     }
     Pool& p = pool();
     std::atomic<int> left{0};
-    int mine = 0;
     {
         std::lock_guard<std::mutex> lock(p.mutex);
         // the pool grows with the callers that copy at the same time (each brings a thread of its own): `want` helpers per caller,
@@ -166,21 +166,26 @@ void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pi
             }
             ++p.threads;
         }
+        // pieces of about total / lanes bytes (a plane larger than that is cut into row ranges, smaller planes go whole), at least
+        // 128 KiB each: several small planes -- the frames of a group's share -- spread over the lanes as well as one large plane does
         const int lanes = std::min(want, p.threads) + 1;
-        mine = nrows / lanes;
-        int y = mine;
-        for (int k = 1; k < lanes; ++k) {
-            const int n = k + 1 == lanes ? nrows - y : nrows / lanes;
-            p.queue.push_back({dst + dst_pitch * y, src + src_pitch * y, dst_pitch, src_pitch, row_bytes, n, &left});
-            ++left;
-            y += n;
+        const size_t piece_bytes = std::max<size_t>(total / static_cast<size_t>(lanes), 128 << 10);
+        for (size_t j = 0; j < njobs; ++j) {
+            const PlaneCopy& c = jobs[j];
+            if (c.rows <= 0 || c.row_bytes == 0) continue;
+            const size_t bytes = c.row_bytes * static_cast<size_t>(c.rows);
+            const int parts = static_cast<int>(std::max<size_t>(1, std::min<size_t>((bytes + piece_bytes - 1) / piece_bytes, static_cast<size_t>(c.rows))));
+            for (int k = 0; k < parts; ++k) {
+                const int y0 = c.rows * k / parts, y1 = c.rows * (k + 1) / parts;
+                p.queue.push_back({c.dst + c.dst_pitch * y0, c.src + c.src_pitch * y0, c.dst_pitch, c.src_pitch, c.row_bytes, y1 - y0, &left});
+                ++left;
+            }
         }
-        if (lanes == 1) mine = nrows;
     }
     p.work.notify_all();
-    rows(dst, dst_pitch, src, src_pitch, row_bytes, mine);
+    // the caller works through its own pieces like a helper would (whatever the helpers do not get to is done here) and waits for
+    // the pieces helpers are still busy with
     std::unique_lock<std::mutex> lock(p.mutex);
-    // a helper that is busy with another instance's copy leaves pieces in the queue: the caller takes them itself rather than wait
     while (left.load() > 0) {
         auto it = std::find_if(p.queue.begin(), p.queue.end(), [&](const Piece& q) { return q.left == &left; });
         if (it == p.queue.end()) {
@@ -195,6 +200,11 @@ void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pi
         left.fetch_sub(1);
     }
     --p.callers;
+}
+
+void copy_plane_rows(char* dst, size_t dst_pitch, const char* src, size_t src_pitch, size_t row_bytes, int nrows, bool may_use_helpers) {
+    const PlaneCopy one{dst, src, dst_pitch, src_pitch, row_bytes, nrows};
+    copy_planes(&one, 1, may_use_helpers);
 }
 
 }  // namespace host

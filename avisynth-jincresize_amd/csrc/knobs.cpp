@@ -22,7 +22,7 @@ const char* const kNames[JINC_KNOB_COUNT] = {
     "float_trim_min_fs", "quad8", "fl_cols_frames", "quad_rg", "quad2x8", "float_scan", "fl_fill_weight", "fl_variant", "fl_1k",
     "fl_lds_kb", "fl_colw", "fl_threads", "flp_lds_kb", "flp_colw", "flp_threads", "blit_workgroups", "group_shares",
     "pipeline_skip", "pipeline_dma", "d2h_priority", "quasi_lds_kb", "blit_setprio", "direct_shape", "gather_passes",
-    "rows_pair", "rowpair_small", "strip_lds", "edge_cols", "rowpair_rows", "colpair", "upload_bounce", "copy_threads", "stage_bands",
+    "rows_pair", "rowpair_small", "strip_lds", "edge_cols", "rowpair_rows", "colpair", "upload_bounce", "copy_threads", "stage_bands", "stage_defer_kb",
 };
 
 thread_local char t_instance[192] = "";

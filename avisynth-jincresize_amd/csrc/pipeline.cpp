@@ -316,13 +316,24 @@ void deliver_frame(jinc_filter& f, FrameGroup& g, size_t k) {
         }
         return;
     }
-    for (int i = 0; i < f.planecount; ++i) {
-        if (!((fr.staged_out >> i) & 1)) continue;
-        int dw, dh;
-        f.plane_dims(f.vi_out, i, dw, dh);
-        copy_plane_rows(static_cast<char*>(fr.dst[i]), static_cast<size_t>(fr.dst_pitch[i]), host_dst_plane(g, i, k),
-                        static_cast<size_t>(g.dst_pitch[i]), static_cast<size_t>(dw) * sb, dh, f.copy_helpers);
+    // Every frame that became complete with this one (the same share of the group, the same event) is delivered with it, as ONE
+    // job for the copy lanes: small planes do not fill six lanes one by one, a share's worth of them does, and the client is
+    // going to ask for the others next (their destination planes stay the caller's until each frame's own wait returns, as
+    // the contract of jinc_filter_submit says).
+    std::vector<PlaneCopy> jobs;
+    for (size_t j = 0; j < g.frames.size(); ++j) {
+        GroupFrame& other = g.frames[j];
+        if (j != k && (other.delivered || other.done_event != fr.done_event || !other.bands.empty())) continue;
+        other.delivered = true;
+        for (int i = 0; i < f.planecount; ++i) {
+            if (!((other.staged_out >> i) & 1)) continue;
+            int dw, dh;
+            f.plane_dims(f.vi_out, i, dw, dh);
+            jobs.push_back({static_cast<char*>(other.dst[i]), host_dst_plane(g, i, j), static_cast<size_t>(other.dst_pitch[i]), static_cast<size_t>(g.dst_pitch[i]),
+                            static_cast<size_t>(dw) * sb, dh});
+        }
     }
+    if (!jobs.empty()) copy_planes(jobs.data(), jobs.size(), f.copy_helpers);
 }
 
 // Row bands a staged plane of `bytes` bytes is cut into on its way between the CPU's copy and the DMA engine, so that one works
@@ -379,6 +390,37 @@ int debug_skip() { return knobs::geti(JINC_KNOB_PIPELINE_SKIP, 0); }
 
 bool dma_forced() { return knobs::flag(JINC_KNOB_PIPELINE_DMA, false); }
 
+// The small pageable source planes the group's frames left for the launch (submit_frame): into the group's pinned buffer as ONE
+// job for the copy lanes, then one DMA copy per plane and run of consecutive frames.
+void stage_deferred_sources(jinc_filter& f, FrameGroup& g) {
+    const int sb = f.vi_in.component_size;
+    std::vector<PlaneCopy> jobs;
+    for (size_t k = 0; k < g.frames.size(); ++k)
+        for (int i = 0; i < f.planecount; ++i)
+            if ((g.frames[k].deferred_in >> i) & 1) {
+                int sw, sh;
+                f.plane_dims(f.vi_in, i, sw, sh);
+                jobs.push_back({host_src_plane(g, i, k), static_cast<const char*>(g.frames[k].src[i]), static_cast<size_t>(g.src_pitch[i]),
+                                static_cast<size_t>(g.frames[k].src_pitch[i]), static_cast<size_t>(sw) * sb, sh});
+            }
+    if (jobs.empty()) return;
+    copy_planes(jobs.data(), jobs.size(), f.copy_helpers);
+    for (int i = 0; i < f.planecount; ++i)
+        for (size_t k = 0; k < g.frames.size();) {
+            if (!((g.frames[k].deferred_in >> i) & 1)) {
+                ++k;
+                continue;
+            }
+            size_t end = k;
+            while (end < g.frames.size() && ((g.frames[end].deferred_in >> i) & 1)) ++end;
+            hip_check(hipMemcpyAsync(static_cast<char*>(g.src[i]) + g.src_fs[i] * k, host_src_plane(g, i, k), g.src_fs[i] * (end - k), hipMemcpyHostToDevice,
+                                     h2d_of(f, g)),
+                      "H2D copy (staged, group)");
+            for (size_t j = k; j < end; ++j) g.frames[j].deferred_in &= ~(1u << i);
+            k = end;
+        }
+}
+
 // Kernels of the group's frames in one call, then the results to the callers' planes and the events their waits block
 // on.  A failure marks the group Failed; every wait on one of its frames reports it.
 void launch_group(jinc_filter& f, FrameGroup& g) {
@@ -389,6 +431,7 @@ void launch_group(jinc_filter& f, FrameGroup& g) {
     try {
         const bool belts = !g.own_stream;
         hipStream_t d2h = d2h_of(f, g);
+        stage_deferred_sources(f, g);
         if (belts) {  // the kernels read what the arrivals belt has copied
             hip_check(hipEventRecord(g.h2d_ready, f.h2d_stream), "hipEventRecord(arrivals)");
             hip_check(hipStreamWaitEvent(f.stream, g.h2d_ready, 0), "hipStreamWaitEvent(arrivals)");
@@ -756,6 +799,16 @@ long long submit_frame(jinc_filter& f, const void* const src[4], const int src_p
     const long long ticket = f.next_ticket;
     GroupFrame fr;
     fr.ticket = ticket;
+    // Frames whose source planes are small do not fill the copy lanes one by one, and one DMA copy per plane and frame costs more
+    // in engine turnaround than on the wire: in a group of four or more they wait for the launch (A/B knob STAGE_DEFER_KB: frames
+    // up to this many KiB of source, default 1536; 0 = never).
+    size_t frame_src_bytes = 0;
+    for (int i = 0; i < f.planecount; ++i) {
+        int sw, sh;
+        f.plane_dims(f.vi_in, i, sw, sh);
+        frame_src_bytes += static_cast<size_t>(sw) * sb * sh;
+    }
+    const bool defer_small = g.capacity >= 4 && frame_src_bytes <= static_cast<size_t>(std::max(0, knobs::geti(JINC_KNOB_STAGE_DEFER_KB, 1536))) << 10;
     for (int i = 0; i < f.planecount; ++i) {
         int sw, sh, dw, dh;
         f.plane_dims(f.vi_in, i, sw, sh);
@@ -773,6 +826,10 @@ long long submit_frame(jinc_filter& f, const void* const src[4], const int src_p
             hip_check(hipMemcpy2DAsync(dev_plane, g.src_pitch[i], src[i], src_pitch[i], static_cast<size_t>(sw) * sb, sh, hipMemcpyHostToDevice,
                                        h2d_of(f, g)),
                       "H2D copy");
+        } else if (defer_small) {  // pageable and small, in company: copied with the rest of the group at its launch
+            fr.src[i] = src[i];
+            fr.src_pitch[i] = src_pitch[i];
+            fr.deferred_in |= 1u << i;
         } else {  // pageable: the CPU copies the rows into the group's pinned buffer (its previous use is over: retire_group)
             char* staged = host_src_plane(g, i, k);
             const int nb = stage_bands(static_cast<size_t>(g.src_pitch[i]) * sh, sh);  // (band j travels while the CPU copies band j + 1)

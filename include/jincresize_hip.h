@@ -178,7 +178,7 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  * independent, so neither grouping nor completion order changes results.
  * register_host_buffers: how the library treats the caller's plane buffers --
  *   0 (a new instance's state)  pageable, and only the CPU ever touches them: source rows are copied into a pinned buffer of the
- *      library's own at submit (the caller may reuse the source planes as soon as submit returns), result rows out of one when the
+ *      library's own at submit (small frames in groups of four or more: when their group is launched), result rows out of one when the
  *      frame's event has fired (in jinc_filter_wait; frames nobody waits for arrive when their group buffer is reused, on
  *      jinc_filter_set_pipeline and on jinc_filter_free).  The DMA engines move whole planes between those buffers and the
  *      device; the device never maps the caller's pages.  Large planes are copied by up to six threads (a process-wide pool of

@@ -148,6 +148,7 @@ typedef enum jinc_knob {
     JINC_KNOB_UPLOAD_BOUNCE,          /* create-time table uploads: 1 (default) through the library's pinned buffer, 0 straight from the host vectors (round 6 A/B) */
     JINC_KNOB_COPY_THREADS,           /* CPU threads that copy a large pageable plane to / from the library's pinned buffers: 1 = the calling thread only; default 6 on hosts with 12 CPUs or more, 4 from 8 on, 2 from 4 on (round 6) */
     JINC_KNOB_STAGE_BANDS,            /* row bands a pageable plane is cut into between the CPU's copy and the DMA engine: default 4 (2 MiB each at least), 1 = whole planes (round 6) */
+    JINC_KNOB_STAGE_DEFER_KB,         /* pageable frames of up to this many KiB of source in groups of 4 or more are copied to the library's pinned buffer when the group is launched (one job, one DMA copy per plane) instead of at submit: default 1536, 0 = never (round 6) */
     JINC_KNOB_COUNT
 } jinc_knob;
 JINC_API int jinc_debug_set_knob(int knob, double value);
