@@ -183,8 +183,8 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  *      jinc_filter_set_pipeline and on jinc_filter_free).  The DMA engines move whole planes between those buffers and the
  *      device; the device never maps the caller's pages.  Large planes are copied by up to six threads (a process-wide pool of
  *      helpers, idle otherwise) unless the script said threads = 1.  Costs pinned host memory of the size of the device staging
- *      (frames in flight x frame bytes, at most 4 GiB: larger groups are halved).  C2: 2 865 frames/s at one frame in flight,
- *      5 941 at eight (profiles/round6/host_modes.log).
+ *      (frames in flight x frame bytes, at most 4 GiB: larger groups are halved).  C2: 2 570 - 2 900 frames/s at one frame in
+ *      flight, 5 280 - 6 000 at eight over four boxes (CPU work: it varies with the host; profiles/round6/host_modes*.log).
  *   3  pageable planes handed to the HIP runtime as they are (hipMemcpy2DAsync on the caller's pointers): the default of rounds
  *      1 - 5.  On this ROCm build the runtime maps the caller's pages into the device behind such a copy and keeps the mapping
  *      for a while; C2 3 879 / 4 283 frames/s.  Full test runs and one measuring script of round 6 ended in GPU memory access
