@@ -76,7 +76,8 @@ def test_default_mode_keeps_the_callers_pages_off_the_device(gpu_pkg, O, fmt, sw
     gpu_pkg.transport_counts(reset=True)
     assert_planes_equal(f.get_frame(srcs[0]), want[0], dims, what="one synchronous frame")
     assert gpu_pkg.staged_frames() == 1
-    for depth, group in ((1, 0), (8, 0), (8, 3), (16, 0)):
+    for depth, group, defer_kb in ((1, 0, -1), (8, 0, -1), (8, 3, -1), (16, 0, -1), (16, 0, 0)):
+        gpu_pkg.set_knob("stage_defer_kb", defer_kb)   # 0: source planes copied at submit also in groups of four or more (default: with the group)
         f.set_pipeline(depth, gpu_pkg.PIN_NONE, group)
         padded = [_padded(s, 64, 7) for s in srcs]
         dsts = []
@@ -96,7 +97,7 @@ def test_default_mode_keeps_the_callers_pages_off_the_device(gpu_pkg, O, fmt, sw
                 assert (d[:, w:] == (0x5A if fmt != "YUV444PS" else 0.25)).all(), "bytes between the rows were written"
     by_shader, by_dma, ranges = gpu_pkg.transport_counts()
     assert (by_shader, by_dma, ranges) == (0, 0, 0) and gpu_pkg.host_registrations() == 0
-    assert gpu_pkg.staged_frames() == 1 + 4 * len(srcs)
+    assert gpu_pkg.staged_frames() == 1 + 5 * len(srcs)
     f.close()
 
 
