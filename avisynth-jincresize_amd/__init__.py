@@ -81,7 +81,7 @@ EXPORTS = ["jinc_device_count", "jinc_pick_device", "jinc_last_error", "jinc_fil
            "jinc_filter_chroma_location", "jinc_filter_set_chroma_location_mode", "jinc_filter_get_frame", "jinc_filter_process_device", "jinc_filter_sync",
            "jinc_alias_args", "jinc_filter_num_tables", "jinc_filter_plan_info", "jinc_filter_plan_pixel",
            "jinc_filter_plan_dump", "jinc_filter_plan_runs", "jinc_filter_plan_set", "jinc_filter_lut", "jinc_filter_set_kernel_mode", "jinc_filter_set_border_strips", "jinc_filter_interior_kernel", "jinc_filter_last_kernel",
-           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_debug_staged_frames", "jinc_debug_copy_rows", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
+           "jinc_filter_set_profiling", "jinc_filter_kernel_times", "jinc_filter_set_border_overlap", "jinc_debug_convert", "jinc_debug_buffer_range_check", "jinc_debug_set_direct_shape", "jinc_debug_last_direct_shape", "jinc_filter_set_simd_order", "jinc_debug_transport_counts", "jinc_debug_staged_frames", "jinc_debug_copy_rows", "jinc_debug_usable_cpus", "jinc_filter_periodic_support", "jinc_filter_periodic_taps", "jinc_filter_set_pipeline",
            "jinc_filter_set_pipeline_group", "jinc_filter_pipeline_group", "jinc_filter_flush", "jinc_filter_adopt_host_range", "jinc_filter_release_host_range", "jinc_batch_set_affinity", "jinc_batch_device_cpus", "jinc_debug_numa_cpus", "jinc_debug_batch_set_registrars", "jinc_debug_batch_refused", "jinc_debug_host_registrations", "jinc_debug_last_call", "jinc_filter_direct_premise", "jinc_debug_valu_pair_probe", "jinc_debug_clock_sampler_start", "jinc_debug_clock_sampler_stop",
            "jinc_filter_submit", "jinc_filter_wait", "jinc_shard_device", "jinc_batch_create", "jinc_batch_devices",
            "jinc_batch_device_of_frame", "jinc_batch_process", "jinc_batch_free", "jinc_batch_last_error",
@@ -232,6 +232,11 @@ def copy_rows(dst: np.ndarray, src: np.ndarray, row_bytes: int, rows: int, helpe
     rc = lib().jinc_debug_copy_rows(dst.ctypes.data, dst.strides[0], src.ctypes.data, src.strides[0], int(row_bytes), int(rows), int(helpers))
     if rc != 0:
         raise JincError(rc, lib().jinc_last_error().decode())
+
+
+def usable_cpus() -> int:
+    """CPUs the process may keep busy as the library counts them (test header)."""
+    return int(lib().jinc_debug_usable_cpus())
 
 
 def staged_frames() -> int:

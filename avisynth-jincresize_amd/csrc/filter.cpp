@@ -169,6 +169,8 @@ int jinc_filter_release_host_range(jinc_filter* f, void* base, size_t bytes) {
 
 long long jinc_debug_staged_frames(void) { return staged_frames(); }
 
+int jinc_debug_usable_cpus(void) { return copy_lanes_cpus(); }
+
 int jinc_debug_copy_rows(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes, int rows, int may_use_helpers) {
     if (!dst || !src || rows < 0 || dst_pitch < row_bytes || src_pitch < row_bytes) return fail(JINC_ERR_INVALID_ARG, "JincResize: bad copy.");
     copy_plane_rows(static_cast<char*>(dst), dst_pitch, static_cast<const char*>(src), src_pitch, row_bytes, rows, may_use_helpers != 0);

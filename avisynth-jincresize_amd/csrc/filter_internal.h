@@ -317,7 +317,8 @@ struct PlaneCopy {
     size_t dst_pitch, src_pitch, row_bytes;
     int rows;
 };
-void copy_planes(const PlaneCopy* jobs, size_t njobs, bool may_use_helpers);  // several planes as ONE job for the lanes (the frames of a group's share)
+void copy_planes(const PlaneCopy* jobs, size_t njobs, bool may_use_helpers);
+int copy_lanes_cpus();  // CPUs the process may keep busy (affinity mask cut down to the cgroup's CFS quota): what the helper pool is sized by  // several planes as ONE job for the lanes (the frames of a group's share)
 long long staged_frames();  // frames whose results went through the library's own pinned buffers since the last reset of transport_counts
 
 }  // namespace host

@@ -141,6 +141,8 @@ int helpers_wanted() {
 
 }  // namespace
 
+int copy_lanes_cpus() { return usable_cpus(); }
+
 void copy_planes(const PlaneCopy* jobs, size_t njobs, bool may_use_helpers) {
     size_t total = 0;
     for (size_t j = 0; j < njobs; ++j) total += jobs[j].row_bytes * static_cast<size_t>(std::max(jobs[j].rows, 0));

@@ -208,6 +208,9 @@ JINC_API int jinc_debug_transport_counts(long long *by_shader, long long *by_dma
 JINC_API long long jinc_debug_staged_frames(void);
 /* host_copy.cpp's plane copy (rows of row_bytes bytes between two pitched buffers, cut into row ranges for the process-wide helper
  * threads when may_use_helpers and the plane is large): needs no device. */
+/* CPUs the process may keep busy as host_copy.cpp counts them (affinity mask, cut down to the CFS quota of the process's cgroup):
+ * what the helper pool of the plane copies is sized by. */
+JINC_API int jinc_debug_usable_cpus(void);
 JINC_API int jinc_debug_copy_rows(void *dst, size_t dst_pitch, const void *src, size_t src_pitch, size_t row_bytes, int rows,
                                   int may_use_helpers);
 /* Border frame of exactly periodic plans: -1 (default) = by call size (strip kernels from ~5e9 taps per call on, one gather

@@ -313,3 +313,19 @@ def test_plane_copies_on_the_helper_threads_move_every_row_and_nothing_else(pkg)
     assert not errors, errors[:1]
     with pytest.raises(pkg.JincError):
         pkg.copy_rows(np.zeros((4, 8), np.uint8), np.zeros((4, 16), np.uint8), 12, 4)   # rows longer than the destination's pitch
+
+
+def test_the_helper_pool_is_sized_by_the_cpus_the_process_may_use(pkg):
+    """host_copy.cpp counts the affinity mask cut down to the cgroup's CFS quota (a container with 256 CPUs in its mask and a
+    quota of 16 cores is throttled as a whole beyond 16 busy threads); bench.py's cpu_quota() reads the same files independently."""
+    import bench
+    mask = len(os.sched_getaffinity(0))
+    quota = bench.cpu_quota()["quota_cores"]
+    want = mask if not quota else max(1, min(mask, int(quota + 0.5)))
+    assert pkg.usable_cpus() == want, (pkg.usable_cpus(), mask, quota)
+
+
+@pytest.mark.gpu
+def test_the_helper_pool_is_sized_by_the_cpus_the_process_may_use_on_the_gpu_box(gpu_pkg):
+    """The same check where the cgroup has a quota (the pool's boxes: 256 CPUs in the mask, 16 cores of quota)."""
+    test_the_helper_pool_is_sized_by_the_cpus_the_process_may_use(gpu_pkg)
