@@ -329,3 +329,32 @@ def test_the_helper_pool_is_sized_by_the_cpus_the_process_may_use(pkg):
 def test_the_helper_pool_is_sized_by_the_cpus_the_process_may_use_on_the_gpu_box(gpu_pkg):
     """The same check where the cgroup has a quota (the pool's boxes: 256 CPUs in the mask, 16 cores of quota)."""
     test_the_helper_pool_is_sized_by_the_cpus_the_process_may_use(gpu_pkg)
+
+
+@pytest.mark.gpu
+def test_four_client_threads_share_the_helper_pool(gpu_pkg, O):
+    """Prefetch(4) at look-ahead 1: four instances on four threads, synchronous frames with planes large enough for the helper
+    threads -- one pool for the process, every caller takes part in its own copies."""
+    import threading
+    fmt, sw, sh, tw, th = "Y8", 1280, 720, 2560, 1440
+    of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
+    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=300 + k) for k in range(4)]
+    want = [of.get_frame(s, threads=8) for s in srcs]
+    errors = []
+
+    def client(k):
+        try:
+            f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
+            for rnd in range(12):
+                j = (k + rnd) % 4
+                assert_planes_equal(f.get_frame(srcs[j]), want[j], f.out_dims(), what=f"thread {k} round {rnd}")
+            f.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=client, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:1]
