@@ -372,9 +372,10 @@ int jinc_debug_convert(const float* sums, void* out, int n, int sample_bytes, fl
         void* d_out = nullptr;
         hip_check(hipMalloc(&d_in, sizeof(float) * (n + 1)), "hipMalloc");
         hip_check(hipMalloc(&d_out, static_cast<size_t>(sample_bytes) * (n + 1)), "hipMalloc");
-        hip_check(hipMemcpy(d_in, sums, sizeof(float) * n, hipMemcpyHostToDevice), "hipMemcpy");
+        bounce_upload(d_in, sums, sizeof(float) * n, "upload of the sums");
         hip_check(static_cast<hipError_t>(jinc::launch_debug_convert(d_in, d_out, n, sample_bytes, peak, nullptr)), "convert launch");
-        hip_check(hipMemcpy(out, d_out, static_cast<size_t>(sample_bytes) * n, hipMemcpyDeviceToHost), "hipMemcpy");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        bounce_download(out, d_out, static_cast<size_t>(sample_bytes) * n, "download of the samples");
         (void)hipFree(d_in);
         (void)hipFree(d_out);
     });

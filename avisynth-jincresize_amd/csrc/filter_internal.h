@@ -319,6 +319,9 @@ struct PlaneCopy {
 };
 void copy_planes(const PlaneCopy* jobs, size_t njobs, bool may_use_helpers);
 int copy_lanes_cpus();  // CPUs the process may keep busy (affinity mask cut down to the cgroup's CFS quota): what the helper pool is sized by  // several planes as ONE job for the lanes (the frames of a group's share)
+// device_plan.cpp: host <-> device copies through the library's pinned bounce buffer (synchronous; test hooks, plan tables)
+void bounce_upload(void* dev, const void* host, size_t bytes, const char* what);
+void bounce_download(void* host, const void* dev, size_t bytes, const char* what);
 long long staged_frames();  // frames whose results went through the library's own pinned buffers since the last reset of transport_counts
 
 }  // namespace host

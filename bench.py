@@ -676,6 +676,21 @@ def e2e_batch_record(pkg, config, ndevices, seconds=2.0, streams=32, pin_mode=0)
     return rec
 
 
+def through_pinned_to_device(torch, t):
+    """A torch CPU tensor on the device through pinned memory of torch's own.  Plain `.to("cuda")` / `.cpu()` hand heap pages of this
+    process to the HIP runtime, which maps them into the device behind the copy: the path round 6's unexplained GPU memory access
+    faults came from (once inside torch's own `tensor.cpu()`; profiles/round6/README.md).  The bench keeps its own copies off it."""
+    pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pinned.copy_(t.contiguous())
+    return pinned.to("cuda")
+
+
+def through_pinned_to_host(torch, t):
+    pinned = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pinned.copy_(t)
+    return pinned.clone()
+
+
 def lcg_planes(fmt, w, h, seed=12345):
     """SURVEY.md Appendix A item 4, the synthetic frame every known answer of tests/golden/kat.json was recorded on: one 32-bit
     LCG stream (s = s * 1664525 + 1013904223, r = s >> 8) over the planes in processing order, rows without padding.  Own
@@ -745,7 +760,7 @@ def self_check(torch, config, fmt, dst_t, ddims):
         for t, (w, h) in zip(dst_t, ddims):
             if t.dtype == torch.uint16:
                 t = t.view(torch.int16)
-            host = t[pos, :h, :w].contiguous().cpu().numpy()
+            host = through_pinned_to_host(torch, t[pos, :h, :w].contiguous()).numpy()
             c = zlib.crc32(host.tobytes(), c)
             nbytes += host.nbytes
         got[pos] = f"{c & 0xFFFFFFFF:08x}"
@@ -788,7 +803,7 @@ def make_workload(pkg, torch, config, frames, device, seed, lcg_first=False):
         import numpy as np
         for t, plane, (w, h) in zip(src_t, lcg_planes(fmt, sw, sh), sdims):
             host = np.ascontiguousarray(plane)
-            dev_plane = torch.from_numpy(host.view(np.int16) if sb == 2 else host).to("cuda")
+            dev_plane = through_pinned_to_device(torch, torch.from_numpy(host.view(np.int16) if sb == 2 else host))
             for pos in check_positions(frames):
                 if sb == 2:
                     t.view(torch.int16)[pos, :h, :w] = dev_plane

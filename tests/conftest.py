@@ -113,6 +113,26 @@ def _knobs_do_not_outlive_a_test():
         assert (left, live) == (0, 0), f"after the test the registry still holds {left} host range(s); hipHostRegister calls not undone: {live}"
 
 
+def to_device(t):
+    """A torch CPU tensor on the device, through pinned memory of torch's own (hipHostMalloc).  Plain `.cuda()` / `.cpu()` hand the
+    process's heap pages to the HIP runtime, which maps them into the device behind the copy -- the path the round-6 GPU memory
+    access faults came from, once inside torch's own `tensor.cpu()` with the library idle (profiles/round6/README.md).  The test
+    harness keeps its own copies off that path; what the LIBRARY does with pageable planes is tests/test_pin_modes.py's subject."""
+    import torch as _torch
+    t = t.contiguous()
+    pinned = _torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pinned.copy_(t)
+    return pinned.to("cuda")
+
+
+def to_host(t):
+    """A device tensor as a (pageable) CPU tensor, through pinned memory of torch's own -- see to_device."""
+    import torch as _torch
+    pinned = _torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    pinned.copy_(t)
+    return pinned.clone()
+
+
 def crop_planes(planes, dims):
     return [np.ascontiguousarray(p[:h, :w]) for p, (w, h) in zip(planes, dims)]
 

@@ -6,7 +6,7 @@ and in device batches; the gather kernel stays the fallback where the direct ker
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -79,7 +79,7 @@ def test_device_batch_with_tight_pitch(gpu_pkg, O, fmt, sw, expect):
     assert f.plan_info().quasi == 1 and f.plan_info().periodic == 0
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=1200 + i) for i in range(n)]
     host = np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])
-    src = torch.from_numpy(host).cuda().contiguous()
+    src = to_device(torch.from_numpy(host)).contiguous()
     dst = torch.zeros((n, th, tw), dtype=src.dtype, device="cuda")
     sb = host.dtype.itemsize
     stream = torch.cuda.current_stream()
@@ -89,7 +89,7 @@ def test_device_batch_with_tight_pitch(gpu_pkg, O, fmt, sw, expect):
     f.process_device([src.data_ptr()], [sw * sb], [sw * sh * sb], [dst.data_ptr()], [tw * sb], [tw * th * sb], n, stream=stream.cuda_stream)
     stream.synchronize()
     assert f.last_kernel(0) == (expect if sb == 1 else RUNS)
-    out = dst.cpu().numpy()
+    out = to_host(dst).numpy()
     for i in range(n):
         want = of.get_frame(frames[i], threads=4)
         assert np.array_equal(out[i].view(np.uint32) if sb == 4 else out[i], want[0][:th, :tw].view(np.uint32) if sb == 4 else want[0][:th, :tw]), f"frame {i}"
@@ -152,7 +152,7 @@ def test_batches_take_the_border_frame_to_the_framelane_kernel(gpu_pkg, O, fmt, 
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=5200 + i) for i in range(n)]
     host = np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])
     sb = host.dtype.itemsize
-    src = torch.from_numpy(host.view(np.int16) if sb == 2 else host).cuda().contiguous()
+    src = to_device(torch.from_numpy(host.view(np.int16) if sb == 2 else host)).contiguous()
     outs = {}
     for mode in (14, 1):
         dst = torch.zeros((n, th, tw), dtype=src.dtype, device="cuda")
@@ -160,7 +160,7 @@ def test_batches_take_the_border_frame_to_the_framelane_kernel(gpu_pkg, O, fmt, 
         stream = torch.cuda.current_stream()
         f.process_device([src.data_ptr()], [sw * sb], [sw * sh * sb], [dst.data_ptr()], [tw * sb], [tw * th * sb], n, stream=stream.cuda_stream)
         stream.synchronize()
-        outs[mode] = dst.cpu().numpy().view(host.dtype if sb != 4 else np.uint32)
+        outs[mode] = to_host(dst).numpy().view(host.dtype if sb != 4 else np.uint32)
         assert f.last_kernel(0) == (RUNS if mode == 14 else "ewa_gather_kernel")
     assert np.array_equal(outs[14], outs[1])
     for i in (0, min(63, n // 2), n - 1):

@@ -6,7 +6,7 @@ is in test_strip_kernel.py / test_benchmarked_instances.py."""
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -83,7 +83,7 @@ def test_edge_columns_write_nothing_outside_their_plane(gpu_pkg, O):
     f.set_border_strips(4)
     f.set_kernel_mode(gpu_pkg.KernelMode.QUAD)
     srcs = [O.lcg_frame(ofmt, sw, sh, seed=60 + k) for k in range(n)]
-    src_t = torch.stack([torch.from_numpy(s[0]) for s in srcs]).cuda()
+    src_t = to_device(torch.stack([torch.from_numpy(s[0]) for s in srcs]))
     pitch, rows = 640, th + 5
     dst_t = torch.full((n, rows, pitch), 0xA5, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
@@ -91,7 +91,7 @@ def test_edge_columns_write_nothing_outside_their_plane(gpu_pkg, O):
                      stream=stream.cuda_stream)
     stream.synchronize()
     assert f.last_border(0) & 64, f.last_border(0)
-    out = dst_t.cpu().numpy()
+    out = to_host(dst_t).numpy()
     f.close()
     for k in range(n):
         want = of.get_frame(srcs[k], threads=8)[0][:th, :tw]

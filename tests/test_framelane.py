@@ -5,7 +5,7 @@
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 from test_gpu_parity import SMALL_CASES, _id, _random_case, _random_case_v2, _random_case_v3, _SWEEP
 
 pytestmark = pytest.mark.gpu
@@ -71,7 +71,7 @@ def test_batches_of_frames(gpu_pkg, O, case):
         return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
 
     for n in sizes:
-        src_t = [torch.stack([to_t(fr[i]) for fr in frames[:n]]).cuda() for i in range(gfmt.planes)]
+        src_t = [to_device(torch.stack([to_t(fr[i]) for fr in frames[:n]])) for i in range(gfmt.planes)]
         dst_t = [torch.zeros((n, h, (w * sb + 63) // 64 * 64 // sb), dtype=tdtype, device="cuda") for (w, h) in ddims]
         # automatic from 16 frames, from 24 for filter sizes above 9 -- except drifting plans the direct kernel's runs form takes
         # (1.5x with tap 8: since round 3 the frame-lane kernel is never their automatic choice below 17 phases)
@@ -88,7 +88,7 @@ def test_batches_of_frames(gpu_pkg, O, case):
         small_rest = n > 128 and 0 < n % 128 < 2   # (automatic mode: n >= 24; from 2 frames the sub-group form of the frame-lane kernel)
         assert f.last_kernel(0).startswith("ewa_gather" if small_rest else "ewa_framelane"), (n, f.last_kernel(0))
         for k in range(n):
-            got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
+            got = [to_host(dst_t[i][k]).numpy().view(np_dtype) for i in range(gfmt.planes)]
             assert_planes_equal(got, wants[k], ddims, what=f"batch {n} frame {k}")
     f.close()
 
@@ -113,10 +113,10 @@ def test_full_size_batch(gpu_pkg, O):
         stream.synchronize()
         if mode == 0:
             assert f.last_kernel(0) == "ewa_framelane_win1k_kernel", f.last_kernel(0)  # 1024 threads, 32 x 32 tiles
-        outs.append(dst[:, :, :tw].cpu().numpy())
+        outs.append(to_host(dst[:, :, :tw]).numpy())
     assert np.array_equal(outs[0], outs[1])
     for k in (0, 31, 64, 68):
-        frame = [np.ascontiguousarray(src[k].cpu().numpy())]
+        frame = [np.ascontiguousarray(to_host(src[k]).numpy())]
         want = of.get_frame(frame, threads=16)[0][:th, :tw]
         assert np.array_equal(outs[0][k], want), f"frame {k}"
     f.close()
@@ -129,7 +129,7 @@ def test_unaligned_destination_takes_the_sample_stores(gpu_pkg, O):
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=50 + i) for i in range(n)]
-    src_t = torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]).cuda()
+    src_t = to_device(torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]))
     for pitch, offset in ((139, 0), (140, 1), (141, 3)):
         buf = torch.full((n * th * pitch + 8,), 0xAB, dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream()
@@ -137,7 +137,7 @@ def test_unaligned_destination_takes_the_sample_stores(gpu_pkg, O):
                          [th * pitch], n, stream=stream.cuda_stream)
         stream.synchronize()
         assert f.last_kernel(0).startswith("ewa_framelane")
-        out = buf.cpu().numpy()
+        out = to_host(buf).numpy()
         body = out[offset:offset + n * th * pitch].reshape(n, th, pitch)
         for k in range(n):
             want = of.get_frame(frames[k], threads=4)[0][:th, :tw]
@@ -184,7 +184,7 @@ def test_randomised_arguments_through_the_framelane_kernel(gpu_pkg, O, seed, gen
             a = np.ascontiguousarray(a)
             return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
 
-        src_t = [torch.stack([to_t(fr[i]) for fr in frames]).cuda() for i in range(gfmt.planes)]
+        src_t = [to_device(torch.stack([to_t(fr[i]) for fr in frames])) for i in range(gfmt.planes)]
         dst_t = [torch.zeros((n, h, (w * sb + 63) // 64 * 64 // sb), dtype=tdtype, device="cuda") for (w, h) in f.out_dims()]
         stream = torch.cuda.current_stream()
         f.process_device([t.data_ptr() for t in src_t], [t.stride(1) * sb for t in src_t], [t.stride(0) * sb for t in src_t],
@@ -192,6 +192,6 @@ def test_randomised_arguments_through_the_framelane_kernel(gpu_pkg, O, seed, gen
                          n, stream=stream.cuda_stream)
         stream.synchronize()
         for k in range(n):
-            got = [dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)]
+            got = [to_host(dst_t[i][k]).numpy().view(np_dtype) for i in range(gfmt.planes)]
             assert_planes_equal(got, wants[k], f.out_dims(), what=what + f" batch frame {k}")
     f.close()

@@ -6,7 +6,7 @@ case and the seeded argument sweeps."""
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 from test_gpu_parity import SMALL_CASES, _id, _random_case, _random_case_v2, _random_case_v3, _SWEEP
 
 pytestmark = pytest.mark.gpu
@@ -24,7 +24,7 @@ def _run_batch(torch, gpu_pkg, f, gfmt, frames, n, mode, pad=64):
         a = np.ascontiguousarray(a)
         return torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a)
 
-    src_t = [torch.stack([to_t(fr[i]) for fr in frames[:n]]).cuda() for i in range(gfmt.planes)]
+    src_t = [to_device(torch.stack([to_t(fr[i]) for fr in frames[:n]])) for i in range(gfmt.planes)]
     dst_t = [torch.zeros((n, h, (w * sb + pad - 1) // pad * pad // sb), dtype=tdtype, device="cuda") for (w, h) in f.out_dims()]
     f.set_kernel_mode(mode)
     stream = torch.cuda.current_stream()
@@ -32,7 +32,7 @@ def _run_batch(torch, gpu_pkg, f, gfmt, frames, n, mode, pad=64):
                      [t.data_ptr() for t in dst_t], [t.stride(1) * sb for t in dst_t], [t.stride(0) * sb for t in dst_t],
                      n, stream=stream.cuda_stream)
     stream.synchronize()
-    return [[dst_t[i][k].cpu().numpy().view(np_dtype) for i in range(gfmt.planes)] for k in range(n)]
+    return [[to_host(dst_t[i][k]).numpy().view(np_dtype) for i in range(gfmt.planes)] for k in range(n)]
 
 
 BATCH_CASES = [
@@ -107,10 +107,10 @@ def test_full_size_batch(gpu_pkg, O):
         stream.synchronize()
         if mode == 0:  # 128 frames on the pair form, the remaining 3 as a call of their own (the frame-lane kernel's sub-group form)
             assert f.last_kernel(0) == "ewa_framelane_sub_kernel", f.last_kernel(0)
-        outs.append(dst[:, :, :tw].cpu().numpy())
+        outs.append(to_host(dst[:, :, :tw]).numpy())
     assert np.array_equal(outs[0], outs[1])
     for k in (0, 63, 127, 130):
-        frame = [np.ascontiguousarray(src[k].cpu().numpy())]
+        frame = [np.ascontiguousarray(to_host(src[k]).numpy())]
         want = of.get_frame(frame, threads=16)[0][:th, :tw]
         assert np.array_equal(outs[0][k], want), f"frame {k}"
     f.close()
@@ -124,7 +124,7 @@ def test_unaligned_destination_takes_the_sample_stores(gpu_pkg, O):
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     f.set_kernel_mode(12)
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=150 + i) for i in range(n)]
-    src_t = torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]).cuda()
+    src_t = to_device(torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]))
     for pitch, offset in ((139, 0), (140, 1), (141, 3)):
         buf = torch.full((n * th * pitch + 8,), 0xAB, dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream()
@@ -132,7 +132,7 @@ def test_unaligned_destination_takes_the_sample_stores(gpu_pkg, O):
                          [th * pitch], n, stream=stream.cuda_stream)
         stream.synchronize()
         assert f.last_kernel(0) == PAIR
-        out = buf.cpu().numpy()
+        out = to_host(buf).numpy()
         body = out[offset:offset + n * th * pitch].reshape(n, th, pitch)
         for k in range(n):
             want = of.get_frame(frames[k], threads=4)[0][:th, :tw]

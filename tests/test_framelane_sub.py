@@ -6,7 +6,7 @@ for what a batch leaves beyond whole groups of 64, unaligned destinations."""
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 from test_framelane_pair import _run_batch
 
 pytestmark = pytest.mark.gpu
@@ -74,7 +74,7 @@ def test_unaligned_destination(gpu_pkg, O):
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     f.set_kernel_mode(16)
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=50 + i) for i in range(n)]
-    src_t = torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]).cuda()
+    src_t = to_device(torch.stack([torch.from_numpy(np.ascontiguousarray(fr[0])) for fr in frames]))
     for pitch, offset in ((139, 0), (140, 1), (141, 3), (140, 0)):
         buf = torch.full((n * th * pitch + 8,), 0xAB, dtype=torch.uint8, device="cuda")
         stream = torch.cuda.current_stream()
@@ -82,7 +82,7 @@ def test_unaligned_destination(gpu_pkg, O):
                          [th * pitch], n, stream=stream.cuda_stream)
         stream.synchronize()
         assert f.last_kernel(0) == "ewa_framelane_sub_kernel"
-        out = buf.cpu().numpy()
+        out = to_host(buf).numpy()
         body = out[offset:offset + n * th * pitch].reshape(n, th, pitch)
         for k in range(n):
             want = of.get_frame(frames[k], threads=4)[0][:th, :tw]

@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -212,7 +212,7 @@ def test_device_batch_path(gpu_pkg, O):
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     sdims, ddims = gpu_pkg.FORMATS[fmt].plane_dims(sw, sh), f.out_dims()
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=100 + i) for i in range(n)]
-    src_t = [torch.stack([torch.from_numpy(np.ascontiguousarray(fr[i])) for fr in frames]).cuda() for i in range(3)]
+    src_t = [to_device(torch.stack([torch.from_numpy(np.ascontiguousarray(fr[i])) for fr in frames])) for i in range(3)]
     dst_t = [torch.zeros((n, h, (w + 63) // 64 * 64), dtype=torch.uint8, device="cuda") for (w, h) in ddims]
     stream = torch.cuda.current_stream()
     f.process_device([t.data_ptr() for t in src_t], [t.stride(1) for t in src_t], [t.stride(0) for t in src_t],
@@ -221,7 +221,7 @@ def test_device_batch_path(gpu_pkg, O):
     stream.synchronize()
     for k in range(n):
         want = of.get_frame(frames[k], threads=4)
-        got = [dst_t[i][k].cpu().numpy() for i in range(3)]
+        got = [to_host(dst_t[i][k]).numpy() for i in range(3)]
         assert_planes_equal(got, want, ddims, what=f"frame {k}")
     f.close()
 
@@ -475,13 +475,13 @@ def test_direct_kernel_wide_walk_on_a_batch(gpu_pkg, O):
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=77 + i) for i in range(n)]
-    src = torch.from_numpy(np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])).cuda().contiguous()
+    src = to_device(torch.from_numpy(np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames]))).contiguous()
     dst = torch.zeros((n, th, tw), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
     f.process_device([src.data_ptr()], [sw], [sw * sh], [dst.data_ptr()], [tw], [tw * th], n, stream=stream.cuda_stream)
     stream.synchronize()
     assert gpu_pkg.last_direct_shape() == 3
-    out = dst.cpu().numpy()
+    out = to_host(dst).numpy()
     for i in (0, n - 1):
         want = of.get_frame(frames[i], threads=8)
         assert zlib.crc32(out[i].tobytes()) == zlib.crc32(np.ascontiguousarray(want[0][:th, :tw]).tobytes()), f"frame {i}"
@@ -499,13 +499,13 @@ def test_direct_kernel_tight_pitch_device_batch(gpu_pkg, O, sw):
     assert f.plan_info().periodic == 1 and f.plan_info().step_x == 2
     n = 5
     frames = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=900 + i) for i in range(n)]
-    src = torch.from_numpy(np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames])).cuda().contiguous()
+    src = to_device(torch.from_numpy(np.stack([np.ascontiguousarray(fr[0][:sh, :sw]) for fr in frames]))).contiguous()
     dst = torch.zeros((n, th, tw), dtype=torch.uint8, device="cuda")
     assert src.stride(1) == sw and dst.stride(1) == tw                    # pitch == row size
     stream = torch.cuda.current_stream()
     f.process_device([src.data_ptr()], [sw], [sw * sh], [dst.data_ptr()], [tw], [tw * th], n, stream=stream.cuda_stream)
     stream.synchronize()
-    out = dst.cpu().numpy()
+    out = to_host(dst).numpy()
     for i in range(n):
         want = of.get_frame(frames[i], threads=4)
         assert np.array_equal(out[i], want[0][:th, :tw]), f"frame {i}"
@@ -571,11 +571,11 @@ def test_plane_ending_on_a_page_boundary(gpu_pkg, O, fmt, slacks):
         off = (-(pool.data_ptr() + nbytes + slack)) % 4096
         view = pool[off:off + nbytes]
         assert (view.data_ptr() + nbytes + slack) % 4096 == 0 and view.data_ptr() % sb == 0
-        view.copy_(torch.from_numpy(plane.view(np.uint8).reshape(-1)))
+        view.copy_(to_device(torch.from_numpy(plane.view(np.uint8).reshape(-1))))
         dst.zero_()
         f.process_device([view.data_ptr()], [sw * sb], [0], [dst.data_ptr()], [tw * sb], [0], 1, stream=stream.cuda_stream)
         stream.synchronize()
-        got = dst.cpu().numpy().view(ofmt.dtype)
+        got = to_host(dst).numpy().view(ofmt.dtype)
         assert np.array_equal(got, want), f"slack {slack} (base % 4 = {view.data_ptr() % 4})"
     f.close()
 

@@ -4,6 +4,8 @@ every interior kernel family, single frames and batches, tight and padded pitche
 import numpy as np
 import pytest
 
+from conftest import to_device, to_host
+
 pytestmark = pytest.mark.gpu
 
 CASES = [
@@ -41,7 +43,7 @@ def test_nothing_outside_the_rows_is_written(gpu_pkg, O, case, pad):
         for i, (w, h) in enumerate(sdims):
             plane = np.zeros((h, sp[i]), np.uint8)
             plane[:, :w * sb] = np.ascontiguousarray(frame[i][:h, :w]).view(np.uint8).reshape(h, w * sb)
-            srcs.append(torch.from_numpy(np.tile(plane.reshape(-1), n)).cuda())
+            srcs.append(to_device(torch.from_numpy(np.tile(plane.reshape(-1), n))))
         # destination: [guard] plane 0 frames [guard] plane 1 frames [guard] ...
         if pad >= 0:
             dp = [(w * sb + 3) // 4 * 4 + pad for (w, h) in ddims]
@@ -57,7 +59,7 @@ def test_nothing_outside_the_rows_is_written(gpu_pkg, O, case, pad):
         stream = torch.cuda.current_stream()
         f.process_device([s.data_ptr() for s in srcs], sp, sfs, [dst.data_ptr() + o for o in offs], dp, dfs, n, stream=stream.cuda_stream)
         stream.synchronize()
-        out = dst.cpu().numpy()
+        out = to_host(dst).numpy()
         first = None
         for i, (w, h) in enumerate(ddims):
             region = np.stack([out[offs[i] + k * dfs[i]:offs[i] + k * dfs[i] + h * dp[i]].reshape(h, dp[i]) for k in range(n)])

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -124,14 +124,14 @@ def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframe
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     rng = np.random.default_rng(nframes)
     host = rng.integers(0, 256, (nframes, sh, 256), dtype=np.uint8)
-    src = torch.from_numpy(host).cuda()
+    src = to_device(torch.from_numpy(host))
     dst = torch.zeros((nframes, th, 256), dtype=torch.uint8, device="cuda")
     f.process_device([src.data_ptr()], [256], [sh * 256], [dst.data_ptr()], [256], [th * 256], nframes)
     torch.cuda.synchronize()
     r = nframes % 128
     # (r = 1: gather kernel; 2 .. 48: the frame-lane kernel's sub-group form -- kernel_framelane_sub.hip)
     assert f.last_kernel(0) == ("ewa_gather_kernel" if r < 2 else "ewa_framelane_sub_kernel"), (r, f.last_kernel(0))
-    out = dst.cpu().numpy()
+    out = to_host(dst).numpy()
     for k in (0, 127, 128, nframes - 1, nframes // 2):
         want = of.get_frame([host[k]])
         assert np.array_equal(out[k][:, :tw], want[0][:th, :tw]), f"frame {k} of {nframes}"

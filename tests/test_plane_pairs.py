@@ -5,7 +5,7 @@ layout must give the oracle's bits."""
 import numpy as np
 import pytest
 
-from conftest import oracle_kwargs
+from conftest import oracle_kwargs, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -55,12 +55,12 @@ def test_planes_of_one_buffer(gpu_pkg, O, case, layout):
     for i, (w, h) in enumerate(sdims):
         plane = np.zeros((h, sp[i]), np.uint8)
         plane[:, :w * sb] = np.ascontiguousarray(frame[i][:h, :w]).view(np.uint8).reshape(h, w * sb)
-        src[so[i]:so[i] + h * sp[i]] = torch.from_numpy(plane.reshape(-1)).cuda()
+        src[so[i]:so[i] + h * sp[i]] = to_device(torch.from_numpy(plane.reshape(-1)))
     stream = torch.cuda.current_stream()
     f.process_device([src.data_ptr() + o for o in so], sp, [0] * len(sp), [dst.data_ptr() + o for o in do], dp, [0] * len(dp), 1,
                      stream=stream.cuda_stream)
     stream.synchronize()
-    out = dst.cpu().numpy()
+    out = to_host(dst).numpy()
     for i, (w, h) in enumerate(ddims):
         got = out[do[i]:do[i] + h * dp[i]].reshape(h, dp[i])[:, :w * sb]
         exp = np.ascontiguousarray(want[i][:h, :w]).view(np.uint8).reshape(h, w * sb)
