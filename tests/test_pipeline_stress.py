@@ -31,18 +31,32 @@ def test_many_frames_through_changing_pipeline_shapes(gpu_pkg, O, case, pooling_
     for depth, group, register in SHAPES:
         f.set_pipeline(depth, register, group)
         rng = np.random.default_rng(depth * 1000 + group)
-        dsts = [[gpu_pkg.alloc_plane(w, h, np_dtype) for (w, h) in dims] for _ in range(n)]
+        # Registered shapes: the frames go through a POOL of depth + 2 buffer sets (source planes copied in, as a host's frame pool
+        # would hand them out), so that a shape registers a few dozen planes once instead of 960 planes through a cache of 64 --
+        # this test is after ordering, and every registration is a fresh mapping of heap pages into the device (tests/conftest.py).
+        nb = depth + 2 if register else n
+        dsts = [[gpu_pkg.alloc_plane(w, h, np_dtype) for (w, h) in dims] for _ in range(nb)]
+        pool_srcs = [[np.empty_like(p) for p in srcs[0]] for _ in range(nb)] if register else None
         tickets, waiting, bad = {}, [], []
 
         def collect(j):
             f.wait(tickets[j])
+            got = dsts[j % nb]
             for i, (w, h) in enumerate(dims):
-                if not np.array_equal(dsts[j][i][:h, :w], want[j][i][:h, :w]):
-                    rows = np.nonzero(np.any(dsts[j][i][:h, :w] != want[j][i][:h, :w], axis=1))[0]
+                if not np.array_equal(got[i][:h, :w], want[j][i][:h, :w]):
+                    rows = np.nonzero(np.any(got[i][:h, :w] != want[j][i][:h, :w], axis=1))[0]
                     bad.append((j, i, int(rows[0]), int(rows[-1]), len(rows)))
 
         for k in range(n):
-            tickets[k] = f.submit(srcs[k], dsts[k])
+            if k - nb in waiting:      # the buffer set this frame takes is still out: its frame is collected first
+                waiting.remove(k - nb)
+                collect(k - nb)
+            src = srcs[k]
+            if register:
+                src = pool_srcs[k % nb]
+                for a, b in zip(src, srcs[k]):
+                    a[...] = b
+            tickets[k] = f.submit(src, dsts[k % nb])
             waiting.append(k)
             if k % 37 == 36:
                 f.flush()
