@@ -35,13 +35,13 @@ def _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs):
     (A137, 64, 64, "ewa_framelane_win"),
     (N15T8, 64, 32, "ewa_direct_runs_kernel"),   # 1.5x with tap 8: since round 3 the runs form of the direct kernel, also in batches
 ], ids=["A137_auto", "A137_g64", "N15T8_g32"])
-def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg, O, case, depth, group, kernels, pooling_host):
+def test_64_frames_through_submit_and_wait_run_on_the_framelane_kernels(gpu_pkg, O, case, depth, group, kernels):
     fmt, sw, sh, tw, th, kw = case
     n = 64
     srcs = _frames(O, fmt, sw, sh, n, 7000)
     ref = _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0, **kw)
-    f.set_pipeline(depth, True, group)
+    f.set_pipeline(depth, False, group)   # (pageable planes, the default: this test is about the launches)
     assert f.pipeline_group == (group or (depth // 2 if depth >= 8 else 1))
     dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
     tickets = [f.submit(srcs[k], dsts[k]) for k in range(n)]
@@ -66,9 +66,14 @@ def test_groups_of_every_fill_state_and_every_way_out(gpu_pkg, O, pooling_host):
     srcs = _frames(O, fmt, sw, sh, n, 8100)
     want = [of.get_frame(s, threads=4) for s in srcs]
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
-    for depth, group, register in ((32, 16, False), (32, 0, True), (8, 8, True), (5, 2, False), (1, 0, False), (40, 20, True)):
+    # (the registered shapes side by side and on the same planes: registered once for the three of them -- every registration is a
+    # fresh mapping of heap pages into the device, tests/conftest.py)
+    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
+    for depth, group, register in ((32, 16, False), (5, 2, False), (1, 0, False), (32, 0, True), (8, 8, True), (40, 20, True)):
         f.set_pipeline(depth, register, group)
-        dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
+        for d in dsts:
+            for plane in d:
+                plane[...] = 0xEE
         tickets = {}
         rng = np.random.default_rng(depth * 100 + group)
         waiting = []
@@ -144,14 +149,14 @@ def test_remainder_of_a_frame_pair_batch_is_chosen_on_its_own(gpu_pkg, O, nframe
     f.close()
 
 
-def test_batch_sharder_hands_each_device_groups(gpu_pkg, O, pooling_host):
+def test_batch_sharder_hands_each_device_groups(gpu_pkg, O):
     """jinc_batch_process with 64 frames in flight per device: the device's frames leave in groups of 32 on the frame-lane
     kernel; every frame equals the single-frame result."""
     fmt, sw, sh, tw, th, kw = "Y8", 320, 180, 438, 246, {}
     n = 150
     srcs = _frames(O, fmt, sw, sh, n, 9100)
     ref = _single_frame_results(gpu_pkg, fmt, sw, sh, tw, th, kw, srcs)
-    b = gpu_pkg.Batch(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, ndevices=0, streams=64, register_host_buffers=True)
+    b = gpu_pkg.Batch(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, ndevices=0, streams=64, register_host_buffers=False)
     outs = b.process(srcs)
     name, frames = gpu_pkg.last_call()
     assert name.startswith("ewa_framelane") and frames > 1, (name, frames)

@@ -384,11 +384,11 @@ def test_lookahead_ring_sequential_and_seek(host, O, depth, monkeypatch):
     (("Y8", 1280, 720, 1754, 986, "JincResize", {}), None, "ewa_framelane_sub_kernel"),   # no phase structure, fs 7: groups of 16 = four sub-groups per wave
     (("Y8", 1280, 720, 1920, 1080, "Jinc256Resize", {}), 32, "ewa_direct_runs_kernel"),   # 1.5x tap 8 (fs 17): one launch per group
 ], ids=["A137_lookahead32", "N15T8_lookahead32_group32"])
-def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, case, group, kernel, monkeypatch, pooling_host):
+def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, case, group, kernel, monkeypatch):
     """with JINCRESIZE_LOOKAHEAD=32 the plugin's per-frame GetFrame (ref :603-630) is served by coalesced
     launches -- the frame-lane kernels -- and every frame is still exactly that frame's result."""
     monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "32")
-    monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
+    monkeypatch.delenv("JINCRESIZE_PIN_FRAMES", raising=False)   # pageable frames, the default (pinned in place: tests/test_plugin_prefetch.py)
     if group:
         monkeypatch.setenv("JINCRESIZE_GROUP", str(group))
     fmt_name, sw, sh, tw, th, fn, named = case
@@ -402,7 +402,7 @@ def test_lookahead_32_reaches_the_batch_kernels_through_get_frame(host, O, pkg, 
     single.close()
     of = O.OracleFilter(fmt, sw, sh, tw, th, **oracle_kwargs(kw))
     h = Host(host)
-    host.mock_env_set_frame_pool(h.env, 4096)   # pinned in place: the host recycles frame buffers, it does not free them
+    host.mock_env_set_frame_pool(h.env, 4096)   # the host recycles frame buffers
     src = h.source(fmt, sw, sh, frames)
     clip, err = h.invoke(fn, src, tw, th, **named)
     assert err is None, err

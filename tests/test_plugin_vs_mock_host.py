@@ -294,13 +294,13 @@ def test_chroma_location_of_frame_zero_decides_when_cplace_is_not_given(vs, O, m
     (("Y8", 1280, 720, 1754, 986, "JincResize", {}), "ewa_framelane"),             # no phase structure: groups of 16 on the frame-lane kernels
     (("YUV420P8", 960, 540, 1920, 1080, "Jinc36Resize", {}), "ewa_periodic"),       # 2x: the periodic kernels' batch forms
 ], ids=["A137", "2x_420"])
-def test_lookahead_in_the_vapoursynth_shell(vs, O, pkg, case, kernel, monkeypatch, pooling_host):
+def test_lookahead_in_the_vapoursynth_shell(vs, O, pkg, case, kernel, monkeypatch):
     """JINCRESIZE_LOOKAHEAD=32 in the VapourSynth shell -- arInitial asks for n .. n + 31, arAllFramesReady
     (fmParallelRequests: one call at a time, any order) feeds the same window ring as the AviSynth shell.  Frames pulled in
     order, then out of order and again: each is that frame's single-call result (and the oracle's), launches are 16-frame
     batches, nothing leaks."""
     monkeypatch.setenv("JINCRESIZE_LOOKAHEAD", "32")
-    monkeypatch.setenv("JINCRESIZE_PIN_FRAMES", "1")
+    monkeypatch.delenv("JINCRESIZE_PIN_FRAMES", raising=False)   # pageable frames, the default
     monkeypatch.delenv("JINCRESIZE_GROUP", raising=False)
     fmt_name, sw, sh, tw, th, fn, named = case
     fmt = O.FORMATS[fmt_name]
