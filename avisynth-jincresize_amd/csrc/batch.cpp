@@ -246,6 +246,7 @@ void jinc_batch_free(jinc_batch* b) {
     if (!b) return;
     for (jinc_filter* f : b->filters) jinc_filter_free(f);  // (waits for frames in flight)
     for (const HostRange& r : b->pinned) {
+        std::lock_guard<std::mutex> one(jinc::knobs::host_registration_mutex());
         if (hipHostUnregister(r.base) == hipSuccess) jinc::knobs::count_host_registration(-1);
         else (void)hipGetLastError();  // (the sticky error must not meet the caller's next launch)
     }
@@ -339,7 +340,11 @@ int jinc_batch_process(jinc_batch* b, int nframes, const void* const* src_planes
                 const std::vector<HostRange>& todo = chunk_todo[static_cast<size_t>(c)];
                 std::vector<HostRange> done, refused;
                 for (const HostRange& rg : todo) {
-                    if (hipHostRegister(rg.base, rg.bytes, hipHostRegisterPortable) == hipSuccess) {
+                    // (one registration call at a time in the process: filter_internal.h host_registration_mutex)
+                    if ([&] {
+                            std::lock_guard<std::mutex> one(jinc::knobs::host_registration_mutex());
+                            return hipHostRegister(rg.base, rg.bytes, hipHostRegisterPortable);
+                        }() == hipSuccess) {
                         jinc::knobs::count_host_registration(+1);
                         done.push_back(rg);
                     }

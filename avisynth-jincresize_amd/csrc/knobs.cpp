@@ -35,6 +35,10 @@ std::atomic<long long> g_live_host_registrations{0};
 }
 void count_host_registration(int delta) { g_live_host_registrations += delta; }
 long long live_host_registrations() { return g_live_host_registrations.load(); }
+std::mutex& host_registration_mutex() {
+    static std::mutex& m = *new std::mutex;  // (leaked: instances may be freed while the process's statics are being destroyed)
+    return m;
+}
 
 bool is_set(int id) { return id >= 0 && id < JINC_KNOB_COUNT && g_slots[id].set.load(std::memory_order_acquire); }
 

@@ -2,6 +2,7 @@
 // The product's code never reads the environment for them: a knob is unset until a test, bench.py or a profiles/ script sets
 // it through jinc_debug_set_knob; every site that consults one names the default it uses while the knob is unset.
 #pragma once
+#include <mutex>
 #include "../../include/jincresize_hip_test.h"
 
 namespace jinc {
@@ -17,6 +18,11 @@ inline bool flag(int id, bool unset_value) { return is_set(id) ? get(id, 0.0) !=
 // registrars): registered - unregistered = host ranges the library holds pinned right now (test header: jinc_debug_host_registrations).
 void count_host_registration(int delta);
 long long live_host_registrations();
+// One hipHostRegister / hipHostUnregister call at a time, process-wide (pipeline.cpp's registry and batch.cpp's registrars take it
+// around each call).  Ranges of neighbouring buffers share pages (registrations cover exact bytes), and the one test that had four
+// threads register such neighbours side by side while the device worked through earlier ones is the one that ended in GPU memory
+// access faults twice in six runs (profiles/round6/README.md); none of the isolated probes reproduces it, so this is a precaution.
+std::mutex& host_registration_mutex();
 
 void set(int id, double value);
 void clear(int id);  // id < 0: every knob

@@ -106,7 +106,10 @@ bool shared_pin_acquire(char* c, size_t bytes, int device, unsigned long long* i
                 *id = e.id, *base = e.base, *len = e.bytes;
                 return true;
             }
-        if (hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess) {
+        if ([&] {
+                std::lock_guard<std::mutex> one(knobs::host_registration_mutex());
+                return hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+            }() == hipSuccess) {
             knobs::count_host_registration(+1);
             pin_registry().pins.push_back({pin_registry().next_id++, c, bytes, 1, true, false, dev_bit});
             *id = pin_registry().pins.back().id, *base = c, *len = bytes;
@@ -126,11 +129,18 @@ bool shared_pin_acquire(char* c, size_t bytes, int device, unsigned long long* i
     // outside the lock: other threads' acquires and releases go on while the devices drain
     for (const Stale& st : stale) {
         if (st.held) quiesce_devices(st.devices);  // (holders learn of it only at their next pin_host_range: nothing of theirs may still be in flight)
-        if (hipHostUnregister(st.base) == hipSuccess) knobs::count_host_registration(-1);
+        if ([&] {
+                std::lock_guard<std::mutex> one(knobs::host_registration_mutex());
+                return hipHostUnregister(st.base);
+            }() == hipSuccess)
+            knobs::count_host_registration(-1);
         (void)hipGetLastError();  // (it may already be gone with its memory: the sticky error must not meet the next launch)
     }
     bool owned = true;
-    const bool again = !stale.empty() && hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped) == hipSuccess;
+    const bool again = !stale.empty() && [&] {
+        std::lock_guard<std::mutex> one(knobs::host_registration_mutex());
+        return hipHostRegister(c, bytes, hipHostRegisterPortable | hipHostRegisterMapped);
+    }() == hipSuccess;
     if (again) knobs::count_host_registration(+1);
     if (!again) {
         (void)hipGetLastError();
@@ -175,6 +185,7 @@ void shared_pin_release(unsigned long long id) {
             }
         // (unregistered under the lock: a concurrent acquire of the same range must either find the entry or find the range free)
         if (unregister) {
+            std::lock_guard<std::mutex> one(knobs::host_registration_mutex());
             if (hipHostUnregister(unregister) == hipSuccess) knobs::count_host_registration(-1);
             else (void)hipGetLastError();
         }
