@@ -115,6 +115,39 @@ def _knobs_do_not_outlive_a_test():
         assert (left, live) == (0, 0), f"after the test the registry still holds {left} host range(s); hipHostRegister calls not undone: {live}"
 
 
+def fresh_mapping(nbytes):
+    """`nbytes` bytes in an anonymous mapping of their own (whole pages that hold nothing else).  The tests that let the device MAP
+    host memory (cached registrations, planes handed to the runtime) take their planes from here, as a video host's large frame
+    allocations are: planes carved out of the malloc heap share their first and last page with whatever else lives there -- the
+    HIP runtime's own structures included -- and every GPU memory access fault of round 6's later runs was on such a long-used heap
+    address (profiles/round6/README.md)."""
+    import mmap
+    return np.frombuffer(mmap.mmap(-1, max(int(nbytes), 1)), np.uint8)
+
+
+def fresh_copies(planes, align=64):
+    """Copies of `planes` (2-D arrays), one after the other in ONE fresh mapping, each start `align`-byte aligned."""
+    room = sum((p.nbytes + align - 1) // align * align for p in planes) + align
+    pool, out, off = fresh_mapping(room), [], 0
+    for p in planes:
+        v = pool[off:off + p.nbytes].view(p.dtype).reshape(p.shape)
+        v[...] = p
+        out.append(v)
+        off += (p.nbytes + align - 1) // align * align
+    return out
+
+
+def fresh_planes(dims, dtype, align=64):
+    """Zeroed planes of `dims` = [(w, h), ...] with rows padded to `align` bytes (as pkg.alloc_plane), in ONE fresh mapping."""
+    isz = np.dtype(dtype).itemsize
+    pitches = [(w * isz + align - 1) // align * align for (w, h) in dims]
+    pool, out, off = fresh_mapping(sum(p * h for p, (w, h) in zip(pitches, dims)) + align), [], 0
+    for p, (w, h) in zip(pitches, dims):
+        out.append(pool[off:off + p * h].view(dtype).reshape(h, p // isz))
+        off += p * h
+    return out
+
+
 def to_device(t):
     """A torch CPU tensor on the device, through pinned memory of torch's own (hipHostMalloc).  Plain `.cuda()` / `.cpu()` hand the
     process's heap pages to the HIP runtime, which maps them into the device behind the copy -- the path the round-6 GPU memory

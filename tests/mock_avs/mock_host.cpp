@@ -2,6 +2,7 @@
 // subset declared in tests/mock_avs/avisynth_c.h, plus a plain C interface (mock_*) through which
 // tests/test_plugin_mock_host.py loads plugin/jincresize_avs.cpp, invokes its script functions with positional and
 // named arguments, pulls frames and reads frame properties.  See the header for what this does and does not prove.
+#include <sys/mman.h>
 #include "avisynth_c.h"
 
 #include <atomic>
@@ -34,10 +35,14 @@ static inline int pt_sub_h(const AVS_VideoInfo* vi) { return (vi->pixel_type >> 
 // One allocation per frame, planes at 64-byte aligned offsets (as AviSynth+ lays frames out).  Buffers of frames made by
 // avs_new_video_frame_p come from -- and go back to -- the environment's frame pool (mock_env_set_frame_pool): every
 // filter instance of a script draws from the same pool, so the same host buffer reaches different instances in turn.
+// A frame buffer is an anonymous mapping of its own (whole pages that hold nothing else), as large frame allocations are in a real
+// host: a plugin that pins frame buffers in place (JINCRESIZE_PIN_FRAMES) then maps no page that somebody else's data lives in.
 struct FrameBuffer {
-    std::vector<unsigned char> bytes;
-    unsigned char* base = nullptr;  // 4096-byte aligned start inside `bytes`
-    size_t size = 0;
+    unsigned char* base = nullptr;  // page-aligned
+    size_t size = 0, mapped = 0;
+    ~FrameBuffer() {
+        if (base) munmap(base, mapped);
+    }
 };
 
 struct AVS_VideoFrame {
@@ -139,8 +144,15 @@ AVS_VideoFrame* make_frame(const AVS_VideoInfo* vi, int pitch_align, AVS_ScriptE
     }
     if (!f->buffer) {
         f->buffer = new FrameBuffer;
-        f->buffer->bytes.resize(total + 4096);
-        f->buffer->base = reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(f->buffer->bytes.data()) + 4095) / 4096 * 4096);
+        f->buffer->mapped = (total + 4095) / 4096 * 4096;
+        void* m = mmap(nullptr, f->buffer->mapped, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) {
+            delete f->buffer;
+            f->buffer = nullptr;
+            delete f;
+            return nullptr;
+        }
+        f->buffer->base = static_cast<unsigned char*>(m);
         f->buffer->size = total;
     }
     std::memset(f->buffer->base, 0xCD, total);

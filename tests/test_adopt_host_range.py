@@ -3,7 +3,7 @@ source and destination plane) tells the instance once; frames inside it travel l
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal
+from conftest import assert_planes_equal, fresh_mapping
 
 pytestmark = pytest.mark.gpu
 
@@ -89,7 +89,7 @@ def test_batch_registrar_on_one_contiguous_unaligned_pool_keeps_the_shader_trans
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
     spitch, dpitch = 320, 448
     per_frame = spitch * sh + dpitch * th
-    pool = np.zeros(n * per_frame + 8192, np.uint8)     # pageable: the registrar pins it
+    pool = fresh_mapping(n * per_frame + 8192)            # pageable, a mapping of its own: the registrar pins it
     off = 52
     srcs, dsts, frames = [], [], []
     for k in range(n):

@@ -40,13 +40,13 @@ def test_512_frames_sharded_over_the_visible_devices(gpu_pkg, O):
     assert len({_crc(o[0], tw, th) for o in outs}) == n        # 512 distinct inputs -> 512 distinct outputs
 
 
-def test_small_batches_and_stream_counts(gpu_pkg, O, pooling_host):
+def test_small_batches_and_stream_counts(gpu_pkg, O):
     """Batch sizes around the number of frames in flight (empty, fewer than streams, not a multiple), 4:2:0 planes."""
     fmt, sw, sh, tw, th = "YUV420P8", 160, 96, 320, 192
     ofmt = O.FORMATS[fmt]
     of = O.OracleFilter(ofmt, sw, sh, tw, th)
     for streams, n in ((1, 3), (2, 0), (2, 1), (3, 7), (16, 5)):
-        b = gpu_pkg.Batch(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, streams=streams, register_host_buffers=(streams == 3))
+        b = gpu_pkg.Batch(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, streams=streams)   # (pageable frames, the default: registering modes are tests/test_pin_modes.py's subject)
         frames = [O.lcg_frame(ofmt, sw, sh, seed=7 + k) for k in range(n)]
         outs = b.process(frames)
         for k in range(n):

@@ -10,7 +10,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
+from conftest import assert_planes_equal, fresh_copies, fresh_planes, oracle_kwargs, to_device, to_host
 
 pytestmark = pytest.mark.gpu
 
@@ -749,6 +749,9 @@ def test_frame_pipeline(gpu_pkg, O, register, pooling_host):
     n = 10
     srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=500 + k) for k in range(n)]
     dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
+    if register:   # planes the device maps come from mappings of their own (conftest.fresh_mapping)
+        srcs = [fresh_copies(s) for s in srcs]
+        dsts = [fresh_planes(f.out_dims(), np.uint8) for _ in range(n)]
     tickets = [None] * n
     for k in range(n):
         tickets[k] = f.submit(srcs[k], dsts[k])

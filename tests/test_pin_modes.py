@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal
+from conftest import assert_planes_equal, fresh_copies, fresh_planes
 
 
 def _case(O):
@@ -33,8 +33,8 @@ def test_pool_mode_keeps_registrations_and_leaving_it_gives_them_back(gpu_pkg, O
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     f.set_pipeline(8, gpu_pkg.PIN_POOL, 4)
     base_ranges = gpu_pkg.transport_counts(reset=True)[2]
-    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=70 + k) for k in range(8)]
-    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(8)]
+    srcs = [fresh_copies(O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=70 + k)) for k in range(8)]
+    dsts = [fresh_planes(f.out_dims(), np.uint8) for _ in range(8)]
     for rnd in range(3):
         tickets = [f.submit(s, d) for s, d in zip(srcs, dsts)]
         for t in tickets:
@@ -149,8 +149,8 @@ def test_runtime_mode_hands_pageable_planes_to_the_runtime(gpu_pkg, O, pooling_h
     fmt, sw, sh, tw, th, of = _case(O)
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     f.set_pipeline(8, gpu_pkg.PIN_RUNTIME, 4)
-    srcs = [O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=60 + k) for k in range(8)]
-    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(8)]
+    srcs = [fresh_copies(O.lcg_frame(O.FORMATS[fmt], sw, sh, seed=60 + k)) for k in range(8)]
+    dsts = [fresh_planes(f.out_dims(), np.uint8) for _ in range(8)]
     gpu_pkg.transport_counts(reset=True)
     tickets = [f.submit(s, d) for s, d in zip(srcs, dsts)]
     for t in tickets:

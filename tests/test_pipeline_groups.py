@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host
+from conftest import assert_planes_equal, oracle_kwargs, to_device, to_host, fresh_copies, fresh_planes
 
 pytestmark = pytest.mark.gpu
 
@@ -63,12 +63,12 @@ def test_groups_of_every_fill_state_and_every_way_out(gpu_pkg, O, pooling_host):
     fmt, sw, sh, tw, th = "YUV420P8", 200, 120, 274, 164
     of = O.OracleFilter(O.FORMATS[fmt], sw, sh, tw, th)
     n = 45
-    srcs = _frames(O, fmt, sw, sh, n, 8100)
+    srcs = [fresh_copies(s) for s in _frames(O, fmt, sw, sh, n, 8100)]   # (planes the device maps: mappings of their own, conftest.fresh_mapping)
     want = [of.get_frame(s, threads=4) for s in srcs]
     f = gpu_pkg.Filter(gpu_pkg.FORMATS[fmt], sw, sh, tw, th, device=0)
     # (the registered shapes side by side and on the same planes: registered once for the three of them -- every registration is a
     # fresh mapping of heap pages into the device, tests/conftest.py)
-    dsts = [[gpu_pkg.alloc_plane(w, h, np.uint8) for (w, h) in f.out_dims()] for _ in range(n)]
+    dsts = [fresh_planes(f.out_dims(), np.uint8) for _ in range(n)]
     for depth, group, register in ((32, 16, False), (5, 2, False), (1, 0, False), (32, 0, True), (8, 8, True), (40, 20, True)):
         f.set_pipeline(depth, register, group)
         for d in dsts:

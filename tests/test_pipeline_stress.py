@@ -5,6 +5,8 @@ not arithmetic."""
 import numpy as np
 import pytest
 
+from conftest import fresh_copies, fresh_planes
+
 pytestmark = pytest.mark.gpu
 
 CASES = [
@@ -35,8 +37,12 @@ def test_many_frames_through_changing_pipeline_shapes(gpu_pkg, O, case, pooling_
         # would hand them out), so that a shape registers a few dozen planes once instead of 960 planes through a cache of 64 --
         # this test is after ordering, and every registration is a fresh mapping of heap pages into the device (tests/conftest.py).
         nb = depth + 2 if register else n
-        dsts = [[gpu_pkg.alloc_plane(w, h, np_dtype) for (w, h) in dims] for _ in range(nb)]
-        pool_srcs = [[np.empty_like(p) for p in srcs[0]] for _ in range(nb)] if register else None
+        if register:   # (planes the device maps: mappings of their own, conftest.fresh_mapping)
+            dsts = [fresh_planes(dims, np_dtype) for _ in range(nb)]
+            pool_srcs = [fresh_copies(srcs[0]) for _ in range(nb)]
+        else:
+            dsts = [[gpu_pkg.alloc_plane(w, h, np_dtype) for (w, h) in dims] for _ in range(nb)]
+            pool_srcs = None
         tickets, waiting, bad = {}, [], []
 
         def collect(j):
