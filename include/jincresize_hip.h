@@ -196,7 +196,10 @@ JINC_API int jinc_filter_get_frame(jinc_filter *f, const void *const src[4], con
  *      runtime consults its table of registered ranges for every host pointer it is handed, so a registration that outlives its
  *      pages makes a later buffer at those addresses travel through a dead mapping (a GPU memory access fault) or be refused
  *      (hipErrorInvalidValue when it starts inside the range and runs past its end) -- and the library cannot see a range that
- *      came back at the same addresses.
+ *      came back at the same addresses.  The frame memory should also OWN ITS PAGES (allocations of whole pages, as large frame
+ *      buffers are): planes carved out of the malloc heap share their first and last page with whatever else lives there, and
+ *      every GPU memory access fault the tests of this mode ran into in round 6 was on such a heap address; with the planes in
+ *      mappings of their own they did not recur (profiles/round6/README.md).
  *   Planes inside a range the caller pinned itself (jinc_filter_adopt_host_range) travel through that mapping in every mode.
  *   Round 6 also built, measured and withdrew "registered at submit, unregistered when the frame's wait returns" (4 508 C2
  *   frames/s): registration at frame rate.
