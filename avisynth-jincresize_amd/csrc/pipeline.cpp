@@ -287,7 +287,7 @@ void ensure_group(jinc_filter& f, FrameGroup& g) {
 // The default (register_host == 0).  Rounds 1 - 5 handed pageable planes to hipMemcpy2DAsync as they were; the runtime maps the
 // caller's pages into the device behind such a copy (2 MB in 46 us = 45 GB/s from "pageable" memory, first touch 77 - 126 us:
 // profiles/round6/pageable_rect_copy_probe.log) and the copy engine or a blit kernel reads them in place.  Full test runs of
-// round 6 ended in GPU memory access faults on HEAP addresses inside exactly those copies (4 of 13 runs, each time with no
+// round 6 ended in GPU memory access faults on HEAP addresses inside exactly those copies (4 of the first 13 runs, each time with no
 // registration of this library alive; profiles/round6/README.md), under every allocator setting tried, and the cause could not
 // be isolated (the probe's unmap / remap / register-over-it / many-streams scenarios all pass).  A library a video host loads
 // must not be able to take the host down with a GPU fault, so by default the device never sees the caller's pages at all:

@@ -17,8 +17,8 @@ except Exception:  # pragma: no cover
 # registration that outlives its pages faulted the GPU; round 6 found that faults on heap addresses also came from the HIP runtime's
 # OWN copies from pageable memory (it maps the caller's pages into the device behind hipMemcpy2DAsync), with and without those
 # options, 4 of 13 full runs, once in a plain measuring script, and later once inside PyTorch's own tensor.cpu() in a test helper with
-# the library idle and three times in one batch test under live cached registrations (always on long-used heap addresses; its planes
-# now come from fresh mappings) -- profiles/round6/README.md.  The product's answer is its
+# the library idle and four times in tests of the registering mode under live cached registrations (always on long-used heap
+# addresses: planes the device maps now come from mappings of their own, fresh_mapping below) -- profiles/round6/README.md.  The product's answer is its
 # default: pageable planes go through pinned buffers of the library's own and the device never maps the caller's pages, so the
 # 1 600 tests that use the default need no model of the host at all.  The handful that switch the instance to cached registrations
 # (or hand planes to the runtime) ask for the `pooling_host` fixture below: for THEIR duration the allocator behaves like a host
