@@ -17,7 +17,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_planes_equal, fresh_copies, fresh_planes
+from conftest import assert_planes_equal, fresh_copies, fresh_mapping, fresh_planes
 
 
 def _case(O):
@@ -187,22 +187,13 @@ def test_pageable_sources_with_results_into_memory_the_host_pinned(gpu_pkg, O):
     del host, pool
 
 
-def _fresh_mapping(nbytes):
-    """Bytes in an anonymous mapping of their own: addresses nothing in this process has registered before.  (The batch tests below
-    ended in GPU memory access faults 3 times in 9 full runs while their planes came from malloc -- each time on an address in a
-    long-used part of the heap, where earlier tests had registered and unregistered other buffers -- and never alone in a fresh
-    process: profiles/round6/README.md.)"""
-    import mmap
-    return np.frombuffer(mmap.mmap(-1, nbytes), np.uint8)
-
-
 def _batch_planes(gpu_pkg, O, fmt, sw, sh, tw, th, n, seed):
     ofmt = O.FORMATS[fmt]
     frames = [O.lcg_frame(ofmt, sw, sh, seed=seed + k) for k in range(n)]
     # source planes one after the other with odd gaps of a few hundred bytes (allocator headers, small objects in between): they
     # share pages with their neighbours and merge into few registrations
     room = sum(p.nbytes + 512 for fr in frames for p in fr) + 4096
-    src_pool = _fresh_mapping(room)
+    src_pool = fresh_mapping(room)
     srcs, off = [], 37
     for fr in frames:
         planes = []
@@ -216,7 +207,7 @@ def _batch_planes(gpu_pkg, O, fmt, sw, sh, tw, th, n, seed):
     # destination planes in ONE allocation, frame after frame (what a batch tool does): neighbouring chunks share pages
     pitches = [(w + 63) // 64 * 64 for (w, h) in ddims]
     per_frame = sum(p * h for p, (w, h) in zip(pitches, ddims))
-    pool = _fresh_mapping(per_frame * n + 4096)[64:]
+    pool = fresh_mapping(per_frame * n + 4096)[64:]
     dsts, off = [], 0
     for k in range(n):
         planes = []
